@@ -1,0 +1,1078 @@
+/*
+ * lcr_oracle.c -- CPU ORACLE (test infrastructure, see lcr_oracle.h for scope and parity status).
+ *
+ * Every function cites the reference lines it restates.  "MJ-DOC" marks statements about the
+ * absent third-party `mujoco` library taken from its public documentation (Computation chapter,
+ * XML reference); those cannot be checked in this image ("parity unpinned").
+ *
+ * The code is deliberately GENERIC and DENSE (world-frame Jacobian sums for the mass matrix, a dense
+ * constraint Jacobian, a dense Delassus matrix, generic Cholesky) so that it shares neither source
+ * nor formulation with the hand-unrolled, matrix-free HIP kernel it checks.
+ */
+#include "lcr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef orc_real real;
+
+/* ------------------------------------------------------------------------------------------------
+ * L0: model constants, transcribed from the MJCF (numbers only).
+ * follower.xml:3   integrator=implicitfast cone=elliptic impratio=100 timestep=0.002
+ * follower.xml:7   joint armature=0.1 damping=1 actuatorfrcrange=+-10
+ * follower.xml:8   position kp=1000 kv=10 inheritrange=1 (ctrlrange := joint range)
+ * follower.xml:51  base quat (-0.707 0 0 0.707)  == Rz(-90deg) after normalisation
+ * follower.xml:56-98 bodies / joints / inertials; :91 site
+ * ---------------------------------------------------------------------------------------------- */
+#define H_STEP 0.002
+#define ARMATURE 0.1
+#define DAMPING 1.0
+#define KP 1000.0
+#define KV 10.0
+#define FRC_LIM 10.0
+#define GRAV 9.81
+#define CUBE_HALF 0.015 /* reach_cube.xml:26 size="0.015 0.015 0.015" */
+#define MJ_MINVAL 1e-15
+#define MJ_MINIMP 0.0001
+#define MJ_MAXIMP 0.9999
+
+static const double LINK_POS[6][3] = {
+    {0.012, 0, 0.0409},          /* follower.xml:56 */
+    {0, -0.0209, 0.0154},        /* :63 */
+    {-0.0148, 0.0065, 0.1083},   /* :70 */
+    {-0.10048, 5e-05, 0.0026999},/* :77 */
+    {-0.045, 0.013097, 0},       /* :84 */
+    {-0.01315, -0.0075, 0.0145}, /* :93 */
+};
+static const double LINK_AXIS[6][3] = {
+    {0, 0, -1}, {0, 1, 0}, {0, -1, 0}, {0, 1, 0}, {1, 0, 0}, {0, 0, -1}, /* :58,65,72,79,86,95 */
+};
+static const double LINK_IPOS[6][3] = {
+    {0.011924, -0.00048792, 0.013381}, {0.0011747, 0.02097, 0.071547},  {-0.05537, 0.014505, 0.0028659},
+    {-0.02652, 0.019195, -9.0614e-06}, {-0.019091, 0.0053379, 0.00018011}, {-0.02507, 0.0010817, -0.01414},
+};
+static const double LINK_IQUAT[6][4] = {
+    {-0.0190903, 0.705417, 0.0178052, 0.708312},   {0.998768, 2.01447e-05, 0.0496266, 0.000367169},
+    {8.17663e-05, 0.710999, -4.16983e-05, 0.703193}, {0.707361, 0.706812, 0.00580344, 0.00484124},
+    {0.105295, 0.703509, -0.0986543, 0.695885},    {0.528148, 0.5474, 0.466496, 0.451436},
+};
+static const double LINK_MASS[6] = {0.05014, 0.050177, 0.06379, 0.019805, 0.029277, 0.012831};
+static const double LINK_DIAGI[6][3] = {
+    {1.44921e-05, 1.2371e-05, 7.59138e-06}, {3.73065e-05, 3.3772e-05, 7.94901e-06},
+    {2.45081e-05, 2.2231e-05, 7.34061e-06}, {2.95813e-06, 2.8759e-06, 1.07787e-06},
+    {8.11303e-06, 7.14908e-06, 3.27429e-06}, {3.49922e-06, 2.45768e-06, 1.4645e-06},
+};
+/* follower.xml:58-95 joint ranges (== actuator ctrlrange through inheritrange) */
+static const double JNT_LO[6] = {-3.14, -3.14, -3.14, -3.14, -3.14, -2.45};
+static const double JNT_HI[6] = {3.14, 3.14, 3.14, 3.14, 3.14, 0.032};
+/* reach_cube_env.py:249-250 hard-coded joint-mode clip (REF-QUIRK-6) */
+static const double TGT_LO[6] = {-3.14159, -1.5708, -1.48353, -1.91986, -2.96706, -1.74533};
+static const double TGT_HI[6] = {3.14159, 1.22173, 1.74533, 1.91986, 2.96706, 0.0523599};
+static const double SITE_POS[3] = {-0.06429, 0.00327, 0.0011}; /* follower.xml:91, on link_5 */
+
+/* (D3) finger proxies: spheres fitted to the fixed-finger part of the link_5_collision hull and to the
+ * jaw tip of the link_6_collision hull (follower.xml:89,97; extents in SURVEY.md 8(c)).
+ * {link index 0..5, centre in link frame, radius} */
+static const int SPH_LINK[4] = {4, 4, 5, 5};
+static const double SPH_POS[4][3] = {
+    {-0.0620, 0.0140, 0.0005}, {-0.0440, 0.0150, 0.0000}, {-0.0500, 0.0075, -0.0140}, {-0.0350, 0.0012, -0.0140}};
+static const double SPH_RAD[4] = {0.0057, 0.0057, 0.0057, 0.0060};
+
+/* default solver parameters (MJ-DOC XML reference): solref=(0.02,1) solimp=(0.9,0.95,0.001,0.5,2) */
+static const double SOLREF[2] = {0.02, 1.0};
+static const double SOLIMP_DEFAULT[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+/* follower.xml:15 finger class solimp="0.015 1 0.036" (trailing values default), friction 1.5, priority 1 */
+static const double SOLIMP_FINGER[5] = {0.015, 1.0, 0.036, 0.5, 2.0};
+/* P9: cube (priority 1) vs finger (priority 1): equal priority -> solimp averaged (solmix 1:1), friction max */
+static const double SOLIMP_FINGER_CUBE[5] = {0.4575, 0.975, 0.0185, 0.5, 2.0};
+static const double MU_CUBE[3] = {0.5, 0.5, 0.005};   /* reach_cube.xml:26 friction="0.5" (+default torsional) */
+static const double MU_FINGER[3] = {1.5, 1.5, 0.005}; /* follower.xml:15 friction="1.5" */
+
+typedef struct {
+    int ncube;
+    double cube_mass, cube_inertia;
+    int has_target;
+} task_model;
+
+static task_model get_task_model(int task) {
+    task_model t;
+    t.ncube = 1;
+    t.cube_mass = 0.1;          /* reach_cube.xml:25, lift_cube.xml:27, push_cube.xml:27 */
+    t.cube_inertia = 0.00016667;
+    t.has_target = 0;
+    if (task == ORC_TASK_PICK_PLACE) { t.cube_mass = 10.0; t.has_target = 1; } /* pick_place_cube.xml:27 REF-QUIRK-4 */
+    if (task == ORC_TASK_PUSH) t.has_target = 1;
+    if (task == ORC_TASK_STACK) { t.ncube = 2; t.cube_inertia = 0.00001125; }   /* stack_two_cubes.xml:27,33 */
+    return t;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small linear algebra                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+static inline void v3set(real *a, real x, real y, real z) { a[0] = x; a[1] = y; a[2] = z; }
+static inline void v3copy(real *a, const real *b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static inline void v3add(real *o, const real *a, const real *b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; }
+static inline void v3sub(real *o, const real *a, const real *b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static inline void v3axpy(real *o, real s, const real *b) { o[0] += s * b[0]; o[1] += s * b[1]; o[2] += s * b[2]; }
+static inline real v3dot(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void v3cross(real *o, const real *a, const real *b) {
+    real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real v3norm(const real *a) { return (real)sqrt((double)v3dot(a, a)); }
+/* o = R v  (R row-major 3x3) */
+static inline void m3v(real *o, const real *R, const real *v) {
+    real x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    real y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    real z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3tv(real *o, const real *R, const real *v) {
+    real x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+    real y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+    real z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3mul(real *o, const real *A, const real *B) {
+    real t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    memcpy(o, t, sizeof t);
+}
+static void quat2mat(real *R, const real *q) { /* q = (w,x,y,z), unit */
+    real w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void axisangle2mat(real *R, const real *a, real th) { /* Rodrigues, |a| = 1 */
+    real c = (real)cos((double)th), s = (real)sin((double)th), C = 1 - c;
+    R[0] = c + a[0] * a[0] * C;        R[1] = a[0] * a[1] * C - a[2] * s; R[2] = a[0] * a[2] * C + a[1] * s;
+    R[3] = a[1] * a[0] * C + a[2] * s; R[4] = c + a[1] * a[1] * C;        R[5] = a[1] * a[2] * C - a[0] * s;
+    R[6] = a[2] * a[0] * C - a[1] * s; R[7] = a[2] * a[1] * C + a[0] * s; R[8] = c + a[2] * a[2] * C;
+}
+/* dense Cholesky A = L L^T in place (lower), n <= ORC_NV_MAX; returns 0 on success */
+static int chol(real *A, int n) {
+    for (int j = 0; j < n; j++) {
+        real d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+        if (!(d > 0)) return -1;
+        d = (real)sqrt((double)d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            real s = A[i * n + j];
+            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const real *L, int n, real *x) { /* x <- (L L^T)^-1 x */
+    for (int i = 0; i < n; i++) {
+        real s = x[i];
+        for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        real s = x[i];
+        for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* kinematics (MJ-DOC mj_kinematics + mj_comPos for this fixed tree)                                */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    real R[7][9]; /* [0] base_link, [i] link_i */
+    real p[7][3];
+    real z[6][3];   /* world joint axes */
+    real com[6][3]; /* world inertial-frame origins (xipos) */
+    real Iw[6][9];  /* world inertia about com */
+    real site[3];
+    real sph[4][3];
+    int ncube;
+    real cR[2][9], cp[2][3];
+} kin_t;
+
+static void arm_kinematics(const real *q, kin_t *K) {
+    /* base: follower.xml:51 quat normalised = (-sqrt.5,0,0,sqrt.5) -> [[0,1,0],[-1,0,0],[0,0,1]] */
+    real bq[4] = {(real)-0.707, 0, 0, (real)0.707};
+    real nn = (real)sqrt((double)(bq[0] * bq[0] + bq[3] * bq[3]));
+    bq[0] /= nn; bq[3] /= nn;
+    quat2mat(K->R[0], bq);
+    v3set(K->p[0], 0, 0, 0);
+    for (int i = 0; i < 6; i++) {
+        real lp[3] = {(real)LINK_POS[i][0], (real)LINK_POS[i][1], (real)LINK_POS[i][2]};
+        real ax[3] = {(real)LINK_AXIS[i][0], (real)LINK_AXIS[i][1], (real)LINK_AXIS[i][2]};
+        real t[3], Rl[9];
+        m3v(t, K->R[i], lp);
+        v3add(K->p[i + 1], K->p[i], t);
+        axisangle2mat(Rl, ax, q[i]);
+        m3mul(K->R[i + 1], K->R[i], Rl);
+        m3v(K->z[i], K->R[i + 1], ax);
+        real ip[3] = {(real)LINK_IPOS[i][0], (real)LINK_IPOS[i][1], (real)LINK_IPOS[i][2]};
+        m3v(t, K->R[i + 1], ip);
+        v3add(K->com[i], K->p[i + 1], t);
+        /* world inertia: Rw = R * Riq ; Iw = Rw diag Rw^T */
+        real iq[4], n2 = 0, Riq[9], Rw[9];
+        for (int k = 0; k < 4; k++) { iq[k] = (real)LINK_IQUAT[i][k]; n2 += iq[k] * iq[k]; }
+        n2 = (real)sqrt((double)n2);
+        for (int k = 0; k < 4; k++) iq[k] /= n2;
+        quat2mat(Riq, iq);
+        m3mul(Rw, K->R[i + 1], Riq);
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                real s = 0;
+                for (int k = 0; k < 3; k++) s += Rw[3 * a + k] * (real)LINK_DIAGI[i][k] * Rw[3 * b + k];
+                K->Iw[i][3 * a + b] = s;
+            }
+    }
+    real sp[3] = {(real)SITE_POS[0], (real)SITE_POS[1], (real)SITE_POS[2]}, t[3];
+    m3v(t, K->R[5], sp);
+    v3add(K->site, K->p[5], t);
+    for (int s = 0; s < 4; s++) {
+        real c[3] = {(real)SPH_POS[s][0], (real)SPH_POS[s][1], (real)SPH_POS[s][2]};
+        m3v(t, K->R[SPH_LINK[s] + 1], c);
+        v3add(K->sph[s], K->p[SPH_LINK[s] + 1], t);
+    }
+}
+
+/* point Jacobians of body b (0..5 arm link, 6/7 cube) at world point pt: Jp,Jr are [3][nv] */
+static void jac_point(const kin_t *K, int nv, int b, const real *pt, real *Jp, real *Jr) {
+    memset(Jp, 0, sizeof(real) * 3 * nv);
+    memset(Jr, 0, sizeof(real) * 3 * nv);
+    if (b < 0) return;
+    if (b < 6) {
+        for (int j = 0; j <= b; j++) {
+            real r[3], c[3];
+            v3sub(r, pt, K->p[j + 1]);
+            v3cross(c, K->z[j], r);
+            for (int k = 0; k < 3; k++) { Jp[k * nv + j] = c[k]; Jr[k * nv + j] = K->z[j][k]; }
+        }
+    } else {
+        int c = b - 6, o = 6 + 6 * c;
+        real r[3];
+        v3sub(r, pt, K->cp[c]);
+        for (int i = 0; i < 3; i++) {
+            Jp[i * nv + o + i] = 1; /* linear dofs: world frame */
+            real col[3] = {K->cR[c][i], K->cR[c][3 + i], K->cR[c][6 + i]}, cr[3]; /* R e_i */
+            v3cross(cr, col, r); /* d(v_pt)/d(omega_body_i) = (R e_i) x r   (MJ-DOC: free-joint angular dofs are body-frame) */
+            for (int k = 0; k < 3; k++) { Jp[k * nv + o + 3 + i] = cr[k]; Jr[k * nv + o + 3 + i] = col[k]; }
+        }
+    }
+}
+
+/* arm joint-space inertia: M = sum_i m_i Jv_i^T Jv_i + Jw_i^T I_i Jw_i (+ armature)  (== MJ-DOC CRBA result) */
+static void arm_mass(const kin_t *K, int with_armature, real *M /*6x6*/) {
+    memset(M, 0, sizeof(real) * 36);
+    for (int i = 0; i < 6; i++) {
+        real Jp[18], Jr[18];
+        jac_point(K, 6, i, K->com[i], Jp, Jr);
+        for (int a = 0; a <= i; a++)
+            for (int b = 0; b <= i; b++) {
+                real s = 0;
+                for (int k = 0; k < 3; k++) s += (real)LINK_MASS[i] * Jp[k * 6 + a] * Jp[k * 6 + b];
+                for (int k = 0; k < 3; k++)
+                    for (int l = 0; l < 3; l++) s += Jr[k * 6 + a] * K->Iw[i][3 * k + l] * Jr[l * 6 + b];
+                M[a * 6 + b] += s;
+            }
+    }
+    if (with_armature)
+        for (int j = 0; j < 6; j++) M[j * 6 + j] += (real)ARMATURE;
+}
+
+/* arm bias forces c(q,qd) incl. gravity: recursive Newton-Euler with zero joint acceleration (MJ-DOC mj_rne) */
+static void arm_bias(const kin_t *K, const real *qd, real *bias) {
+    real w[7][3], wd[7][3], a[7][3]; /* angular vel/acc, linear acc of body origin */
+    real F[6][3], N[6][3];
+    v3set(w[0], 0, 0, 0); v3set(wd[0], 0, 0, 0); v3set(a[0], 0, 0, (real)GRAV);
+    for (int i = 0; i < 6; i++) {
+        real zq[3] = {K->z[i][0] * qd[i], K->z[i][1] * qd[i], K->z[i][2] * qd[i]}, t[3], r[3];
+        v3add(w[i + 1], w[i], zq);
+        v3cross(t, w[i], zq);
+        v3add(wd[i + 1], wd[i], t);
+        v3sub(r, K->p[i + 1], K->p[i]);
+        v3cross(t, wd[i], r);
+        v3add(a[i + 1], a[i], t);
+        real wr[3];
+        v3cross(wr, w[i], r);
+        v3cross(t, w[i], wr);
+        v3add(a[i + 1], a[i + 1], t);
+        /* com acceleration */
+        real rc[3], ac[3];
+        v3sub(rc, K->com[i], K->p[i + 1]);
+        v3cross(t, wd[i + 1], rc);
+        v3add(ac, a[i + 1], t);
+        v3cross(wr, w[i + 1], rc);
+        v3cross(t, w[i + 1], wr);
+        v3add(ac, ac, t);
+        for (int k = 0; k < 3; k++) F[i][k] = (real)LINK_MASS[i] * ac[k];
+        real Iw_[3], Iwd[3];
+        m3v(Iw_, K->Iw[i], w[i + 1]);
+        m3v(Iwd, K->Iw[i], wd[i + 1]);
+        v3cross(t, w[i + 1], Iw_);
+        v3add(N[i], Iwd, t);
+    }
+    real f[3] = {0, 0, 0}, n[3] = {0, 0, 0}; /* force/torque transmitted through joint i+1, torque about p[i+2] */
+    for (int i = 5; i >= 0; i--) {
+        /* n_i (about p[i+1]) = N_i + (com - p) x F_i + n_{i+1} + (p_{i+2} - p_{i+1}) x f_{i+1} */
+        real rc[3], t[3], nn[3];
+        v3sub(rc, K->com[i], K->p[i + 1]);
+        v3cross(t, rc, F[i]);
+        v3add(nn, N[i], t);
+        if (i < 5) {
+            real r[3];
+            v3sub(r, K->p[i + 2], K->p[i + 1]);
+            v3cross(t, r, f);
+            v3add(nn, nn, t);
+            v3add(nn, nn, n);
+        }
+        v3add(f, f, F[i]);
+        v3copy(n, nn);
+        bias[i] = v3dot(K->z[i], n);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* constraint model (MJ-DOC "soft constraint model", engine_core_constraint semantics)              */
+/* ------------------------------------------------------------------------------------------------ */
+static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* impedance d(r) and spring-damper (k,b) from solref/solimp; MJ-DOC "Solver parameters" */
+static void kbi(const double *solref, const double *solimp, double pos, double *k, double *b, double *imp) {
+    double d0 = clampd(solimp[0], MJ_MINIMP, MJ_MAXIMP), dw = clampd(solimp[1], MJ_MINIMP, MJ_MAXIMP);
+    double width = solimp[2] > MJ_MINVAL ? solimp[2] : MJ_MINVAL;
+    double mid = clampd(solimp[3], MJ_MINIMP, MJ_MAXIMP), power = solimp[4] < 1 ? 1 : solimp[4];
+    *k = 1.0 / (dw * dw * solref[0] * solref[0] * solref[1] * solref[1]);
+    *b = 2.0 / (dw * solref[0]);
+    if (d0 == dw || width <= MJ_MINVAL) { *imp = 0.5 * (d0 + dw); return; }
+    double x = fabs(pos) / width, y;
+    if (x > 1) x = 1;
+    if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+    else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+    *imp = d0 + y * (dw - d0);
+}
+
+/* contact frame from normal (MJ-DOC mju_makeFrame): rows n, t1, t2 */
+static void make_frame(real *fr /*[9]*/, const real *n) {
+    v3copy(fr, n);
+    real y[3] = {0, 0, 0};
+    if (n[1] < (real)0.5 && n[1] > (real)-0.5) y[1] = 1; else y[2] = 1;
+    real d = v3dot(n, y);
+    v3axpy(y, -d, n);
+    real l = v3norm(y);
+    for (int k = 0; k < 3; k++) fr[3 + k] = y[k] / l;
+    v3cross(fr + 6, fr, fr + 3);
+}
+
+typedef struct {
+    int b1, b2;       /* body ids: -1 world, 0..5 arm link, 6,7 cubes; frame normal points b1 -> b2 */
+    real pos[3], frame[9], dist;
+    const double *mu; /* [3] tan, tan, torsional */
+    const double *solimp;
+} contact_t;
+
+#define MAX_CONTACTS (8 + 8 + ORC_MAX_ARM_CONTACTS)
+#define MAX_ROWS (12 + 4 * MAX_CONTACTS)
+
+/* plane z=0 (geom1, world) vs box (geom2): MJ-DOC mjc_PlaneBox -- vertex i=(+-,+-,+-) by bits 0,1,2;
+ * contact where vertex height <= 0... margin 0 => strictly below counts (dist<0); at most 4; pos midway */
+static int collide_plane_box(const kin_t *K, int c, contact_t *out) {
+    int n = 0;
+    for (int i = 0; i < 8 && n < 4; i++) {
+        real v[3] = {(i & 1) ? (real)CUBE_HALF : (real)-CUBE_HALF, (i & 2) ? (real)CUBE_HALF : (real)-CUBE_HALF,
+                     (i & 4) ? (real)CUBE_HALF : (real)-CUBE_HALF}, w[3];
+        m3v(w, K->cR[c], v);
+        v3add(w, w, K->cp[c]);
+        real dist = w[2];
+        if (!(dist < 0)) continue;
+        contact_t *ct = &out[n++];
+        ct->b1 = -1; ct->b2 = 6 + c; ct->dist = dist;
+        v3set(ct->pos, w[0], w[1], w[2] - dist * (real)0.5);
+        real nz[3] = {0, 0, 1};
+        make_frame(ct->frame, nz);
+        ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT; /* P9: cube priority 1 beats floor priority 0 */
+    }
+    return n;
+}
+/* box c (geom1) vs finger sphere s (geom2) -- (D3) */
+static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
+    real d[3], l[3], q[3];
+    v3sub(d, K->sph[s], K->cp[c]);
+    m3tv(l, K->cR[c], d);
+    int outside = 0;
+    for (int k = 0; k < 3; k++) {
+        q[k] = l[k];
+        if (l[k] > (real)CUBE_HALF) { q[k] = (real)CUBE_HALF; outside = 1; }
+        if (l[k] < (real)-CUBE_HALF) { q[k] = (real)-CUBE_HALF; outside = 1; }
+    }
+    real nl[3], dist;
+    if (outside) {
+        real df[3];
+        v3sub(df, l, q);
+        real dn = v3norm(df);
+        dist = dn - (real)SPH_RAD[s];
+        if (!(dist < 0)) return 0;
+        for (int k = 0; k < 3; k++) nl[k] = df[k] / dn;
+    } else {
+        int best = 0; real bd = (real)CUBE_HALF - (real)fabs((double)l[0]);
+        for (int k = 1; k < 3; k++) { real dk = (real)CUBE_HALF - (real)fabs((double)l[k]); if (dk < bd) { bd = dk; best = k; } }
+        real sg = l[best] < 0 ? (real)-1 : (real)1;
+        v3set(nl, 0, 0, 0); nl[best] = sg;
+        q[best] = sg * (real)CUBE_HALF;
+        dist = -(bd + (real)SPH_RAD[s]);
+    }
+    real pl[3] = {q[0] + nl[0] * dist * (real)0.5, q[1] + nl[1] * dist * (real)0.5, q[2] + nl[2] * dist * (real)0.5};
+    real nw[3], pw[3];
+    m3v(nw, K->cR[c], nl);
+    m3v(pw, K->cR[c], pl);
+    v3add(ct->pos, pw, K->cp[c]);
+    make_frame(ct->frame, nw);
+    ct->b1 = 6 + c; ct->b2 = SPH_LINK[s]; ct->dist = dist;
+    ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER_CUBE;
+    return 1;
+}
+static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
+    real dist = K->sph[s][2] - (real)SPH_RAD[s];
+    if (!(dist < 0)) return 0;
+    v3set(ct->pos, K->sph[s][0], K->sph[s][1], dist * (real)0.5);
+    real nz[3] = {0, 0, 1};
+    make_frame(ct->frame, nz);
+    ct->b1 = -1; ct->b2 = SPH_LINK[s]; ct->dist = dist;
+    ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
+    return 1;
+}
+/* (D5) box0 (geom1) vs box1 (geom2): face axis of minimum overlap among the 6 face normals, then the
+ * vertices of each box that lie below the other's reference face inside its footprint; <= 4 + 4 points */
+static int collide_box_box(const kin_t *K, contact_t *out) {
+    const real h = (real)CUBE_HALF;
+    real dc[3];
+    v3sub(dc, K->cp[1], K->cp[0]);
+    real best = (real)-1e30; int bax = -1; real bsgn = 1; /* axis id 0..2 on box0, 3..5 on box1 */
+    for (int ax = 0; ax < 6; ax++) {
+        int bx = ax / 3, k = ax % 3;
+        real n[3] = {K->cR[bx][k], K->cR[bx][3 + k], K->cR[bx][6 + k]};
+        int ob = 1 - bx;
+        real ext = 0;
+        for (int j = 0; j < 3; j++) {
+            real col[3] = {K->cR[ob][j], K->cR[ob][3 + j], K->cR[ob][6 + j]};
+            ext += (real)fabs((double)v3dot(n, col)) * h;
+        }
+        real dd = v3dot(n, dc);
+        real sep = (real)fabs((double)dd) - h - ext; /* >0 separated */
+        if (sep > best) { best = sep; bax = ax; bsgn = dd < 0 ? (real)-1 : (real)1; }
+    }
+    if (!(best < 0)) return 0;
+    int k = bax % 3, bx = bax / 3;
+    real n[3] = {K->cR[bx][k] * bsgn, K->cR[bx][3 + k] * bsgn, K->cR[bx][6 + k] * bsgn}; /* points box0 -> box1 */
+    int cnt = 0;
+    const real tol = (real)1e-4; /* footprint tolerance so that exactly aligned faces keep their corners */
+    for (int pass = 0; pass < 2; pass++) {
+        int inc = pass == 0 ? 1 : 0, ref = 1 - inc; /* vertices of `inc` against `ref` */
+        int m = 0;
+        for (int i = 0; i < 8 && m < 4; i++) {
+            real v[3] = {(i & 1) ? h : -h, (i & 2) ? h : -h, (i & 4) ? h : -h}, w[3], d[3], l[3];
+            m3v(w, K->cR[inc], v);
+            v3add(w, w, K->cp[inc]);
+            v3sub(d, w, K->cp[ref]);
+            m3tv(l, K->cR[ref], d);
+            if ((real)fabs((double)l[0]) > h + tol || (real)fabs((double)l[1]) > h + tol || (real)fabs((double)l[2]) > h + tol) continue;
+            /* depth along n measured from ref's face */
+            real nd = v3dot(n, d);
+            real refext = 0;
+            for (int j = 0; j < 3; j++) {
+                real col[3] = {K->cR[ref][j], K->cR[ref][3 + j], K->cR[ref][6 + j]};
+                refext += (real)fabs((double)v3dot(n, col)) * h;
+            }
+            real dist = (ref == 0) ? (nd - refext) : (-nd - refext);
+            if (!(dist < 0)) continue;
+            contact_t *ct = &out[cnt++]; m++;
+            ct->b1 = 6; ct->b2 = 7; ct->dist = dist;
+            real sh = (ref == 0) ? -dist * (real)0.5 : dist * (real)0.5;
+            v3set(ct->pos, w[0] + n[0] * sh, w[1] + n[1] * sh, w[2] + n[2] * sh);
+            make_frame(ct->frame, n);
+            ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT;
+        }
+    }
+    return cnt;
+}
+
+/* precomputed at qpos0 (MJ-DOC body_invweight0 / dof_invweight0, used by diagApprox) */
+static double g_inv_tran[6], g_inv_rot[6], g_inv_dof[6];
+static int g_inv_ready = 0;
+static void ensure_invweight0(void) {
+    if (g_inv_ready) return;
+#ifdef _OPENMP
+#pragma omp critical(orc_invw)
+#endif
+    {
+        if (!g_inv_ready) {
+            real q[6] = {0, 0, 0, 0, 0, 0}, M[36], L[36];
+            kin_t K;
+            arm_kinematics(q, &K);
+            arm_mass(&K, 1, M);
+            memcpy(L, M, sizeof L);
+            chol(L, 6);
+            for (int j = 0; j < 6; j++) {
+                real e[6] = {0, 0, 0, 0, 0, 0};
+                e[j] = 1;
+                chol_solve(L, 6, e);
+                g_inv_dof[j] = (double)e[j];
+            }
+            for (int b = 0; b < 6; b++) {
+                real Jp[18], Jr[18];
+                jac_point(&K, 6, b, K.com[b], Jp, Jr);
+                double tr = 0, rr = 0;
+                for (int k = 0; k < 3; k++) {
+                    real x[6], y[6];
+                    for (int j = 0; j < 6; j++) { x[j] = Jp[k * 6 + j]; y[j] = Jr[k * 6 + j]; }
+                    real x0[6], y0[6];
+                    memcpy(x0, x, sizeof x); memcpy(y0, y, sizeof y);
+                    chol_solve(L, 6, x); chol_solve(L, 6, y);
+                    for (int j = 0; j < 6; j++) { tr += (double)(x0[j] * x[j]); rr += (double)(y0[j] * y[j]); }
+                }
+                g_inv_tran[b] = tr / 3; g_inv_rot[b] = rr / 3;
+            }
+            g_inv_ready = 1;
+        }
+    }
+}
+static void body_invweight(const task_model *T, int b, double *tr, double *ro) {
+    if (b < 0) { *tr = 0; *ro = 0; }
+    else if (b < 6) { *tr = g_inv_tran[b]; *ro = g_inv_rot[b]; }
+    else { *tr = 1.0 / T->cube_mass; *ro = 1.0 / T->cube_inertia; }
+}
+
+static int g_diag_rows, g_diag_contacts;
+static double g_diag_res;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* one physics substep == mujoco.mj_step (reach_cube_env.py:276-277) -- MJ-DOC restatement          */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct { real ee[3]; real cube[2][3]; } lag_t;
+
+static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
+                    int diag) {
+    const int nc = T->ncube, nv = 6 + 6 * nc;
+    const real h = (real)H_STEP;
+    kin_t K;
+    /* -- position stage: normalise quaternions, kinematics */
+    K.ncube = nc;
+    for (int c = 0; c < nc; c++) {
+        real *qq = qpos + 6 + 7 * c + 3, n2 = 0;
+        for (int k = 0; k < 4; k++) n2 += qq[k] * qq[k];
+        n2 = (real)sqrt((double)n2);
+        for (int k = 0; k < 4; k++) qq[k] /= n2;
+        quat2mat(K.cR[c], qq);
+        v3copy(K.cp[c], qpos + 6 + 7 * c);
+    }
+    arm_kinematics(qpos, &K);
+    /* P8: what data.site_xpos / data.xpos hold after this mj_step returns */
+    v3copy(lag->ee, K.site);
+    for (int c = 0; c < nc; c++) v3copy(lag->cube[c], K.cp[c]);
+
+    /* -- inertia */
+    real M[ORC_NV_MAX * ORC_NV_MAX], L[ORC_NV_MAX * ORC_NV_MAX], Ma[36];
+    memset(M, 0, sizeof M);
+    arm_mass(&K, 1, Ma);
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) M[i * nv + j] = Ma[i * 6 + j];
+    for (int c = 0; c < nc; c++)
+        for (int k = 0; k < 3; k++) {
+            M[(6 + 6 * c + k) * nv + 6 + 6 * c + k] = (real)T->cube_mass;
+            M[(9 + 6 * c + k) * nv + 9 + 6 * c + k] = (real)T->cube_inertia;
+        }
+    memcpy(L, M, sizeof(real) * nv * nv);
+    chol(L, nv);
+
+    /* -- velocity stage + actuation: qfrc_smooth = passive - bias + actuator */
+    real tau[ORC_NV_MAX], bias[6];
+    arm_bias(&K, qvel, bias);
+    for (int j = 0; j < 6; j++) {
+        real c = ctrl[j];
+        if (c < (real)JNT_LO[j]) c = (real)JNT_LO[j]; /* ctrlrange clamp (inheritrange) */
+        if (c > (real)JNT_HI[j]) c = (real)JNT_HI[j];
+        real f = (real)KP * (c - qpos[j]) - (real)KV * qvel[j]; /* position actuator: gain kp, bias (0,-kp,-kv) */
+        if (f > (real)FRC_LIM) f = (real)FRC_LIM;               /* actuatorfrcrange */
+        if (f < (real)-FRC_LIM) f = (real)-FRC_LIM;
+        tau[j] = -(real)DAMPING * qvel[j] + f - bias[j];
+    }
+    for (int c = 0; c < nc; c++) {
+        real *t = tau + 6 + 6 * c;
+        t[0] = 0; t[1] = 0; t[2] = -(real)T->cube_mass * (real)GRAV; /* isotropic inertia: no gyroscopic term */
+        t[3] = t[4] = t[5] = 0;
+    }
+    real a0[ORC_NV_MAX];
+    memcpy(a0, tau, sizeof(real) * nv);
+    chol_solve(L, nv, a0); /* qacc_smooth */
+
+    /* -- collision (D3, D5) in fixed order: floor-cube(s), cube-cube, sphere-cube, sphere-floor */
+    contact_t con[MAX_CONTACTS];
+    int ncon = 0;
+    for (int c = 0; c < nc; c++) ncon += collide_plane_box(&K, c, con + ncon);
+    if (nc == 2) ncon += collide_box_box(&K, con + ncon);
+    int narm = 0;
+    for (int c = 0; c < nc; c++)
+        for (int s = 0; s < 4; s++)
+            if (narm < ORC_MAX_ARM_CONTACTS && collide_box_sphere(&K, c, s, con + ncon)) { ncon++; narm++; }
+    for (int s = 0; s < 4; s++)
+        if (narm < ORC_MAX_ARM_CONTACTS && collide_plane_sphere(&K, s, con + ncon)) { ncon++; narm++; }
+
+    /* -- constraint rows: joint limits first, then contacts (4 rows each: n, t1, t2, torsion) */
+    static const int ROWDIM = 4;
+    real J[MAX_ROWS * ORC_NV_MAX], aref[MAX_ROWS], Rr[MAX_ROWS];
+    int kind[MAX_ROWS]; /* 0 limit, 1 contact-normal (block start), 2 friction */
+    const double *rowmu[MAX_ROWS];
+    int nr = 0;
+    memset(J, 0, sizeof J);
+    for (int j = 0; j < 6; j++)
+        for (int side = 0; side < 2; side++) {
+            real pos = side == 0 ? qpos[j] - (real)JNT_LO[j] : (real)JNT_HI[j] - qpos[j];
+            if (!(pos < 0)) continue;
+            real sg = side == 0 ? (real)1 : (real)-1;
+            J[nr * nv + j] = sg;
+            double k, b, imp;
+            kbi(SOLREF, SOLIMP_DEFAULT, (double)pos, &k, &b, &imp);
+            real vel = sg * qvel[j];
+            aref[nr] = (real)(-b * (double)vel - k * imp * (double)pos);
+            double r = (1 - imp) / imp * g_inv_dof[j];
+            Rr[nr] = (real)(r > MJ_MINVAL ? r : MJ_MINVAL);
+            kind[nr] = 0; rowmu[nr] = 0;
+            nr++;
+        }
+    for (int ci = 0; ci < ncon; ci++) {
+        contact_t *ct = &con[ci];
+        real Jp1[3 * ORC_NV_MAX], Jr1[3 * ORC_NV_MAX], Jp2[3 * ORC_NV_MAX], Jr2[3 * ORC_NV_MAX];
+        jac_point(&K, nv, ct->b1, ct->pos, Jp1, Jr1);
+        jac_point(&K, nv, ct->b2, ct->pos, Jp2, Jr2);
+        double k, b, imp, t1, r1, t2, r2;
+        kbi(SOLREF, ct->solimp, (double)ct->dist, &k, &b, &imp);
+        body_invweight(T, ct->b1, &t1, &r1);
+        body_invweight(T, ct->b2, &t2, &r2);
+        double Rn = (1 - imp) / imp * (t1 + t2);
+        if (Rn < MJ_MINVAL) Rn = MJ_MINVAL;
+        double impr = P->impratio > MJ_MINVAL ? P->impratio : MJ_MINVAL;
+        double Rf = Rn / impr; /* elliptic cone: friction rows regularised by R/impratio, scaled mu0^2/mu_j^2 */
+        for (int r = 0; r < ROWDIM; r++) {
+            real *Jrow = J + (size_t)(nr + r) * nv;
+            const real *fr = ct->frame + 3 * (r < 3 ? r : 0);
+            for (int d = 0; d < nv; d++) {
+                real s = 0;
+                if (r < 3) for (int k3 = 0; k3 < 3; k3++) s += fr[k3] * (Jp2[k3 * nv + d] - Jp1[k3 * nv + d]);
+                else for (int k3 = 0; k3 < 3; k3++) s += fr[k3] * (Jr2[k3 * nv + d] - Jr1[k3 * nv + d]);
+                Jrow[d] = s;
+            }
+            real vel = 0;
+            for (int d = 0; d < nv; d++) vel += Jrow[d] * qvel[d];
+            double posr = r == 0 ? (double)ct->dist : 0.0;
+            aref[nr + r] = (real)(-b * (double)vel - k * imp * posr);
+            double Rrow = r == 0 ? Rn : Rf * ct->mu[0] * ct->mu[0] / (ct->mu[r - 1] * ct->mu[r - 1]);
+            Rr[nr + r] = (real)Rrow;
+            kind[nr + r] = r == 0 ? 1 : 2;
+            rowmu[nr + r] = ct->mu;
+        }
+        nr += ROWDIM;
+    }
+
+    /* -- dual problem: A = J M^-1 J^T, b = J a0 - aref ; PGS, cold start, fixed iterations (D1, D2) */
+    real f[MAX_ROWS];
+    real qfc[ORC_NV_MAX];
+    memset(qfc, 0, sizeof qfc);
+    if (nr > 0) {
+        real *MiJt = (real *)malloc(sizeof(real) * (size_t)nr * nv);
+        real *A = (real *)malloc(sizeof(real) * (size_t)nr * nr);
+        real bvec[MAX_ROWS];
+        for (int i = 0; i < nr; i++) {
+            memcpy(MiJt + (size_t)i * nv, J + (size_t)i * nv, sizeof(real) * nv);
+            chol_solve(L, nv, MiJt + (size_t)i * nv);
+        }
+        for (int i = 0; i < nr; i++) {
+            for (int j = 0; j < nr; j++) {
+                real s = 0;
+                for (int d = 0; d < nv; d++) s += J[(size_t)i * nv + d] * MiJt[(size_t)j * nv + d];
+                A[(size_t)i * nr + j] = s;
+            }
+            real s = 0;
+            for (int d = 0; d < nv; d++) s += J[(size_t)i * nv + d] * a0[d];
+            bvec[i] = s - aref[i];
+            f[i] = 0;
+        }
+        double lastchange = 0;
+        for (int it = 0; it < P->pgs_iters; it++) {
+            lastchange = 0;
+            for (int i = 0; i < nr; i++) {
+                real res = bvec[i] + Rr[i] * f[i];
+                for (int j = 0; j < nr; j++) res += A[(size_t)i * nr + j] * f[j];
+                real old = f[i];
+                real nf = f[i] - res / (A[(size_t)i * nr + i] + Rr[i]);
+                if (kind[i] != 2 && nf < 0) nf = 0; /* unilateral rows */
+                f[i] = nf;
+                if (fabs((double)(nf - old)) > lastchange) lastchange = fabs((double)(nf - old));
+                if (kind[i] == 2 && (i + 1 == nr || kind[i + 1] != 2)) {
+                    /* last friction row of this contact: project onto the elliptic cone (D2) */
+                    int i0 = i - (ROWDIM - 1);
+                    const double *mu = rowmu[i];
+                    real fn = f[i0], s2 = 0;
+                    for (int r = 1; r < ROWDIM; r++) { real x = f[i0 + r] / (real)mu[r - 1]; s2 += x * x; }
+                    if (fn <= 0) { for (int r = 1; r < ROWDIM; r++) f[i0 + r] = 0; }
+                    else if (s2 > fn * fn) {
+                        real sc = fn / (real)sqrt((double)s2);
+                        for (int r = 1; r < ROWDIM; r++) f[i0 + r] *= sc;
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < nr; i++)
+            for (int d = 0; d < nv; d++) qfc[d] += J[(size_t)i * nv + d] * f[i];
+        free(MiJt); free(A);
+        if (diag) { g_diag_res = lastchange; }
+    }
+    if (diag) { g_diag_rows = nr; g_diag_contacts = ncon; if (nr == 0) g_diag_res = 0; }
+
+    /* -- implicitfast: (M - h*D) qacc = qfrc_smooth + qfrc_constraint, D = d(passive+actuator)/dqvel
+     *    = -(damping + kv) on the arm diagonal (the joint-level force clamp is ignored in D) */
+    real Mh[ORC_NV_MAX * ORC_NV_MAX], rhs[ORC_NV_MAX];
+    memcpy(Mh, M, sizeof(real) * nv * nv);
+    for (int j = 0; j < 6; j++) Mh[j * nv + j] += h * (real)(DAMPING + KV);
+    chol(Mh, nv);
+    for (int d = 0; d < nv; d++) rhs[d] = tau[d] + qfc[d];
+    chol_solve(Mh, nv, rhs);
+    for (int d = 0; d < nv; d++) qvel[d] += h * rhs[d];
+    for (int j = 0; j < 6; j++) qpos[j] += h * qvel[j];
+    for (int c = 0; c < nc; c++) {
+        real *pp = qpos + 6 + 7 * c, *qq = pp + 3, *vv = qvel + 6 + 6 * c, *ww = vv + 3;
+        for (int k = 0; k < 3; k++) pp[k] += h * vv[k];
+        /* MJ-DOC mju_quatIntegrate: q <- q * exp(h w / 2), w in body frame, then normalise */
+        real wn = v3norm(ww);
+        if (wn > 0) {
+            real ang = h * wn, s = (real)sin((double)ang * 0.5) / wn, cw = (real)cos((double)ang * 0.5);
+            real dq[4] = {cw, ww[0] * s, ww[1] * s, ww[2] * s};
+            real r0 = qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2] - qq[3] * dq[3];
+            real r1 = qq[0] * dq[1] + qq[1] * dq[0] + qq[2] * dq[3] - qq[3] * dq[2];
+            real r2 = qq[0] * dq[2] - qq[1] * dq[3] + qq[2] * dq[0] + qq[3] * dq[1];
+            real r3 = qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1] + qq[3] * dq[0];
+            real n2 = (real)sqrt((double)(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3));
+            qq[0] = r0 / n2; qq[1] = r1 / n2; qq[2] = r2 / n2; qq[3] = r3 / n2;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* glue: reach_cube_env.py:141-348 and the per-task deltas                                          */
+/* ------------------------------------------------------------------------------------------------ */
+void orc_default_params(orc_params *p, int task) {
+    memset(p, 0, sizeof *p);
+    p->task = task;
+    p->action_mode = ORC_ACTION_JOINT;   /* reach:80 */
+    p->reward_type = ORC_REWARD_SPARSE;  /* reach:81 */
+    p->block_gripper = (task == ORC_TASK_REACH || task == ORC_TASK_PUSH) ? 1 : 0; /* reach:82 push:84 lift:82 */
+    p->distance_threshold = 0.05;        /* reach:83 */
+    p->cube_xy_range = 0.3;              /* reach:84 */
+    p->target_xy_range = 0.3;            /* push:87 */
+    p->goal_z_range = 0.1;               /* pick_place:88 */
+    p->height_threshold = 0.1;           /* lift:84 */
+    p->n_substeps = 20;                  /* reach:85 */
+    p->max_episode_steps = 50;           /* gym_lowcostrobot/__init__.py:12-42 */
+    p->impratio = 100.0;                 /* follower.xml:3 (after the scene's own <option>; later wins, MJ-DOC unverified) */
+    p->pgs_iters = 10;
+    p->compat = 0;
+    p->auto_reset = 1;
+}
+int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
+int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }
+int orc_action_dim(const orc_params *p) { /* reach:95-96 */
+    return (p->action_mode == ORC_ACTION_EE ? 3 : 5) + (p->block_gripper ? 0 : 1);
+}
+static int gripper_active(const orc_params *p) { return !(p->task == ORC_TASK_REACH || p->task == ORC_TASK_PUSH); }
+
+static float clip1(float a) { return a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a); } /* reach:234 */
+
+/* joint-mode target (reach:248-268; lift:258-277) */
+void orc_joint_ctrl(const orc_params *p, const double *q6, const float *action, double *ctrl6) {
+    int k = orc_action_dim(p);
+    for (int j = 0; j < 5; j++) ctrl6[j] = clampd((double)clip1(action[j]) + q6[j], TGT_LO[j], TGT_HI[j]);
+    if (gripper_active(p)) ctrl6[5] = clampd((double)clip1(action[k - 1]) + q6[5], TGT_LO[5], TGT_HI[5]); /* lift:264,274: action[-1] */
+    else ctrl6[5] = 0.0;                                                                                     /* reach:255,265 */
+}
+
+/* inverse_kinematics (reach:148-221) incl. REF-QUIRK-3: writes the sim's qpos */
+static int ik_solve(real *q_state /*in: qpos[:6], out: teleported*/, const real *target, real *q_ctrl, real *site_last) {
+    real q[6];
+    int iters = 0;
+    memcpy(q, q_state, sizeof q); /* reach:182 */
+    for (int it = 0; it < 10; it++) { /* max_iter reach:156 */
+        kin_t K;
+        memcpy(q_state, q, sizeof q); /* reach:185 */
+        arm_kinematics(q, &K);        /* reach:186 mj_forward */
+        v3copy(site_last, K.site);
+        iters++;
+        real e[3];
+        v3sub(e, target, K.site); /* reach:189 */
+        if (v3norm(e) < (real)0.01) break; /* reach:193 */
+        real Jp[18], Jr[18];
+        jac_point(&K, 6, 4, K.site, Jp, Jr); /* reach:197 mj_jacSite; column 6 is zero */
+        real A[36], rhs[6];
+        for (int a = 0; a < 6; a++) {
+            for (int b = 0; b < 6; b++) {
+                real s = 0;
+                for (int k = 0; k < 3; k++) s += Jp[k * 6 + a] * Jp[k * 6 + b];
+                A[a * 6 + b] = s + (a == b ? (real)0.15 : 0); /* lm_damping reach:155,200 */
+            }
+            rhs[a] = Jp[a] * e[0] + Jp[6 + a] * e[1] + Jp[12 + a] * e[2];
+        }
+        chol(A, 6);
+        chol_solve(A, 6, rhs); /* == inv(JtJ + 0.15 I) Jt e, reach:201-202 ; nullspace term is x 0.0 (reach:205-207) */
+        real nn = 0;
+        for (int a = 0; a < 6; a++) nn += rhs[a] * rhs[a];
+        nn = (real)sqrt((double)nn);
+        if (nn > 1) for (int a = 0; a < 6; a++) rhs[a] /= nn; /* reach:210-212 */
+        for (int a = 0; a < 6; a++) {
+            q[a] += rhs[a] * (real)0.5; /* step reach:154,215 */
+            if (q[a] < (real)JNT_LO[a]) q[a] = (real)JNT_LO[a]; /* check_joint_limits reach:141-146 */
+            if (q[a] > (real)JNT_HI[a]) q[a] = (real)JNT_HI[a];
+        }
+    }
+    memcpy(q_ctrl, q, sizeof q);
+    return iters;
+}
+
+void orc_reward(const orc_params *p, const double *a3, const double *b3, float *reward32, double *reward64,
+                uint8_t *success) {
+    /* goal_distance/is_success/compute_reward reach:335-348 */
+    double d = sqrt((a3[0] - b3[0]) * (a3[0] - b3[0]) + (a3[1] - b3[1]) * (a3[1] - b3[1]) + (a3[2] - b3[2]) * (a3[2] - b3[2]));
+    *success = d < p->distance_threshold;
+    if (p->reward_type == ORC_REWARD_SPARSE) {
+        *reward32 = -(float)(d > p->distance_threshold); /* -0.0f when within threshold (REF-QUIRK-7) */
+        *reward64 = (double)*reward32;
+    } else {
+        *reward64 = -d;
+        *reward32 = (float)*reward64;
+    }
+}
+
+/* ---- numpy-compatible RNG ---- */
+typedef unsigned __int128 u128;
+#define PCG_MULT (((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL)
+static uint32_t ss_hashmix(uint32_t v, uint32_t *hc) {
+    v ^= *hc; *hc *= 0x931e8875u; v *= *hc; v ^= v >> 16; return v;
+}
+static uint32_t ss_mix(uint32_t x, uint32_t y) {
+    uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; r ^= r >> 16; return r;
+}
+void orc_rng_seed(uint64_t seed, uint64_t rng[4]) {
+    /* numpy SeedSequence(seed).generate_state(4, uint64) then PCG64 srandom (numpy/random/_pcg64.pyx, bit_generator.pyx) */
+    uint32_t ent[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    int nent = ent[1] ? 2 : 1;
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    for (int i = 0; i < 4; i++) pool[i] = ss_hashmix(i < nent ? ent[i] : 0u, &hc);
+    for (int s = 0; s < 4; s++)
+        for (int d = 0; d < 4; d++)
+            if (s != d) pool[d] = ss_mix(pool[d], ss_hashmix(pool[s], &hc));
+    uint32_t w[8], hb = 0x8b51f9ddu;
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = pool[i & 3];
+        v ^= hb; hb *= 0x58f38dedu; v *= hb; v ^= v >> 16; w[i] = v;
+    }
+    uint64_t s64[4];
+    for (int i = 0; i < 4; i++) s64[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    u128 initstate = ((u128)s64[0] << 64) | s64[1], initseq = ((u128)s64[2] << 64) | s64[3];
+    u128 inc = (initseq << 1) | 1, st = 0;
+    st = st * PCG_MULT + inc;
+    st += initstate;
+    st = st * PCG_MULT + inc;
+    rng[0] = (uint64_t)(st >> 64); rng[1] = (uint64_t)st; rng[2] = (uint64_t)(inc >> 64); rng[3] = (uint64_t)inc;
+}
+double orc_rng_double(uint64_t rng[4]) {
+    u128 st = ((u128)rng[0] << 64) | rng[1], inc = ((u128)rng[2] << 64) | rng[3];
+    st = st * PCG_MULT + inc;
+    rng[0] = (uint64_t)(st >> 64); rng[1] = (uint64_t)st;
+    uint64_t hi = rng[0], lo = rng[1], x = hi ^ lo;
+    unsigned rot = (unsigned)(hi >> 58);
+    uint64_t out = (x >> rot) | (x << ((64 - rot) & 63));
+    return (double)(out >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* reset(): reach:297-311, push:308-328, pick_place:316-336, stack:307-324 */
+static void reset_one(const orc_params *P, const task_model *T, double *qpos, double *qvel, double *ee_lag, float *target,
+                      int32_t *elapsed, uint64_t *rng) {
+    double lo[3] = {-P->cube_xy_range / 2, -P->cube_xy_range / 2, 0}, hi[3] = {P->cube_xy_range / 2, P->cube_xy_range / 2, 0};
+    lo[1] += 0.165; hi[1] += 0.10; /* reach:138-139 */
+    for (int c = 0; c < T->ncube; c++) {
+        for (int k = 0; k < 3; k++) qpos[6 + 7 * c + k] = lo[k] + (hi[k] - lo[k]) * orc_rng_double(rng); /* np_random.uniform */
+        qpos[6 + 7 * c + 3] = 1; qpos[6 + 7 * c + 4] = 0; qpos[6 + 7 * c + 5] = 0; qpos[6 + 7 * c + 6] = 0;
+    }
+    if (T->has_target) {
+        double tl[3] = {-P->target_xy_range / 2, -P->target_xy_range / 2, 0};
+        double th[3] = {P->target_xy_range / 2, P->target_xy_range / 2, P->task == ORC_TASK_PICK_PLACE ? P->goal_z_range : 0.0};
+        tl[1] += 0.165; th[1] += 0.10; /* push:147-148 */
+        for (int k = 0; k < 3; k++) target[k] = (float)(tl[k] + (th[k] - tl[k]) * orc_rng_double(rng)); /* .astype(float32) push:320 */
+    }
+    for (int j = 0; j < 6; j++) qpos[j] = 0;
+    if (P->compat & ORC_COMPAT_ZERO_QVEL_ON_RESET) for (int d = 0; d < ORC_NV_MAX; d++) qvel[d] = 0; /* default: REF-QUIRK-1 keep */
+    /* mj_forward (reach:309) refreshes site_xpos at q=0 */
+    real q0[6] = {0, 0, 0, 0, 0, 0};
+    kin_t K;
+    arm_kinematics(q0, &K);
+    for (int k = 0; k < 3; k++) ee_lag[k] = (double)K.site[k];
+    *elapsed = 0;
+}
+
+static void write_obs(const orc_params *P, const task_model *T, const double *qpos, const double *qvel, const float *target,
+                      float *obs) { /* get_observation reach:281-295 push:291-306 stack:290-305 */
+    for (int j = 0; j < 6; j++) { obs[j] = (float)qpos[j]; obs[6 + j] = (float)qvel[j]; }
+    for (int k = 0; k < 3; k++) obs[12 + k] = (float)qpos[6 + k];
+    for (int k = 0; k < 3; k++)
+        obs[15 + k] = T->has_target ? target[k] : (P->task == ORC_TASK_STACK ? (float)qpos[13 + k] : 0.0f);
+}
+
+void orc_reset(const orc_params *p, orc_io *io, int n, const uint8_t *mask, const uint64_t *seeds) {
+    task_model T = get_task_model(p->task);
+    for (int e = 0; e < n; e++) {
+        if (mask && !mask[e]) continue;
+        if (seeds) orc_rng_seed(seeds[e], io->rng + 4 * (size_t)e);
+        reset_one(p, &T, io->qpos + (size_t)e * ORC_NQ_MAX, io->qvel + (size_t)e * ORC_NV_MAX, io->ee_lag + 3 * (size_t)e,
+                  io->target + 3 * (size_t)e, io->elapsed + e, io->rng + 4 * (size_t)e);
+        if (io->obs) write_obs(p, &T, io->qpos + (size_t)e * ORC_NQ_MAX, io->qvel + (size_t)e * ORC_NV_MAX, io->target + 3 * (size_t)e,
+                               io->obs + 18 * (size_t)e);
+    }
+}
+
+static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_t e, const float *action) {
+    double *qpos64 = io->qpos + e * ORC_NQ_MAX, *qvel64 = io->qvel + e * ORC_NV_MAX, *ee_lag = io->ee_lag + 3 * e;
+    float *target = io->target + 3 * e;
+    const int nq = orc_nq(P->task), nv = orc_nv(P->task), k = orc_action_dim(P);
+    real qpos[ORC_NQ_MAX], qvel[ORC_NV_MAX], ctrl[6];
+    for (int i = 0; i < nq; i++) qpos[i] = (real)qpos64[i];
+    for (int i = 0; i < nv; i++) qvel[i] = (real)qvel64[i];
+
+    /* ---- apply_action reach:223-273 */
+    if (P->action_mode == ORC_ACTION_EE) {
+        real tgt[3], qc[6], sl[3];
+        for (int i = 0; i < 3; i++) tgt[i] = (real)(ee_lag[i] + (double)(clip1(action[i]) * 0.05f)); /* reach:241 (float32 product) */
+        if (tgt[2] < 0) tgt[2] = 0; /* reach:242 */
+        ik_solve(qpos, tgt, qc, sl);
+        for (int j = 0; j < 6; j++) ctrl[j] = qc[j];
+        if (gripper_active(P)) { /* lift:253-257 */
+            double g = (double)qpos[5] + (double)(clip1(action[3]) * 0.2f);
+            ctrl[5] = (real)clampd(g, JNT_LO[5], JNT_HI[5]);
+        } else ctrl[5] = 0; /* reach:247 */
+    } else {
+        double q6[6], c6[6];
+        for (int j = 0; j < 6; j++) q6[j] = (double)qpos[j];
+        orc_joint_ctrl(P, q6, action, c6);
+        for (int j = 0; j < 6; j++) ctrl[j] = (real)c6[j];
+    }
+    (void)k;
+    /* ---- 20 x mj_step reach:276-279 */
+    lag_t lag;
+    memset(&lag, 0, sizeof lag);
+    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, e == 0 && s == P->n_substeps - 1);
+    for (int i = 0; i < nq; i++) qpos64[i] = (double)qpos[i];
+    for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
+    for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];
+
+    /* ---- observation, reward, termination: reach:313-333 (+ lift:322-346 push:330-346 stack:326-348) */
+    float *obs = io->obs + 18 * e;
+    write_obs(P, T, qpos64, qvel64, target, obs);
+    double a3[3], b3[3];
+    float r32 = 0; double r64 = 0; uint8_t succ = 0, term = 0;
+    double cube[3] = {(double)lag.cube[0][0], (double)lag.cube[0][1], (double)lag.cube[0][2]};
+    switch (P->task) {
+    case ORC_TASK_REACH:
+        for (int i = 0; i < 3; i++) { a3[i] = ee_lag[i]; b3[i] = cube[i]; }
+        orc_reward(P, a3, b3, &r32, &r64, &succ); term = succ; break;
+    case ORC_TASK_LIFT: { /* lift:341-345 REF-QUIRK-5 */
+        double d = sqrt((ee_lag[0] - cube[0]) * (ee_lag[0] - cube[0]) + (ee_lag[1] - cube[1]) * (ee_lag[1] - cube[1]) +
+                        (ee_lag[2] - cube[2]) * (ee_lag[2] - cube[2]));
+        r64 = (cube[2] - P->height_threshold) + d; r32 = (float)r64; succ = 0; term = 0; break; }
+    case ORC_TASK_PUSH: case ORC_TASK_PICK_PLACE:
+        for (int i = 0; i < 3; i++) { a3[i] = cube[i]; b3[i] = (double)target[i]; }
+        orc_reward(P, a3, b3, &r32, &r64, &succ); term = succ; break;
+    case ORC_TASK_STACK: /* stack:334-347 */
+        for (int i = 0; i < 3; i++) { a3[i] = (double)lag.cube[1][i]; b3[i] = (double)lag.cube[0][i]; }
+        b3[2] += 0.03;
+        orc_reward(P, a3, b3, &r32, &r64, &succ); term = succ; break;
+    }
+    io->elapsed[e] += 1;
+    uint8_t trunc = io->elapsed[e] >= P->max_episode_steps; /* gymnasium TimeLimit */
+    io->reward[e] = r32; io->reward64[e] = r64; io->terminated[e] = term; io->truncated[e] = trunc; io->is_success[e] = succ;
+    memcpy(io->term_obs + 18 * e, obs, sizeof(float) * 18);
+    io->did_reset[e] = 0;
+    if (P->auto_reset && (term || trunc)) { /* SB3 DummyVecEnv.step_wait semantics (examples/gym_manipulation_sb3.py:34-39) */
+        reset_one(P, T, qpos64, qvel64, ee_lag, target, io->elapsed + e, io->rng + 4 * e);
+        write_obs(P, T, qpos64, qvel64, target, obs);
+        io->did_reset[e] = 1;
+    }
+}
+
+void orc_step(const orc_params *p, orc_io *io, int n, const float *action, int threads) {
+    task_model T = get_task_model(p->task);
+    const int k = orc_action_dim(p);
+    ensure_invweight0();
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+    for (int e = 0; e < n; e++) step_one(p, &T, io, (size_t)e, action + (size_t)e * k);
+    (void)threads;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_last_diag(int *n_rows, int *n_contacts, double *pgs_residual) {
+    *n_rows = g_diag_rows; *n_contacts = g_diag_contacts; *pgs_residual = g_diag_res;
+}
+
+/* ---- model queries ---- */
+void orc_fk(const double *q6, double *link_pos, double *site, double *spheres) {
+    real q[6]; kin_t K;
+    for (int j = 0; j < 6; j++) q[j] = (real)q6[j];
+    arm_kinematics(q, &K);
+    for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) link_pos[3 * i + k] = (double)K.p[i + 1][k];
+    for (int k = 0; k < 3; k++) site[k] = (double)K.site[k];
+    if (spheres) for (int s = 0; s < 4; s++) for (int k = 0; k < 3; k++) spheres[3 * s + k] = (double)K.sph[s][k];
+}
+void orc_mass_matrix(const double *q6, int with_armature, double *M) {
+    real q[6], Mr[36]; kin_t K;
+    for (int j = 0; j < 6; j++) q[j] = (real)q6[j];
+    arm_kinematics(q, &K);
+    arm_mass(&K, with_armature, Mr);
+    for (int i = 0; i < 36; i++) M[i] = (double)Mr[i];
+}
+void orc_bias(const double *q6, const double *qd6, double *bias) {
+    real q[6], qd[6], b[6]; kin_t K;
+    for (int j = 0; j < 6; j++) { q[j] = (real)q6[j]; qd[j] = (real)qd6[j]; }
+    arm_kinematics(q, &K);
+    arm_bias(&K, qd, b);
+    for (int j = 0; j < 6; j++) bias[j] = (double)b[j];
+}
+void orc_site_jac(const double *q6, double *J) {
+    real q[6], Jp[18], Jr[18]; kin_t K;
+    for (int j = 0; j < 6; j++) q[j] = (real)q6[j];
+    arm_kinematics(q, &K);
+    jac_point(&K, 6, 4, K.site, Jp, Jr);
+    for (int i = 0; i < 18; i++) J[i] = (double)Jp[i];
+}
+void orc_invweight0(double *body_tran, double *body_rot, double *dof) {
+    ensure_invweight0();
+    for (int i = 0; i < 6; i++) { body_tran[i] = g_inv_tran[i]; body_rot[i] = g_inv_rot[i]; dof[i] = g_inv_dof[i]; }
+}
+int orc_ik(const double *q6_in, const double *target3, double *q_ctrl, double *q_state, double *site_last) {
+    real qs[6], t[3], qc[6], sl[3];
+    for (int j = 0; j < 6; j++) qs[j] = (real)q6_in[j];
+    for (int k = 0; k < 3; k++) t[k] = (real)target3[k];
+    int it = ik_solve(qs, t, qc, sl);
+    for (int j = 0; j < 6; j++) { q_ctrl[j] = (double)qc[j]; q_state[j] = (double)qs[j]; }
+    for (int k = 0; k < 3; k++) site_last[k] = (double)sl[k];
+    return it;
+}

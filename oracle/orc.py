@@ -1,0 +1,195 @@
+"""ctypes binding of the CPU oracle (oracle/lcr_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+product package (gym_lowcostrobot_amd), which must fail loudly without its HIP library.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4}
+NQ_MAX, NV_MAX = 20, 18
+
+
+class OrcParams(ctypes.Structure):
+    _fields_ = [
+        ("task", ctypes.c_int32),
+        ("action_mode", ctypes.c_int32),
+        ("reward_type", ctypes.c_int32),
+        ("block_gripper", ctypes.c_int32),
+        ("distance_threshold", ctypes.c_double),
+        ("cube_xy_range", ctypes.c_double),
+        ("target_xy_range", ctypes.c_double),
+        ("goal_z_range", ctypes.c_double),
+        ("height_threshold", ctypes.c_double),
+        ("n_substeps", ctypes.c_int32),
+        ("max_episode_steps", ctypes.c_int32),
+        ("impratio", ctypes.c_double),
+        ("pgs_iters", ctypes.c_int32),
+        ("compat", ctypes.c_uint32),
+        ("auto_reset", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
+    ]
+
+
+class OrcIO(ctypes.Structure):
+    _fields_ = [
+        ("qpos", ctypes.c_void_p),
+        ("qvel", ctypes.c_void_p),
+        ("ee_lag", ctypes.c_void_p),
+        ("target", ctypes.c_void_p),
+        ("elapsed", ctypes.c_void_p),
+        ("rng", ctypes.c_void_p),
+        ("obs", ctypes.c_void_p),
+        ("term_obs", ctypes.c_void_p),
+        ("reward", ctypes.c_void_p),
+        ("reward64", ctypes.c_void_p),
+        ("terminated", ctypes.c_void_p),
+        ("truncated", ctypes.c_void_p),
+        ("is_success", ctypes.c_void_p),
+        ("did_reset", ctypes.c_void_p),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    so = os.path.join(_HERE, "liblcr_oracle.so")
+    src = os.path.join(_HERE, "lcr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+_libs = {}
+
+
+def lib(f32=False):
+    key = bool(f32)
+    if key not in _libs:
+        build()
+        name = "liblcr_oracle_f32.so" if f32 else "liblcr_oracle.so"
+        L = ctypes.CDLL(os.path.join(_HERE, name))
+        L.orc_rng_double.restype = ctypes.c_double
+        L.orc_nq.restype = ctypes.c_int
+        L.orc_nv.restype = ctypes.c_int
+        L.orc_action_dim.restype = ctypes.c_int
+        L.orc_max_threads.restype = ctypes.c_int
+        L.orc_ik.restype = ctypes.c_int
+        _libs[key] = L
+    return _libs[key]
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Oracle:
+    """n independent envs stepped on the CPU, AoS arrays (env-major)."""
+
+    def __init__(self, task, n, f32=False, **kw):
+        self.L = lib(f32)
+        self.task = TASKS[task] if isinstance(task, str) else int(task)
+        self.n = n
+        self.params = OrcParams()
+        self.L.orc_default_params(ctypes.byref(self.params), self.task)
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(k)
+            setattr(self.params, k, v)
+        self.nq = self.L.orc_nq(self.task)
+        self.nv = self.L.orc_nv(self.task)
+        self.action_dim = self.L.orc_action_dim(ctypes.byref(self.params))
+        self.qpos = np.zeros((n, NQ_MAX))
+        self.qpos[:, 9] = 1.0
+        self.qpos[:, 16] = 1.0
+        self.qvel = np.zeros((n, NV_MAX))
+        self.ee_lag = np.zeros((n, 3))
+        self.target = np.zeros((n, 3), np.float32)
+        self.elapsed = np.zeros(n, np.int32)
+        self.rng = np.zeros((n, 4), np.uint64)
+        self.obs = np.zeros((n, 18), np.float32)
+        self.term_obs = np.zeros((n, 18), np.float32)
+        self.reward = np.zeros(n, np.float32)
+        self.reward64 = np.zeros(n)
+        self.terminated = np.zeros(n, np.uint8)
+        self.truncated = np.zeros(n, np.uint8)
+        self.is_success = np.zeros(n, np.uint8)
+        self.did_reset = np.zeros(n, np.uint8)
+        self.io = OrcIO(
+            _p(self.qpos), _p(self.qvel), _p(self.ee_lag), _p(self.target), _p(self.elapsed), _p(self.rng),
+            _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.reward64), _p(self.terminated),
+            _p(self.truncated), _p(self.is_success), _p(self.did_reset),
+        )
+
+    def reset(self, seeds=None, mask=None):
+        s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.L.orc_reset(ctypes.byref(self.params), ctypes.byref(self.io), self.n,
+                         None if m is None else _p(m), None if s is None else _p(s))
+
+    def step(self, action, threads=1):
+        a = np.ascontiguousarray(action, np.float32)
+        assert a.shape == (self.n, self.action_dim), (a.shape, (self.n, self.action_dim))
+        self.L.orc_step(ctypes.byref(self.params), ctypes.byref(self.io), self.n, _p(a), int(threads))
+
+    def diag(self):
+        r, c, res = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        self.L.orc_last_diag(ctypes.byref(r), ctypes.byref(c), ctypes.byref(res))
+        return r.value, c.value, res.value
+
+
+# ---- model queries ----
+def fk(q):
+    q = np.ascontiguousarray(q, np.float64)
+    lp, site, sph = np.zeros((6, 3)), np.zeros(3), np.zeros((4, 3))
+    lib().orc_fk(_p(q), _p(lp), _p(site), _p(sph))
+    return lp, site, sph
+
+
+def mass_matrix(q, armature=True):
+    q = np.ascontiguousarray(q, np.float64)
+    M = np.zeros((6, 6))
+    lib().orc_mass_matrix(_p(q), int(armature), _p(M))
+    return M
+
+
+def bias(q, qd):
+    q = np.ascontiguousarray(q, np.float64)
+    qd = np.ascontiguousarray(qd, np.float64)
+    b = np.zeros(6)
+    lib().orc_bias(_p(q), _p(qd), _p(b))
+    return b
+
+
+def site_jac(q):
+    q = np.ascontiguousarray(q, np.float64)
+    J = np.zeros((3, 6))
+    lib().orc_site_jac(_p(q), _p(J))
+    return J
+
+
+def invweight0():
+    t, r, d = np.zeros(6), np.zeros(6), np.zeros(6)
+    lib().orc_invweight0(_p(t), _p(r), _p(d))
+    return t, r, d
+
+
+def ik(q, target):
+    q = np.ascontiguousarray(q, np.float64)
+    t = np.ascontiguousarray(target, np.float64)
+    qc, qs, sl = np.zeros(6), np.zeros(6), np.zeros(3)
+    it = lib().orc_ik(_p(q), _p(t), _p(qc), _p(qs), _p(sl))
+    return it, qc, qs, sl
+
+
+def rng_seed(seed):
+    r = np.zeros(4, np.uint64)
+    lib().orc_rng_seed(ctypes.c_uint64(int(seed)), _p(r))
+    return r
+
+
+def rng_double(r):
+    return lib().orc_rng_double(_p(r))

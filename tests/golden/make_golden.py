@@ -1,0 +1,213 @@
+"""Generate golden vectors by IMPORTING the reference's pure-numpy glue (no source is copied).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Writes tests/golden/glue_golden.json.
+
+`mujoco` and `gymnasium` are absent here, so tiny stand-in modules are injected into sys.modules
+just far enough for `import gym_lowcostrobot.envs.*` to succeed; objects are made with
+`Cls.__new__` and only methods that are pure numpy are called:
+  * goal_distance / is_success / compute_reward      (reach:335-348, push:348-361, pick_place:356-369, stack:350-363)
+  * the reset() sampling arithmetic                   (reach:297-306, push:308-322, pick_place:316-330, stack:307-319)
+    - reset() itself is run with a stand-in `data` whose qpos is a numpy array and with
+      `mujoco.mj_forward` a no-op, so the qpos it WRITES and the target it samples are the reference's.
+  * joint-mode target arithmetic of apply_action      (reach:248-273, lift:258-282) with mj_step a no-op.
+The physics (mujoco.mj_step) cannot be run: "parity unpinned" for it.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+
+
+def _install_stubs():
+    mj = types.ModuleType("mujoco")
+    mj.viewer = types.ModuleType("mujoco.viewer")
+    mj.mj_forward = lambda m, d: None
+    mj.mj_step = lambda m, d: None
+    sys.modules["mujoco"] = mj
+    sys.modules["mujoco.viewer"] = mj.viewer
+
+    gym = types.ModuleType("gymnasium")
+
+    class Env:
+        def reset(self, seed=None, options=None):
+            if seed is not None:
+                # gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed)))
+                self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.shape = tuple(shape)
+            self.low = np.full(self.shape, low, dtype=dtype)
+            self.high = np.full(self.shape, high, dtype=dtype)
+            self.dtype = dtype
+
+    spaces = types.ModuleType("gymnasium.spaces")
+    spaces.Box = Box
+    spaces.Dict = dict
+    gym.Env = Env
+    gym.spaces = spaces
+    reg = types.ModuleType("gymnasium.envs.registration")
+    reg.register = lambda **kw: None
+    envs = types.ModuleType("gymnasium.envs")
+    envs.registration = reg
+    gym.envs = envs
+    sys.modules["gymnasium"] = gym
+    sys.modules["gymnasium.spaces"] = spaces
+    sys.modules["gymnasium.envs"] = envs
+    sys.modules["gymnasium.envs.registration"] = reg
+    return Box
+
+
+class _FakeGeom:
+    pos = None
+
+
+class _FakeModel:
+    def __init__(self):
+        self._g = _FakeGeom()
+        # follower.xml:58-95 joint ranges == actuator ctrlrange (inheritrange=1)
+        self.jnt_range = np.array([[-3.14, 3.14]] * 5 + [[-2.45, 0.032]])
+        self.actuator_ctrlrange = self.jnt_range.copy()
+
+    def geom(self, name):
+        return self._g
+
+
+class _FakeData:
+    def __init__(self, nq):
+        self.qpos = np.zeros(nq)
+        self.qvel = np.zeros(nq - 1)
+        self.ctrl = np.zeros(6)
+
+
+def main():
+    Box = _install_stubs()
+    sys.path.insert(0, REF)
+    from gym_lowcostrobot.envs.lift_cube_env import LiftCubeEnv
+    from gym_lowcostrobot.envs.pick_place_cube_env import PickPlaceCubeEnv
+    from gym_lowcostrobot.envs.push_cube_env import PushCubeEnv
+    from gym_lowcostrobot.envs.reach_cube_env import ReachCubeEnv
+    from gym_lowcostrobot.envs.stack_two_cubes_env import StackTwoCubesEnv
+
+    out = {"rewards": [], "resets": [], "joint_targets": []}
+    rng = np.random.default_rng(12345)
+
+    # ---- rewards / success --------------------------------------------------------------
+    for cls, name, b_is_f32 in [
+        (ReachCubeEnv, "reach", False),
+        (PushCubeEnv, "push", True),
+        (PickPlaceCubeEnv, "pick_place", True),
+        (StackTwoCubesEnv, "stack", False),
+    ]:
+        for reward_type in ("sparse", "dense"):
+            env = cls.__new__(cls)
+            env.distance_threshold = 0.05
+            env.reward_type = reward_type
+            cases = [
+                (np.array([0.0, 0.2, 0.1]), np.array([0.0, 0.2, 0.06])),
+                (np.array([0.1, 0.2, 0.015]), np.array([0.0, 0.1, 0.0])),
+                (np.array([0.0, 0.0, 0.0]), np.array([0.05, 0.0, 0.0])),  # d == threshold (neither < nor >)
+                (np.array([0.0, 0.0, 0.0]), np.array([0.03, 0.04, 0.0])),  # 3-4-5 -> 0.05 up to rounding
+            ]
+            for _ in range(12):
+                a = rng.uniform(-0.2, 0.3, 3)
+                b = a + rng.normal(0, 0.04, 3)
+                cases.append((a, b))
+            for a, b in cases:
+                bb = b.astype(np.float32) if b_is_f32 else b
+                r = env.compute_reward(a, bb)
+                s = env.is_success(a, bb)
+                out["rewards"].append(
+                    {
+                        "task": name,
+                        "reward_type": reward_type,
+                        "a": a.tolist(),
+                        "b": [float(x) for x in bb],
+                        "b_is_f32": b_is_f32,
+                        "reward": float(r),
+                        "reward_dtype": str(np.asarray(r).dtype),
+                        "reward_signbit": bool(np.signbit(r)),
+                        "is_success": bool(s),
+                    }
+                )
+
+    # ---- reset sampling -----------------------------------------------------------------
+    def mk(cls, nq, **kw):
+        env = cls.__new__(cls)
+        env.model = _FakeModel()
+        env.data = _FakeData(nq)
+        env.num_dof = 6
+        env.observation_mode = "state"
+        rng_xy = kw.get("cube_xy_range", 0.3)
+        env.cube_low = np.array([-rng_xy / 2, -rng_xy / 2, 0])
+        env.cube_high = np.array([rng_xy / 2, rng_xy / 2, 0])
+        env.cube_low[1] += 0.165
+        env.cube_high[1] += 0.10
+        if "target_z" in kw:
+            t = kw.get("target_xy_range", 0.3)
+            env.target_low = np.array([-t / 2, -t / 2, 0])
+            env.target_high = np.array([t / 2, t / 2, kw["target_z"]])
+            env.target_low[1] += 0.165
+            env.target_high[1] += 0.10
+        return env
+
+    for cls, name, nq, kw in [
+        (ReachCubeEnv, "reach", 13, {}),
+        (LiftCubeEnv, "lift", 13, {}),
+        (PushCubeEnv, "push", 13, {"target_z": 0.0}),
+        (PickPlaceCubeEnv, "pick_place", 13, {"target_z": 0.1}),
+        (StackTwoCubesEnv, "stack", 20, {}),
+    ]:
+        for seed in (0, 1, 42, 2**31 - 1, 2**40 + 7):
+            env = mk(cls, nq, **kw)
+            env.data.qpos[:] = 0.123  # must be overwritten by reset for [0:13] / [0:20]
+            seq = []
+            obs, info = env.reset(seed=seed)
+            rec = {"qpos": env.data.qpos.tolist(), "obs": {k: [float(x) for x in v] for k, v in obs.items()}}
+            if hasattr(env, "target_pos"):
+                rec["target_pos"] = [float(x) for x in env.target_pos]
+            seq.append(rec)
+            for _ in range(3):  # un-seeded resets continue the same generator stream
+                obs, info = env.reset()
+                rec = {"qpos": env.data.qpos.tolist(), "obs": {k: [float(x) for x in v] for k, v in obs.items()}}
+                if hasattr(env, "target_pos"):
+                    rec["target_pos"] = [float(x) for x in env.target_pos]
+                seq.append(rec)
+            out["resets"].append({"task": name, "seed": seed, "sequence": seq})
+
+    # ---- joint-mode control targets (apply_action with mj_step stubbed) ------------------
+    for cls, name, gripper in [(ReachCubeEnv, "reach", False), (LiftCubeEnv, "lift", True)]:
+        env = mk(cls, 13)
+        env.action_mode = "joint"
+        env.render_mode = None
+        env.control_decimation = 1
+        k = 6 if gripper else 5
+        env.action_space = Box(-1.0, 1.0, shape=(k,), dtype=np.float32)
+        for _ in range(16):
+            env.data.qpos[:6] = rng.uniform(-2.0, 2.0, 6)
+            env.data.qpos[5] = rng.uniform(-2.45, 0.032)
+            act = rng.uniform(-1.5, 1.5, k).astype(np.float32)
+            env.apply_action(act)
+            out["joint_targets"].append(
+                {
+                    "task": name,
+                    "qpos": env.data.qpos[:6].tolist(),
+                    "action": [float(x) for x in act],
+                    "ctrl": [float(x) for x in np.asarray(env.data.ctrl, dtype=np.float64)],
+                }
+            )
+
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "glue_golden.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", dst, {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
