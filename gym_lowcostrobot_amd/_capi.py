@@ -1,0 +1,148 @@
+"""ctypes binding of the C ABI declared in include/lcr.h (liblcr_hip.so).
+
+There is deliberately NO fallback: if the HIP library is missing or no MI355X is visible, importing the
+library / creating a simulator raises -- the product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblcr_hip.so")
+
+ABI_VERSION = 1
+TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4}
+ACTION_MODES = {"joint": 0, "ee": 1}
+OBS_MODES = {"image": 0, "state": 1, "both": 2}
+REWARD_TYPES = {"sparse": 0, "dense": 1}
+COMPAT_ZERO_QVEL_ON_RESET = 1
+IMG_H, IMG_W = 240, 320
+
+LCR_OK, LCR_ERR_INVALID, LCR_ERR_NO_DEVICE, LCR_ERR_HIP, LCR_ERR_OOM, LCR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+# every symbol include/lcr.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "lcr_abi_version", "lcr_last_error", "lcr_config_default", "lcr_action_dim", "lcr_nq", "lcr_nv",
+    "lcr_create", "lcr_destroy", "lcr_set_stream", "lcr_sync", "lcr_reset", "lcr_step", "lcr_step_host",
+    "lcr_get_obs", "lcr_get_outputs", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
+    "lcr_memcpy_h2d", "lcr_memcpy_d2h", "lcr_timer_begin", "lcr_timer_end", "lcr_fill_random_actions",
+]
+
+
+class LcrConfig(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("task", ctypes.c_int32),
+        ("n_envs", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("env_id_offset", ctypes.c_int64),
+        ("action_mode", ctypes.c_int32),
+        ("obs_mode", ctypes.c_int32),
+        ("reward_type", ctypes.c_int32),
+        ("block_gripper", ctypes.c_int32),
+        ("distance_threshold", ctypes.c_double),
+        ("cube_xy_range", ctypes.c_double),
+        ("target_xy_range", ctypes.c_double),
+        ("goal_z_range", ctypes.c_double),
+        ("height_threshold", ctypes.c_double),
+        ("impratio", ctypes.c_double),
+        ("n_substeps", ctypes.c_int32),
+        ("max_episode_steps", ctypes.c_int32),
+        ("pgs_iters", ctypes.c_int32),
+        ("compat", ctypes.c_uint32),
+        ("auto_reset", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
+        ("base_seed", ctypes.c_uint64),
+    ]
+
+
+class LcrObsView(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", ctypes.c_int32),
+        ("has_aux", ctypes.c_int32),
+        ("arm_qpos", ctypes.c_void_p),
+        ("arm_qvel", ctypes.c_void_p),
+        ("cube_pos", ctypes.c_void_p),
+        ("aux_pos", ctypes.c_void_p),
+        ("image_front", ctypes.c_void_p),
+        ("image_top", ctypes.c_void_p),
+    ]
+
+
+class LcrOutView(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
+        ("reward", ctypes.c_void_p),
+        ("terminated", ctypes.c_void_p),
+        ("truncated", ctypes.c_void_p),
+        ("is_success", ctypes.c_void_p),
+        ("did_reset", ctypes.c_void_p),
+        ("terminal_obs", ctypes.c_void_p),
+    ]
+
+
+class LcrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lcr error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def load():
+    """Load liblcr_hip.so; raises OSError with a build hint if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `python -m gym_lowcostrobot_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64
+    L.lcr_abi_version.restype = ctypes.c_int
+    L.lcr_last_error.restype = ctypes.c_char_p
+    L.lcr_config_default.argtypes = [ctypes.POINTER(LcrConfig), ctypes.c_int]
+    L.lcr_action_dim.argtypes = [ctypes.POINTER(LcrConfig)]
+    L.lcr_nq.argtypes = [ctypes.c_int]
+    L.lcr_nv.argtypes = [ctypes.c_int]
+    L.lcr_create.argtypes = [ctypes.POINTER(LcrConfig), ctypes.POINTER(vp)]
+    L.lcr_destroy.argtypes = [vp]
+    L.lcr_destroy.restype = None
+    L.lcr_set_stream.argtypes = [vp, vp]
+    L.lcr_sync.argtypes = [vp]
+    L.lcr_reset.argtypes = [vp, vp, vp]
+    L.lcr_step.argtypes = [vp, vp]
+    L.lcr_step_host.argtypes = [vp, vp]
+    L.lcr_get_obs.argtypes = [vp, ctypes.POINTER(LcrObsView)]
+    L.lcr_get_outputs.argtypes = [vp, ctypes.POINTER(LcrOutView)]
+    L.lcr_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.lcr_set_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.lcr_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.lcr_free.argtypes = [vp, vp]
+    L.lcr_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.lcr_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.lcr_timer_begin.argtypes = [vp]
+    L.lcr_timer_end.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.lcr_fill_random_actions.argtypes = [vp, vp, u64, u64]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("lcr_last_error", "lcr_destroy"):
+            fn.restype = ctypes.c_int
+    if L.lcr_abi_version() != ABI_VERSION:
+        raise OSError(f"liblcr_hip.so ABI {L.lcr_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        L = load()
+        msg = L.lcr_last_error().decode("utf-8", "replace")
+        if rc == LCR_ERR_INVALID:
+            raise ValueError(msg)
+        raise LcrError(rc, msg)
+    return rc

@@ -1,0 +1,399 @@
+// lcr_capi.hip -- the C ABI of include/lcr.h: device-memory ownership, launches, host<->device state I/O.
+// No simulation arithmetic lives here (that is lcr_kernels.hip) and there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/lcr.h"
+#include "lcr_device.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(LCR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+}  // namespace
+
+struct lcr_sim {
+    lcr_config cfg;
+    LcrDev dev;
+    int nq, nv, k;
+    int ee_mode;
+    hipStream_t stream;
+    void *arena;        // one allocation holding every SoA array
+    size_t arena_bytes;
+    float *action_stage;     // [k][N] staging for lcr_step_host
+    unsigned char *mask_dev; // [N]
+    unsigned long long *seeds_dev; // [N]
+    hipEvent_t ev0, ev1;
+    bool has_images;
+};
+
+extern "C" {
+
+int lcr_abi_version(void) { return LCR_ABI_VERSION; }
+const char *lcr_last_error(void) { return g_err; }
+
+int lcr_nq(int task) { return task == LCR_TASK_STACK ? 20 : 13; }
+int lcr_nv(int task) { return task == LCR_TASK_STACK ? 18 : 12; }
+
+int lcr_config_default(lcr_config *cfg, int task) {
+    if (!cfg) return fail(LCR_ERR_INVALID, "cfg is NULL");
+    if (task < LCR_TASK_REACH || task > LCR_TASK_STACK) return fail(LCR_ERR_INVALID, "unknown task %d", task);
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof(lcr_config);
+    cfg->task = task;
+    cfg->n_envs = 1;
+    cfg->device = 0;
+    cfg->env_id_offset = 0;
+    cfg->action_mode = LCR_ACTION_JOINT;   // reach_cube_env.py:80
+    cfg->obs_mode = LCR_OBS_IMAGE;         // reach_cube_env.py:79 (the reference default is "image")
+    cfg->reward_type = LCR_REWARD_SPARSE;  // reach_cube_env.py:81
+    cfg->block_gripper = -1;
+    cfg->distance_threshold = 0.05;
+    cfg->cube_xy_range = 0.3;
+    cfg->target_xy_range = 0.3;
+    cfg->goal_z_range = 0.1;
+    cfg->height_threshold = 0.1;
+    cfg->impratio = 100.0;
+    cfg->n_substeps = 20;
+    cfg->max_episode_steps = 50;
+    cfg->pgs_iters = 10;
+    cfg->compat = 0;
+    cfg->auto_reset = 1;
+    cfg->base_seed = 0;
+    return LCR_OK;
+}
+
+static int resolved_block_gripper(const lcr_config *cfg) {
+    if (cfg->block_gripper >= 0) return cfg->block_gripper ? 1 : 0;
+    return (cfg->task == LCR_TASK_REACH || cfg->task == LCR_TASK_PUSH) ? 1 : 0;  // reach:82 push:84 / lift:82
+}
+
+int lcr_action_dim(const lcr_config *cfg) {
+    if (!cfg) return fail(LCR_ERR_INVALID, "cfg is NULL");
+    if (cfg->action_mode != LCR_ACTION_JOINT && cfg->action_mode != LCR_ACTION_EE)
+        return fail(LCR_ERR_INVALID, "Invalid action mode, must be 'ee' or 'joint'");
+    return (cfg->action_mode == LCR_ACTION_EE ? 3 : 5) + (resolved_block_gripper(cfg) ? 0 : 1);
+}
+
+int lcr_create(const lcr_config *cfg, lcr_sim **out) {
+    if (!cfg || !out) return fail(LCR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(lcr_config))
+        return fail(LCR_ERR_INVALID, "lcr_config size mismatch (got %u, want %zu): ABI version skew", cfg->struct_size, sizeof(lcr_config));
+    if (cfg->task < LCR_TASK_REACH || cfg->task > LCR_TASK_STACK) return fail(LCR_ERR_INVALID, "unknown task %d", cfg->task);
+    if (cfg->n_envs <= 0) return fail(LCR_ERR_INVALID, "n_envs must be positive");
+    if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
+    if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters must be >= 0");
+    if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
+    if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
+    int k = lcr_action_dim(cfg);
+    if (k < 0) return k;
+    const bool gripper_task = !(cfg->task == LCR_TASK_REACH || cfg->task == LCR_TASK_PUSH);
+    if (cfg->action_mode == LCR_ACTION_EE && gripper_task && resolved_block_gripper(cfg))
+        return fail(LCR_ERR_INVALID, "ee mode with block_gripper on a gripper task indexes action[3] out of range in the reference (lift_cube_env.py:242)");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(LCR_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(LCR_ERR_INVALID, "device %d out of range (have %d)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LCR_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+
+    lcr_sim *s = new (std::nothrow) lcr_sim();
+    if (!s) return fail(LCR_ERR_OOM, "host allocation failed");
+    memset(s, 0, sizeof *s);
+    s->cfg = *cfg;
+    s->cfg.block_gripper = resolved_block_gripper(cfg);
+    s->nq = lcr_nq(cfg->task);
+    s->nv = lcr_nv(cfg->task);
+    s->k = k;
+    s->ee_mode = cfg->action_mode == LCR_ACTION_EE;
+    s->stream = nullptr;
+    s->has_images = cfg->obs_mode != LCR_OBS_STATE;
+    const size_t N = (size_t)cfg->n_envs;
+
+    // ---- one arena for all SoA arrays (256-B aligned slices) ----
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off = 0;
+    size_t o_qpos = off; off += al(sizeof(float) * s->nq * N);
+    size_t o_qvel = off; off += al(sizeof(float) * s->nv * N);
+    size_t o_ee = off; off += al(sizeof(float) * 3 * N);
+    size_t o_tgt = off; off += al(sizeof(float) * 3 * N);
+    size_t o_el = off; off += al(sizeof(int) * N);
+    size_t o_rng = off; off += al(sizeof(unsigned long long) * 4 * N);
+    size_t o_rew = off; off += al(sizeof(float) * N);
+    size_t o_term = off; off += al(N);
+    size_t o_trunc = off; off += al(N);
+    size_t o_succ = off; off += al(N);
+    size_t o_dres = off; off += al(N);
+    size_t o_tobs = off; off += al(sizeof(float) * LCR_OBS_DIM * N);
+    size_t o_act = off; off += al(sizeof(float) * 6 * N);
+    size_t o_mask = off; off += al(N);
+    size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
+    size_t o_img0 = off, o_img1 = off;
+    const size_t img_bytes = (size_t)LCR_IMG_H * LCR_IMG_W * 3;
+    if (s->has_images) { o_img0 = off; off += al(img_bytes * N); o_img1 = off; off += al(img_bytes * N); }
+    s->arena_bytes = off;
+    e = hipMalloc(&s->arena, off);
+    if (e != hipSuccess) { delete s; return fail(LCR_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(e)); }
+    e = hipMemset(s->arena, 0, off);
+    if (e != hipSuccess) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
+    char *base = (char *)s->arena;
+
+    LcrDev &D = s->dev;
+    D.n = cfg->n_envs;
+    D.k = k;
+    D.task = cfg->task;
+    D.n_substeps = cfg->n_substeps;
+    D.max_steps = cfg->max_episode_steps;
+    D.pgs_iters = cfg->pgs_iters;
+    D.auto_reset = cfg->auto_reset ? 1 : 0;
+    D.gripper_active = gripper_task ? 1 : 0;
+    D.reward_type = cfg->reward_type;
+    D.has_target = (cfg->task == LCR_TASK_PUSH || cfg->task == LCR_TASK_PICK_PLACE) ? 1 : 0;
+    D.compat = cfg->compat;
+    D.env_off = cfg->env_id_offset;
+    D.dist_thr = (float)cfg->distance_threshold;
+    D.height_thr = (float)cfg->height_threshold;
+    D.inv_impratio = (float)(1.0 / (cfg->impratio > 1e-15 ? cfg->impratio : 1e-15));
+    // scene constants: reach/lift/push cube 0.1 kg, I=1.6667e-4 (reach_cube.xml:25); pick_place 10 kg (pick_place_cube.xml:27);
+    // stack 0.1 kg, I=1.125e-5 (stack_two_cubes.xml:27,33)
+    double cm = cfg->task == LCR_TASK_PICK_PLACE ? 10.0 : 0.1;
+    double ci = cfg->task == LCR_TASK_STACK ? 0.00001125 : 0.00016667;
+    D.cube_mass = (float)cm;
+    D.cube_minv = (float)(1.0 / cm);
+    D.cube_iinv = (float)(1.0 / ci);
+    {   // reach_cube_env.py:132-139, push_cube_env.py:141-148, pick_place_cube_env.py:143-150 -- same fp64 expressions
+        double lo[3] = {-cfg->cube_xy_range / 2, -cfg->cube_xy_range / 2, 0}, hi[3] = {cfg->cube_xy_range / 2, cfg->cube_xy_range / 2, 0};
+        lo[1] += 0.165; hi[1] += 0.10;
+        double tl[3] = {-cfg->target_xy_range / 2, -cfg->target_xy_range / 2, 0};
+        double th[3] = {cfg->target_xy_range / 2, cfg->target_xy_range / 2, cfg->task == LCR_TASK_PICK_PLACE ? cfg->goal_z_range : 0.0};
+        tl[1] += 0.165; th[1] += 0.10;
+        for (int i = 0; i < 3; i++) { D.cube_lo[i] = lo[i]; D.cube_rng[i] = hi[i] - lo[i]; D.tgt_lo[i] = tl[i]; D.tgt_rng[i] = th[i] - tl[i]; }
+    }
+    D.qpos = (float *)(base + o_qpos);
+    D.qvel = (float *)(base + o_qvel);
+    D.ee_lag = (float *)(base + o_ee);
+    D.target = (float *)(base + o_tgt);
+    D.elapsed = (int *)(base + o_el);
+    D.rng = (unsigned long long *)(base + o_rng);
+    D.reward = (float *)(base + o_rew);
+    D.terminated = (unsigned char *)(base + o_term);
+    D.truncated = (unsigned char *)(base + o_trunc);
+    D.is_success = (unsigned char *)(base + o_succ);
+    D.did_reset = (unsigned char *)(base + o_dres);
+    D.term_obs = (float *)(base + o_tobs);
+    D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
+    D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
+    s->action_stage = (float *)(base + o_act);
+    s->mask_dev = (unsigned char *)(base + o_mask);
+    s->seeds_dev = (unsigned long long *)(base + o_seeds);
+    e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e != hipSuccess) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
+
+    // initial state: reset of seed (base_seed + global env id) for every env
+    int rc = lcr_launch_reset(D, nullptr, nullptr, 1, cfg->base_seed, s->stream);
+    if (rc) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); }
+    if (s->has_images) lcr_launch_image_stub(D, s->stream);
+    e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e)); }
+    *out = s;
+    return LCR_OK;
+}
+
+void lcr_destroy(lcr_sim *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipEventDestroy(s->ev0);
+    (void)hipEventDestroy(s->ev1);
+    (void)hipFree(s->arena);
+    delete s;
+}
+
+#define SIMCHK(s)                                             \
+    if (!(s)) return fail(LCR_ERR_INVALID, "sim is NULL"); \
+    HIPCHK(hipSetDevice((s)->cfg.device))
+
+int lcr_set_stream(lcr_sim *s, void *hip_stream) {
+    SIMCHK(s);
+    s->stream = (hipStream_t)hip_stream;
+    return LCR_OK;
+}
+
+int lcr_sync(lcr_sim *s) {
+    SIMCHK(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return LCR_OK;
+}
+
+int lcr_reset(lcr_sim *s, const uint8_t *mask_host, const uint64_t *seeds_host) {
+    SIMCHK(s);
+    const size_t N = (size_t)s->dev.n;
+    if (mask_host) HIPCHK(hipMemcpyAsync(s->mask_dev, mask_host, N, hipMemcpyHostToDevice, s->stream));
+    if (seeds_host) HIPCHK(hipMemcpyAsync(s->seeds_dev, seeds_host, N * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    int rc = lcr_launch_reset(s->dev, mask_host ? s->mask_dev : nullptr, seeds_host ? s->seeds_dev : nullptr, 0, 0, s->stream);
+    if (rc) return fail(LCR_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (s->has_images) lcr_launch_image_stub(s->dev, s->stream);
+    // the staging copies above read caller memory: do not return before they are consumed
+    if (mask_host || seeds_host) HIPCHK(hipStreamSynchronize(s->stream));
+    return LCR_OK;
+}
+
+int lcr_step(lcr_sim *s, const float *action_dev) {
+    SIMCHK(s);
+    if (!action_dev) return fail(LCR_ERR_INVALID, "action is NULL");
+    int rc = lcr_launch_step(s->dev, action_dev, s->ee_mode, s->stream);
+    if (rc) return fail(LCR_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (s->has_images) {
+        rc = lcr_launch_image_stub(s->dev, s->stream);
+        if (rc) return fail(LCR_ERR_HIP, "image stub launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    return LCR_OK;
+}
+
+int lcr_step_host(lcr_sim *s, const float *action_host) {
+    SIMCHK(s);
+    if (!action_host) return fail(LCR_ERR_INVALID, "action is NULL");
+    HIPCHK(hipMemcpyAsync(s->action_stage, action_host, sizeof(float) * (size_t)s->k * s->dev.n, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return lcr_step(s, s->action_stage);
+}
+
+int lcr_get_obs(lcr_sim *s, lcr_obs_view *out) {
+    if (!s || !out) return fail(LCR_ERR_INVALID, "NULL argument");
+    const size_t N = (size_t)s->dev.n;
+    out->n_envs = s->dev.n;
+    out->arm_qpos = s->dev.qpos;
+    out->arm_qvel = s->dev.qvel;
+    out->cube_pos = s->dev.qpos + 6 * N;
+    if (s->dev.has_target) { out->has_aux = 1; out->aux_pos = s->dev.target; }
+    else if (s->cfg.task == LCR_TASK_STACK) { out->has_aux = 1; out->aux_pos = s->dev.qpos + 13 * N; }
+    else { out->has_aux = 0; out->aux_pos = nullptr; }
+    out->image_front = s->dev.img_front;
+    out->image_top = s->dev.img_top;
+    return LCR_OK;
+}
+
+int lcr_get_outputs(lcr_sim *s, lcr_out_view *out) {
+    if (!s || !out) return fail(LCR_ERR_INVALID, "NULL argument");
+    out->n_envs = s->dev.n;
+    out->_pad = 0;
+    out->reward = s->dev.reward;
+    out->terminated = s->dev.terminated;
+    out->truncated = s->dev.truncated;
+    out->is_success = s->dev.is_success;
+    out->did_reset = s->dev.did_reset;
+    out->terminal_obs = s->dev.term_obs;
+    return LCR_OK;
+}
+
+int lcr_get_state(lcr_sim *s, double *qpos, double *qvel, double *ee_lag, float *target, int32_t *elapsed, uint64_t *rng) {
+    SIMCHK(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const size_t N = (size_t)s->dev.n;
+    std::vector<float> tmp;
+    auto pull = [&](double *dst, const float *src, size_t cnt) -> hipError_t {
+        tmp.resize(cnt);
+        hipError_t e = hipMemcpy(tmp.data(), src, cnt * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) for (size_t i = 0; i < cnt; i++) dst[i] = (double)tmp[i];
+        return e;
+    };
+    if (qpos) HIPCHK(pull(qpos, s->dev.qpos, s->nq * N));
+    if (qvel) HIPCHK(pull(qvel, s->dev.qvel, s->nv * N));
+    if (ee_lag) HIPCHK(pull(ee_lag, s->dev.ee_lag, 3 * N));
+    if (target) HIPCHK(hipMemcpy(target, s->dev.target, 3 * N * sizeof(float), hipMemcpyDeviceToHost));
+    if (elapsed) HIPCHK(hipMemcpy(elapsed, s->dev.elapsed, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rng) HIPCHK(hipMemcpy(rng, s->dev.rng, 4 * N * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return LCR_OK;
+}
+
+int lcr_set_state(lcr_sim *s, const double *qpos, const double *qvel, const double *ee_lag, const float *target,
+                  const int32_t *elapsed, const uint64_t *rng) {
+    SIMCHK(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const size_t N = (size_t)s->dev.n;
+    std::vector<float> tmp;
+    auto push = [&](float *dst, const double *src, size_t cnt) -> hipError_t {
+        tmp.resize(cnt);
+        for (size_t i = 0; i < cnt; i++) tmp[i] = (float)src[i];
+        return hipMemcpy(dst, tmp.data(), cnt * sizeof(float), hipMemcpyHostToDevice);
+    };
+    if (qpos) HIPCHK(push(s->dev.qpos, qpos, s->nq * N));
+    if (qvel) HIPCHK(push(s->dev.qvel, qvel, s->nv * N));
+    if (ee_lag) HIPCHK(push(s->dev.ee_lag, ee_lag, 3 * N));
+    if (target) HIPCHK(hipMemcpy(s->dev.target, target, 3 * N * sizeof(float), hipMemcpyHostToDevice));
+    if (elapsed) HIPCHK(hipMemcpy(s->dev.elapsed, elapsed, N * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (rng) HIPCHK(hipMemcpy(s->dev.rng, rng, 4 * N * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return LCR_OK;
+}
+
+int lcr_malloc(lcr_sim *s, size_t bytes, void **dev_out) {
+    SIMCHK(s);
+    if (!dev_out) return fail(LCR_ERR_INVALID, "dev_out is NULL");
+    hipError_t e = hipMalloc(dev_out, bytes);
+    if (e != hipSuccess) return fail(LCR_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return LCR_OK;
+}
+int lcr_free(lcr_sim *s, void *dev) {
+    SIMCHK(s);
+    HIPCHK(hipFree(dev));
+    return LCR_OK;
+}
+int lcr_memcpy_h2d(lcr_sim *s, void *dst_dev, const void *src_host, size_t bytes) {
+    SIMCHK(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return LCR_OK;
+}
+int lcr_memcpy_d2h(lcr_sim *s, void *dst_host, const void *src_dev, size_t bytes) {
+    SIMCHK(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return LCR_OK;
+}
+
+int lcr_timer_begin(lcr_sim *s) {
+    SIMCHK(s);
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    return LCR_OK;
+}
+int lcr_timer_end(lcr_sim *s, float *ms_out) {
+    SIMCHK(s);
+    if (!ms_out) return fail(LCR_ERR_INVALID, "ms_out is NULL");
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    HIPCHK(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+    return LCR_OK;
+}
+
+int lcr_fill_random_actions(lcr_sim *s, float *action_dev, uint64_t seed, uint64_t step) {
+    SIMCHK(s);
+    if (!action_dev) return fail(LCR_ERR_INVALID, "action is NULL");
+    int rc = lcr_launch_fill_actions(action_dev, s->dev.n, s->k, s->dev.env_off, seed, step, s->stream);
+    if (rc) return fail(LCR_ERR_HIP, "fill kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return LCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// lcr_device.h -- kernel argument block shared by the C ABI (lcr_capi.hip) and the kernels (lcr_kernels.hip).
+#pragma once
+#include <stdint.h>
+
+#define LCR_OBS_DIM 18
+
+struct LcrDev {
+    int n;            // envs on this device
+    int k;            // action components
+    int task;         // lcr_task
+    int n_substeps;
+    int max_steps;    // TimeLimit, <=0 disabled
+    int pgs_iters;
+    int auto_reset;
+    int gripper_active;   // lift / pick_place / stack
+    int reward_type;
+    int has_target;
+    unsigned compat;
+    int _pad0;
+    long long env_off;
+    float dist_thr, height_thr, inv_impratio;
+    float cube_mass, cube_minv, cube_iinv;
+    // reset sampling boxes, fp64 exactly as the reference builds them (reach_cube_env.py:132-139, push:141-148)
+    double cube_lo[3], cube_rng[3], tgt_lo[3], tgt_rng[3];
+    // state, SoA [component][n]
+    float *qpos;      // [nq][n]
+    float *qvel;      // [nv][n]
+    float *ee_lag;    // [3][n]
+    float *target;    // [3][n]
+    int *elapsed;     // [n]
+    unsigned long long *rng;  // [4][n]  PCG64 state_hi, state_lo, inc_hi, inc_lo
+    // step outputs
+    float *reward;
+    unsigned char *terminated, *truncated, *is_success, *did_reset;
+    float *term_obs;  // [18][n]
+    // image stub
+    unsigned char *img_front, *img_top;  // [n][240][320][3] or null
+};
+
+// launchers implemented in lcr_kernels.hip (plain C++ linkage, same shared object)
+int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
+int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,
+                     unsigned long long base_seed, void *stream);
+int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,
+                            unsigned long long step, void *stream);
+int lcr_launch_image_stub(const LcrDev &P, void *stream);

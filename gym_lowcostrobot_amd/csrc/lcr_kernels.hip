@@ -1,0 +1,1170 @@
+// lcr_kernels.hip -- hand-written gfx950 kernels of the batched low-cost-robot simulator.
+//
+// Mapping: ONE wavefront lane == ONE environment.  A workgroup is one wave (64 lanes), so nothing in the
+// step kernel needs a barrier; 65 536 envs = 1024 waves = one wave per SIMD of the 256 CUs.
+// State is SoA [component][env] in HBM: every per-lane scalar load/store is one fully coalesced 256-B
+// wave transaction.  State is read once at kernel entry, kept in VGPRs across all n_substeps physics
+// substeps, and written once at exit; reward / termination / TimeLimit / auto-reset are fused at the tail.
+// The only LDS use is the per-lane scratch of the contact rows that couple into the arm
+// (g = L^-1 J^T, 4 slots x 4 rows x 6 floats, laid out [slot][row][k][lane] => bank-conflict free).
+// MFMA is not used: the largest contraction is 6x6.
+//
+// What is restated here (reference file:line, relative to /root/reference/gym_lowcostrobot/):
+//   apply_action joint mode   envs/reach_cube_env.py:248-273 (+ lift_cube_env.py:258-282 gripper)
+//   apply_action ee mode + IK envs/reach_cube_env.py:236-247, 148-221 (incl. the qpos overwrite)
+//   20 x mujoco.mj_step       envs/reach_cube_env.py:276-279 -> substep() below; the MuJoCo pipeline itself
+//                             (CRBA+armature, RNE, position actuators, soft contacts, implicitfast) follows
+//                             MuJoCo's public documentation; constants from assets/low_cost_robot_6dof/*.xml
+//   reward / success / done   envs/reach_cube_env.py:313-348, lift:322-346, push:330-361, pick_place:338-369,
+//                             stack_two_cubes_env.py:326-363; TimeLimit(50) from __init__.py:9-43
+//   reset                     envs/reach_cube_env.py:297-311, push:308-328, pick_place:316-336, stack:307-324
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lcr_device.h"
+#include "lcr_model_gen.h"
+
+#define DEV __device__ __forceinline__
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// constants (follower.xml:3,7,8 ; scene xmls)
+// ------------------------------------------------------------------------------------------------
+constexpr float H = 0.002f;
+constexpr float ARMATURE = 0.1f;
+constexpr float DAMPING = 1.0f;
+constexpr float KP = 1000.0f;
+constexpr float KV = 10.0f;
+constexpr float FRC = 10.0f;
+constexpr float GRAV = 9.81f;
+constexpr float CH = 0.015f;  // cube half size
+constexpr float JLO[6] = {-3.14f, -3.14f, -3.14f, -3.14f, -3.14f, -2.45f};
+constexpr float JHI[6] = {3.14f, 3.14f, 3.14f, 3.14f, 3.14f, 0.032f};
+// soft-constraint parameters (MuJoCo defaults solref=(0.02,1), solimp=(0.9,0.95,0.001,0.5,2); follower.xml:15 fingers)
+// K = 1/(dmax^2 tc^2), B = 2/(dmax tc)
+constexpr float K_DEF = 1.0f / (0.95f * 0.95f * 0.02f * 0.02f), B_DEF = 2.0f / (0.95f * 0.02f);
+constexpr float D0_DEF = 0.9f, DW_DEF = 0.95f, W_DEF = 0.001f;
+constexpr float K_FC = 1.0f / (0.975f * 0.975f * 0.02f * 0.02f), B_FC = 2.0f / (0.975f * 0.02f);  // finger-cube (mixed)
+constexpr float D0_FC = 0.4575f, DW_FC = 0.975f, W_FC = 0.0185f;
+constexpr float K_FF = 1.0f / (0.9999f * 0.9999f * 0.02f * 0.02f), B_FF = 2.0f / (0.9999f * 0.02f);  // finger-floor
+constexpr float D0_FF = 0.015f, DW_FF = 0.9999f, W_FF = 0.036f;
+constexpr float MU_CUBE = 0.5f, MU_FINGER = 1.5f, MU_TORS = 0.005f;
+constexpr float INVW_DOF[6] = {lcrm::INVW_DOF1, lcrm::INVW_DOF2, lcrm::INVW_DOF3, lcrm::INVW_DOF4, lcrm::INVW_DOF5, lcrm::INVW_DOF6};
+
+struct f3 { float x, y, z; };
+DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV f3 axpy(float s, f3 a, f3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }  // s*a+b
+DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi())
+DEV float impedance(float dist, float d0, float dw, float inv_width) {
+    float x = fminf(fabsf(dist) * inv_width, 1.0f);
+    float y = x <= 0.5f ? 2.0f * x * x : 1.0f - 2.0f * (1.0f - x) * (1.0f - x);
+    return fmaf(y, dw - d0, d0);
+}
+
+// contact frame from unit normal (MuJoCo mju_makeFrame): t1, t2
+DEV void make_frame(f3 n, f3 &t1, f3 &t2) {
+    f3 y = (n.y < 0.5f && n.y > -0.5f) ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f);
+    float d = dot(n, y);
+    y = axpy(-d, n, y);
+    float il = rsq(dot(y, y));
+    t1 = il * y;
+    t2 = cross(n, t1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// arm kinematics: world frames of link_1..link_6 (base quat of follower.xml:51 folded in)
+// ------------------------------------------------------------------------------------------------
+struct ArmFrames {
+    f3 X[6], Y[6], Z[6], p[6];
+};
+
+DEV void arm_frames(const float (&q)[6], ArmFrames &F) {
+    using namespace lcrm;
+    float s, c;
+    // base_link: Rz(-90deg): X0=(0,-1,0) Y0=(1,0,0) Z0=(0,0,1)
+    const f3 X0 = mk(0.f, -1.f, 0.f), Y0 = mk(1.f, 0.f, 0.f), Z0 = mk(0.f, 0.f, 1.f);
+    // link_1: pos (P1x,0,P1z), axis -z
+    F.p[0] = axpy(P1x, X0, P1z * Z0);
+    sincosf(q[0], &s, &c);
+    F.X[0] = axpy(c, X0, (-s) * Y0);
+    F.Y[0] = axpy(s, X0, c * Y0);
+    F.Z[0] = Z0;
+    // link_2: pos (0,P2y,P2z), axis +y
+    F.p[1] = axpy(P2y, F.Y[0], axpy(P2z, F.Z[0], F.p[0]));
+    sincosf(q[1], &s, &c);
+    F.X[1] = axpy(c, F.X[0], (-s) * F.Z[0]);
+    F.Z[1] = axpy(s, F.X[0], c * F.Z[0]);
+    F.Y[1] = F.Y[0];
+    // link_3: axis -y
+    F.p[2] = axpy(P3x, F.X[1], axpy(P3y, F.Y[1], axpy(P3z, F.Z[1], F.p[1])));
+    sincosf(q[2], &s, &c);
+    F.X[2] = axpy(c, F.X[1], s * F.Z[1]);
+    F.Z[2] = axpy(-s, F.X[1], c * F.Z[1]);
+    F.Y[2] = F.Y[1];
+    // link_4: axis +y
+    F.p[3] = axpy(P4x, F.X[2], axpy(P4y, F.Y[2], axpy(P4z, F.Z[2], F.p[2])));
+    sincosf(q[3], &s, &c);
+    F.X[3] = axpy(c, F.X[2], (-s) * F.Z[2]);
+    F.Z[3] = axpy(s, F.X[2], c * F.Z[2]);
+    F.Y[3] = F.Y[2];
+    // link_5: pos (P5x,P5y,0), axis +x
+    F.p[4] = axpy(P5x, F.X[3], axpy(P5y, F.Y[3], F.p[3]));
+    sincosf(q[4], &s, &c);
+    F.Y[4] = axpy(c, F.Y[3], s * F.Z[3]);
+    F.Z[4] = axpy(-s, F.Y[3], c * F.Z[3]);
+    F.X[4] = F.X[3];
+    // link_6: axis -z
+    F.p[5] = axpy(P6x, F.X[4], axpy(P6y, F.Y[4], axpy(P6z, F.Z[4], F.p[4])));
+    sincosf(q[5], &s, &c);
+    F.X[5] = axpy(c, F.X[4], (-s) * F.Y[4]);
+    F.Y[5] = axpy(s, F.X[4], c * F.Y[4]);
+    F.Z[5] = F.Z[4];
+}
+DEV f3 joint_axis(const ArmFrames &F, int j) {  // world joint axes (follower.xml:58,65,72,79,86,95); j is a literal after unrolling
+    switch (j) {
+    case 0: return neg(F.Z[0]);
+    case 1: return F.Y[1];
+    case 2: return neg(F.Y[2]);
+    case 3: return F.Y[3];
+    case 4: return F.X[4];
+    default: return neg(F.Z[5]);
+    }
+}
+DEV f3 local_point(const ArmFrames &F, int i, float x, float y, float z) {
+    return axpy(x, F.X[i], axpy(y, F.Y[i], axpy(z, F.Z[i], F.p[i])));
+}
+DEV f3 site_pos(const ArmFrames &F) { return local_point(F, 4, lcrm::SITEx, lcrm::SITEy, lcrm::SITEz); }
+
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+DEV f3 symv(const Sym3 &S, f3 v) {
+    return mk(fmaf(S.xx, v.x, fmaf(S.xy, v.y, S.xz * v.z)), fmaf(S.xy, v.x, fmaf(S.yy, v.y, S.yz * v.z)),
+              fmaf(S.xz, v.x, fmaf(S.yz, v.y, S.zz * v.z)));
+}
+// world inertia about the link com: R Ic R^T with R = [X Y Z]
+DEV Sym3 world_inertia(f3 X, f3 Y, f3 Z, float ixx, float ixy, float ixz, float iyy, float iyz, float izz) {
+    f3 Tx = axpy(ixx, X, axpy(ixy, Y, ixz * Z));
+    f3 Ty = axpy(ixy, X, axpy(iyy, Y, iyz * Z));
+    f3 Tz = axpy(ixz, X, axpy(iyz, Y, izz * Z));
+    Sym3 S;
+    S.xx = fmaf(Tx.x, X.x, fmaf(Ty.x, Y.x, Tz.x * Z.x));
+    S.xy = fmaf(Tx.x, X.y, fmaf(Ty.x, Y.y, Tz.x * Z.y));
+    S.xz = fmaf(Tx.x, X.z, fmaf(Ty.x, Y.z, Tz.x * Z.z));
+    S.yy = fmaf(Tx.y, X.y, fmaf(Ty.y, Y.y, Tz.y * Z.y));
+    S.yz = fmaf(Tx.y, X.z, fmaf(Ty.y, Y.z, Tz.y * Z.z));
+    S.zz = fmaf(Tx.z, X.z, fmaf(Ty.z, Y.z, Tz.z * Z.z));
+    return S;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6x6 dense helpers (fully unrolled; everything lives in VGPRs)
+// ------------------------------------------------------------------------------------------------
+struct Chol6 {
+    float L[6][6];  // strictly-lower part used
+    float id[6];    // 1 / L_ii
+};
+DEV void chol6(const float (&A)[6][6], Chol6 &C) {  // A symmetric, lower part read
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d = fmaf(-C.L[j][k], C.L[j][k], d);
+        float id = rsq(d);
+        C.id[j] = id;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s = fmaf(-C.L[i][k], C.L[j][k], s);
+            C.L[i][j] = s * id;
+        }
+    }
+}
+DEV void fsub(const Chol6 &C, float (&x)[6]) {  // x <- L^-1 x
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s = fmaf(-C.L[i][k], x[k], s);
+        x[i] = s * C.id[i];
+    }
+}
+DEV void bsub(const Chol6 &C, float (&x)[6]) {  // x <- L^-T x
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        float s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s = fmaf(-C.L[k][i], x[k], s);
+        x[i] = s * C.id[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// numpy-compatible PCG64 (Generator(PCG64(SeedSequence(seed)))) -- reset sampling must reproduce
+// self.np_random.uniform(low, high) of reach_cube_env.py:302 bit for bit
+// ------------------------------------------------------------------------------------------------
+typedef unsigned __int128 u128;
+DEV u128 pcg_mult() { return (((u128)0x2360ED051FC65DA4ULL) << 64) | 0x4385DF649FCCF645ULL; }
+struct Pcg { u128 st, inc; };
+DEV double pcg_double(Pcg &g) {
+    g.st = g.st * pcg_mult() + g.inc;
+    unsigned long long hi = (unsigned long long)(g.st >> 64), lo = (unsigned long long)g.st, x = hi ^ lo;
+    unsigned rot = (unsigned)(hi >> 58);
+    unsigned long long o = (x >> rot) | (x << ((64 - rot) & 63));
+    return (double)(o >> 11) * (1.0 / 9007199254740992.0);
+}
+DEV uint32_t ss_hashmix(uint32_t v, uint32_t &hc) { v ^= hc; hc *= 0x931e8875u; v *= hc; v ^= v >> 16; return v; }
+DEV uint32_t ss_mix(uint32_t x, uint32_t y) { uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; r ^= r >> 16; return r; }
+DEV Pcg pcg_seed(unsigned long long seed) {  // SeedSequence(seed).generate_state(4, uint64) -> pcg64 srandom
+    uint32_t ent0 = (uint32_t)seed, ent1 = (uint32_t)(seed >> 32);
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    pool[0] = ss_hashmix(ent0, hc);
+    pool[1] = ss_hashmix(ent1, hc);  // a zero high word hashes exactly like the implicit zero padding
+    pool[2] = ss_hashmix(0u, hc);
+    pool[3] = ss_hashmix(0u, hc);
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (s != d) pool[d] = ss_mix(pool[d], ss_hashmix(pool[s], hc));
+    uint32_t w[8], hb = 0x8b51f9ddu;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = pool[i & 3];
+        v ^= hb; hb *= 0x58f38dedu; v *= hb; v ^= v >> 16; w[i] = v;
+    }
+    unsigned long long s0 = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+    unsigned long long s1 = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+    unsigned long long s2 = (unsigned long long)w[4] | ((unsigned long long)w[5] << 32);
+    unsigned long long s3 = (unsigned long long)w[6] | ((unsigned long long)w[7] << 32);
+    u128 initstate = ((u128)s0 << 64) | s1, initseq = ((u128)s2 << 64) | s3;
+    Pcg g;
+    g.inc = (initseq << 1) | 1;
+    g.st = 0;
+    g.st = g.st * pcg_mult() + g.inc;
+    g.st += initstate;
+    g.st = g.st * pcg_mult() + g.inc;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-env state held in registers
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+struct EnvState {
+    float q[6], qd[6];
+    f3 cp[NC];       // cube positions
+    float cq[NC][4]; // cube quaternions (w,x,y,z)
+    f3 cv[NC];       // cube linear velocity (world)
+    f3 cw[NC];       // cube angular velocity (BODY frame, MuJoCo free-joint convention)
+};
+
+template <int NC>
+DEV void load_state(const LcrDev &P, int e, EnvState<NC> &S) {
+    const int N = P.n;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { S.q[j] = P.qpos[j * N + e]; S.qd[j] = P.qvel[j * N + e]; }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const float *qp = P.qpos + (size_t)(6 + 7 * c) * N + e;
+        const float *qv = P.qvel + (size_t)(6 + 6 * c) * N + e;
+        S.cp[c] = mk(qp[0], qp[N], qp[2 * N]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) S.cq[c][k] = qp[(3 + k) * N];
+        S.cv[c] = mk(qv[0], qv[N], qv[2 * N]);
+        S.cw[c] = mk(qv[3 * N], qv[4 * N], qv[5 * N]);
+    }
+}
+template <int NC>
+DEV void store_state(const LcrDev &P, int e, const EnvState<NC> &S) {
+    const int N = P.n;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { P.qpos[j * N + e] = S.q[j]; P.qvel[j * N + e] = S.qd[j]; }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float *qp = P.qpos + (size_t)(6 + 7 * c) * N + e;
+        float *qv = P.qvel + (size_t)(6 + 6 * c) * N + e;
+        qp[0] = S.cp[c].x; qp[N] = S.cp[c].y; qp[2 * N] = S.cp[c].z;
+#pragma unroll
+        for (int k = 0; k < 4; k++) qp[(3 + k) * N] = S.cq[c][k];
+        qv[0] = S.cv[c].x; qv[N] = S.cv[c].y; qv[2 * N] = S.cv[c].z;
+        qv[3 * N] = S.cw[c].x; qv[4 * N] = S.cw[c].y; qv[5 * N] = S.cw[c].z;
+    }
+}
+
+struct CubeRot { f3 X, Y, Z; };  // columns of the cube rotation matrix
+DEV CubeRot quat_to_cols(const float (&q)[4]) {
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    CubeRot R;
+    R.X = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y));
+    R.Y = mk(2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x));
+    R.Z = mk(2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y));
+    return R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// floor <-> cube contact slot (cube-only rows; frame n=+z, t1=+y, t2=-x)
+// ------------------------------------------------------------------------------------------------
+struct FloorSlot {
+    f3 r;            // contact point relative to cube centre (world)
+    float f[4];      // n, t1, t2, torsion
+    float aref[4];
+    float inv[4];    // 1 / (A_ii + R_i)
+    float Rn;
+    bool act;
+};
+
+// ------------------------------------------------------------------------------------------------
+// arm-coupled contact slot: finger sphere vs cube (HASCUBE) or vs floor
+// ------------------------------------------------------------------------------------------------
+struct ArmSlot {
+    f3 n, t1, t2, rc;  // frame and contact point relative to the cube centre (cube slots only)
+    float f[4], aref[4], inv[4];
+    float Rn;
+    bool act;
+};
+
+constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
+constexpr int LDS_SLOT = 4 * LDS_ROW;      // four rows
+constexpr int LDS_FLOATS = 4 * LDS_SLOT;   // four slots -> 24 KiB per wave
+
+// ------------------------------------------------------------------------------------------------
+// one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, f3 &lag_ee, f3 (&lag_cube)[NC]) {
+    using namespace lcrm;
+    // ---- position stage -------------------------------------------------------------------------
+    CubeRot CR[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float n2 = S.cq[c][0] * S.cq[c][0] + S.cq[c][1] * S.cq[c][1] + S.cq[c][2] * S.cq[c][2] + S.cq[c][3] * S.cq[c][3];
+        float in = rsq(n2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) S.cq[c][k] *= in;
+        CR[c] = quat_to_cols(S.cq[c]);
+        lag_cube[c] = S.cp[c];  // P8: body xpos as left behind by this mj_step
+    }
+    ArmFrames F;
+    arm_frames(S.q, F);
+    lag_ee = site_pos(F);
+    f3 z[6], v0[6];  // joint axes and p x z (linear velocity of the world origin per unit joint rate)
+#pragma unroll
+    for (int j = 0; j < 6; j++) { z[j] = joint_axis(F, j); v0[j] = cross(F.p[j], z[j]); }
+
+    // link coms and world inertias
+    f3 com[6];
+    Sym3 Iw[6];
+    com[0] = local_point(F, 0, C1x, C1y, C1z); Iw[0] = world_inertia(F.X[0], F.Y[0], F.Z[0], I1_xx, I1_xy, I1_xz, I1_yy, I1_yz, I1_zz);
+    com[1] = local_point(F, 1, C2x, C2y, C2z); Iw[1] = world_inertia(F.X[1], F.Y[1], F.Z[1], I2_xx, I2_xy, I2_xz, I2_yy, I2_yz, I2_zz);
+    com[2] = local_point(F, 2, C3x, C3y, C3z); Iw[2] = world_inertia(F.X[2], F.Y[2], F.Z[2], I3_xx, I3_xy, I3_xz, I3_yy, I3_yz, I3_zz);
+    com[3] = local_point(F, 3, C4x, C4y, C4z); Iw[3] = world_inertia(F.X[3], F.Y[3], F.Z[3], I4_xx, I4_xy, I4_xz, I4_yy, I4_yz, I4_zz);
+    com[4] = local_point(F, 4, C5x, C5y, C5z); Iw[4] = world_inertia(F.X[4], F.Y[4], F.Z[4], I5_xx, I5_xy, I5_xz, I5_yy, I5_yz, I5_zz);
+    com[5] = local_point(F, 5, C6x, C6y, C6z); Iw[5] = world_inertia(F.X[5], F.Y[5], F.Z[5], I6_xx, I6_xy, I6_xz, I6_yy, I6_yz, I6_zz);
+    const float mass[6] = {M1, M2, M3, M4, M5, M6};
+
+    // ---- joint-space inertia: composite rigid bodies referenced to the WORLD ORIGIN ----------------
+    // composite (m, h = sum m c, I_O = sum I_w + m(|c|^2 1 - c c^T)); column i of M from the composite of links i..6
+    float Mm[6][6];
+    {
+        float mc = 0.f;
+        f3 hc = mk(0.f, 0.f, 0.f);
+        Sym3 Ic = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            const float m = mass[i];
+            const f3 c = com[i];
+            const float cc = dot(c, c);
+            mc += m;
+            hc = axpy(m, c, hc);
+            Ic.xx += Iw[i].xx + m * (cc - c.x * c.x);
+            Ic.yy += Iw[i].yy + m * (cc - c.y * c.y);
+            Ic.zz += Iw[i].zz + m * (cc - c.z * c.z);
+            Ic.xy += Iw[i].xy - m * c.x * c.y;
+            Ic.xz += Iw[i].xz - m * c.x * c.z;
+            Ic.yz += Iw[i].yz - m * c.y * c.z;
+            // spatial momentum of the composite for unit rate of joint i
+            f3 l = axpy(mc, v0[i], cross(z[i], hc));
+            f3 n = symv(Ic, z[i]) + cross(hc, v0[i]);
+#pragma unroll
+            for (int j = 0; j <= i; j++) Mm[i][j] = dot(z[j], n) + dot(v0[j], l);
+            Mm[i][i] += ARMATURE;
+        }
+    }
+    Chol6 CL;
+    chol6(Mm, CL);
+
+    // ---- bias forces: recursive Newton-Euler, zero joint acceleration, base accelerating at -g ------
+    float tau[6];
+    {
+        f3 w = mk(0.f, 0.f, 0.f), wd = mk(0.f, 0.f, 0.f), a = mk(0.f, 0.f, GRAV), pprev = mk(0.f, 0.f, 0.f);
+        f3 Fi[6], Ni[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            f3 r = F.p[i] - pprev;
+            a = a + cross(wd, r) + cross(w, cross(w, r));  // acceleration of this link's origin (rigid with the parent)
+            f3 zq = S.qd[i] * z[i];
+            wd = wd + cross(w, zq);
+            w = w + zq;
+            f3 rc = com[i] - F.p[i];
+            f3 ac = a + cross(wd, rc) + cross(w, cross(w, rc));
+            Fi[i] = mass[i] * ac;
+            Ni[i] = symv(Iw[i], wd) + cross(w, symv(Iw[i], w));
+            pprev = F.p[i];
+        }
+        f3 f = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            f3 nn = Ni[i] + cross(com[i] - F.p[i], Fi[i]);
+            if (i < 5) nn = nn + n + cross(F.p[i + 1] - F.p[i], f);
+            f = f + Fi[i];
+            n = nn;
+            float bias = dot(z[i], n);
+            // passive damping + position actuator (ctrlrange == joint range via inheritrange; joint-level force clamp)
+            float c = clampf(ctrl[i], JLO[i], JHI[i]);
+            float fa = clampf(fmaf(KP, c - S.q[i], -KV * S.qd[i]), -FRC, FRC);
+            tau[i] = fa - DAMPING * S.qd[i] - bias;
+        }
+    }
+    // y = L^T a  (scaled arm acceleration);  y_smooth = L^-1 tau
+    float y[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) y[j] = tau[j];
+    fsub(CL, y);
+    // cube accelerations, world frame (isotropic inertia: no gyroscopic term)
+    f3 ca[NC], cal[NC];
+    f3 cww[NC];  // cube angular velocity in world frame
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        ca[c] = mk(0.f, 0.f, -GRAV);
+        cal[c] = mk(0.f, 0.f, 0.f);
+        cww[c] = axpy(S.cw[c].x, CR[c].X, axpy(S.cw[c].y, CR[c].Y, S.cw[c].z * CR[c].Z));
+    }
+    const float minv = P.cube_minv, iinv = P.cube_iinv;
+
+    // ---- collision: floor <-> cube (MuJoCo plane-box: penetrating vertices in index order, at most 4) ----
+    FloorSlot FS[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { FS[c][s].act = false; FS[c][s].r = mk(0.f, 0.f, 0.f); FS[c][s].Rn = 1.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { FS[c][s].f[k] = 0.f; FS[c][s].aref[k] = 0.f; FS[c][s].inv[k] = 0.f; } }
+        int cnt = 0;
+        float sdist[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
+            f3 rv = axpy(sx, CR[c].X, axpy(sy, CR[c].Y, sz * CR[c].Z));
+            float dist = S.cp[c].z + rv.z;
+            bool pen = dist < 0.f && cnt < 4;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                bool take = pen && cnt == s;
+                FS[c][s].r.x = take ? rv.x : FS[c][s].r.x;
+                FS[c][s].r.y = take ? rv.y : FS[c][s].r.y;
+                FS[c][s].r.z = take ? rv.z - 0.5f * dist : FS[c][s].r.z;  // contact point midway between vertex and plane
+                sdist[s] = take ? dist : sdist[s];
+                FS[c][s].act = FS[c][s].act || take;
+            }
+            cnt += pen ? 1 : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            FloorSlot &T = FS[c][s];
+            float imp = impedance(sdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
+            float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);  // diagApprox = cube body_invweight0 (translational)
+            float Rf = Rn * P.inv_impratio;                          // elliptic cone: friction rows R/impratio
+            float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+            T.Rn = Rn;
+            f3 vp = S.cv[c] + cross(cww[c], T.r);  // velocity of the contact point
+            T.aref[0] = -B_DEF * vp.z - K_DEF * imp * sdist[s];
+            T.aref[1] = -B_DEF * vp.y;
+            T.aref[2] = B_DEF * vp.x;       // t2 = -x
+            T.aref[3] = -B_DEF * cww[c].z;  // torsion about n
+            T.inv[0] = rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn);
+            T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
+            T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
+            T.inv[3] = rcp(iinv + Rt);
+        }
+    }
+
+    // ---- collision: finger spheres (one per finger geom) vs cube / floor; rows g = L^-1 J^T go to LDS ----
+    ArmSlot AS[4];
+    bool slot_any[4];
+    const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
+    const float srad[2] = {SPH0r, SPH1r};
+    int slot_cube[2] = {0, 0};  // which cube each sphere's cube slot refers to
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int sp = s & 1;
+        const bool vs_cube = s < 2;
+        ArmSlot &T = AS[s];
+        f3 pos, n;
+        float dist;
+        int cidx = 0;
+        if (vs_cube) {
+            // sphere vs box: closest point on the box in the box frame
+            float bestd = 1e30f;
+            pos = mk(0.f, 0.f, 0.f); n = mk(0.f, 0.f, 1.f);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                f3 d = sph[sp] - S.cp[c];
+                f3 l = mk(dot(CR[c].X, d), dot(CR[c].Y, d), dot(CR[c].Z, d));
+                f3 qv = mk(clampf(l.x, -CH, CH), clampf(l.y, -CH, CH), clampf(l.z, -CH, CH));
+                bool outside = (l.x != qv.x) || (l.y != qv.y) || (l.z != qv.z);
+                f3 df = l - qv;
+                float dn2 = dot(df, df);
+                float idn = rsq(fmaxf(dn2, 1e-30f));
+                float dn = dn2 * idn;
+                f3 nl_out = idn * df;
+                // centre inside the box: face of least depth (first minimal index)
+                float dx = CH - fabsf(l.x), dy = CH - fabsf(l.y), dz = CH - fabsf(l.z);
+                int best = 0; float bd = dx;
+                if (dy < bd) { bd = dy; best = 1; }
+                if (dz < bd) { bd = dz; best = 2; }
+                float sg = ((best == 0 ? l.x : (best == 1 ? l.y : l.z)) < 0.f) ? -1.f : 1.f;
+                f3 nl_in = mk(best == 0 ? sg : 0.f, best == 1 ? sg : 0.f, best == 2 ? sg : 0.f);
+                f3 q_in = mk(best == 0 ? sg * CH : l.x, best == 1 ? sg * CH : l.y, best == 2 ? sg * CH : l.z);
+                f3 nl = outside ? nl_out : nl_in;
+                f3 ql = outside ? qv : q_in;
+                float dd = outside ? dn - srad[sp] : -(bd + srad[sp]);
+                f3 pl = axpy(0.5f * dd, nl, ql);
+                if (dd < bestd) {  // deepest cube wins (tie: cube 0)
+                    bestd = dd; cidx = c;
+                    n = axpy(nl.x, CR[c].X, axpy(nl.y, CR[c].Y, nl.z * CR[c].Z));
+                    pos = axpy(pl.x, CR[c].X, axpy(pl.y, CR[c].Y, axpy(pl.z, CR[c].Z, S.cp[c])));
+                }
+            }
+            dist = bestd;
+            slot_cube[sp] = cidx;
+        } else {
+            dist = sph[sp].z - srad[sp];
+            n = mk(0.f, 0.f, 1.f);
+            pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
+        }
+        T.act = dist < 0.f;
+        slot_any[s] = __any(T.act) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { T.f[k] = 0.f; T.aref[k] = 0.f; T.inv[k] = 0.f; }
+        T.Rn = 1.f; T.n = n; T.t1 = mk(0.f, 1.f, 0.f); T.t2 = mk(-1.f, 0.f, 0.f); T.rc = mk(0.f, 0.f, 0.f);
+        if (slot_any[s]) {  // wave-uniform: skip the whole row set-up when no lane of the wave touches
+            if (vs_cube) make_frame(n, T.t1, T.t2);
+            const int nj = sp == 0 ? 5 : 6;  // sphere 0 sits on link_5 (joints 1..5), sphere 1 on link_6
+            const float invw_link = sp == 0 ? INVW_TRAN_L5 : INVW_TRAN_L6;
+            f3 cube_p = mk(0.f, 0.f, 0.f), cube_v = mk(0.f, 0.f, 0.f), cube_w = mk(0.f, 0.f, 0.f);
+            if (vs_cube) {
+                if (NC == 2 && cidx == 1) { cube_p = S.cp[NC - 1]; cube_v = S.cv[NC - 1]; cube_w = cww[NC - 1]; }
+                else { cube_p = S.cp[0]; cube_v = S.cv[0]; cube_w = cww[0]; }
+                T.rc = pos - cube_p;
+            }
+            float imp, Kc, Bc, mu0 = MU_FINGER;
+            if (vs_cube) { imp = impedance(dist, D0_FC, DW_FC, 1.0f / W_FC); Kc = K_FC; Bc = B_FC; }
+            else { imp = impedance(dist, D0_FF, DW_FF, 1.0f / W_FF); Kc = K_FF; Bc = B_FF; }
+            float Rn = fmaxf((1.f - imp) * rcp(imp) * (invw_link + (vs_cube ? minv : 0.f)), 1e-15f);
+            float Rf = Rn * P.inv_impratio;
+            float Rt = Rf * (mu0 * mu0) / (MU_TORS * MU_TORS);
+            T.Rn = Rn;
+            // point Jacobian columns of the link at the contact point
+            f3 jc[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) jc[j] = j < nj ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
+                float g[6];
+                float vel = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    g[j] = r < 3 ? dot(jc[j], d) : (j < nj ? dot(z[j], d) : 0.f);
+                    vel = fmaf(g[j], S.qd[j], vel);
+                }
+                float diagc = 0.f;
+                if (vs_cube) {
+                    if (r < 3) {
+                        f3 rxd = cross(T.rc, d);
+                        vel -= dot(d, cube_v) + dot(rxd, cube_w);
+                        diagc = minv + iinv * dot(rxd, rxd);
+                    } else {
+                        vel -= dot(d, cube_w);
+                        diagc = iinv;
+                    }
+                }
+                fsub(CL, g);
+                float gg = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; j++) { gg = fmaf(g[j], g[j], gg); lds[s * LDS_SLOT + r * LDS_ROW + j * 64 + lane] = g[j]; }
+                float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
+                T.inv[r] = rcp(gg + diagc + Rr);
+            }
+        }
+    }
+
+    // ---- joint limits (rare): rows +-e_j ---------------------------------------------------------
+    float flim[6];
+    bool lim_act[6];
+    bool any_lim = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        flim[j] = 0.f;
+        lim_act[j] = (S.q[j] < JLO[j]) || (S.q[j] > JHI[j]);
+        any_lim = any_lim || lim_act[j];
+    }
+    const bool wave_lim = __any(any_lim) != 0;
+    const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3];
+
+    // ---- projected Gauss-Seidel on the dual, matrix-free, cold start, fixed sweeps -----------------
+    for (int it = 0; it < P.pgs_iters; it++) {
+        if (wave_lim) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool lower = S.q[j] < JLO[j];
+                const float sg = lower ? 1.f : -1.f;
+                const float pos = lower ? S.q[j] - JLO[j] : JHI[j] - S.q[j];
+                float imp = impedance(pos, D0_DEF, DW_DEF, 1.0f / W_DEF);
+                float Rl = fmaxf((1.f - imp) * rcp(imp) * INVW_DOF[j], 1e-15f);
+                float aref = -B_DEF * sg * S.qd[j] - K_DEF * imp * pos;
+                float g[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) g[k] = k == j ? sg : 0.f;
+                fsub(CL, g);
+                float gg = 0.f, gy = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { gg = fmaf(g[k], g[k], gg); gy = fmaf(g[k], y[k], gy); }
+                float res = gy - aref + Rl * flim[j];
+                float nf = fmaxf(flim[j] - res * rcp(gg + Rl), 0.f);
+                float dl = lim_act[j] ? nf - flim[j] : 0.f;
+                flim[j] += dl;
+#pragma unroll
+                for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], dl, y[k]);
+            }
+        }
+        // floor <-> cube
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                FloorSlot &T = FS[c][s];
+                const f3 r = T.r;
+                const float Rf = T.Rn * P.inv_impratio;
+                const float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+                // normal row: J = [z ; r x z]
+                float res = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - T.aref[0] + T.Rn * T.f[0];
+                float nf = fmaxf(T.f[0] - res * T.inv[0], 0.f);
+                float d = T.act ? nf - T.f[0] : 0.f;
+                T.f[0] += d;
+                ca[c].z = fmaf(minv, d, ca[c].z);
+                cal[c].x = fmaf(iinv * r.y, d, cal[c].x);
+                cal[c].y = fmaf(-iinv * r.x, d, cal[c].y);
+                // t1 = +y : J = [y ; r x y] = [y ; (-r.z, 0, r.x)]
+                res = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * T.f[1];
+                d = T.act ? -res * T.inv[1] : 0.f;
+                T.f[1] += d;
+                ca[c].y = fmaf(minv, d, ca[c].y);
+                cal[c].x = fmaf(-iinv * r.z, d, cal[c].x);
+                cal[c].z = fmaf(iinv * r.x, d, cal[c].z);
+                // t2 = -x : J = [-x ; r x (-x)] = [-x ; (0, -r.z, r.y)]
+                res = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * T.f[2];
+                d = T.act ? -res * T.inv[2] : 0.f;
+                T.f[2] += d;
+                ca[c].x = fmaf(-minv, d, ca[c].x);
+                cal[c].y = fmaf(-iinv * r.z, d, cal[c].y);
+                cal[c].z = fmaf(iinv * r.y, d, cal[c].z);
+                // torsion about n = z
+                res = cal[c].z - T.aref[3] + Rt * T.f[3];
+                d = T.act ? -res * T.inv[3] : 0.f;
+                T.f[3] += d;
+                cal[c].z = fmaf(iinv, d, cal[c].z);
+                // elliptic cone: radial projection of the friction part
+                float fn = T.f[0];
+                float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * (1.f / (MU_CUBE * MU_CUBE)) + T.f[3] * T.f[3] * (1.f / (MU_TORS * MU_TORS));
+                float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                float d1 = T.f[1] * sc - T.f[1], d2 = T.f[2] * sc - T.f[2], d3 = T.f[3] * sc - T.f[3];
+                T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                ca[c].y = fmaf(minv, d1, ca[c].y);
+                ca[c].x = fmaf(-minv, d2, ca[c].x);
+                cal[c].x = fmaf(-iinv * r.z, d1, cal[c].x);
+                cal[c].y = fmaf(-iinv * r.z, d2, cal[c].y);
+                cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
+            }
+        }
+        // finger spheres
+        if (wave_arm) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                if (!slot_any[s]) continue;
+                ArmSlot &T = AS[s];
+                const bool vs_cube = s < 2;
+                const int sp = s & 1;
+                const float Rf = T.Rn * P.inv_impratio;
+                const float Rt = Rf * (MU_FINGER * MU_FINGER) / (MU_TORS * MU_TORS);
+                float g[4][6];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) g[r][j] = lds[s * LDS_SLOT + r * LDS_ROW + j * 64 + lane];
+                // pick the cube this slot talks to (wave-divergent only for Stack)
+                f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
+                const bool second = vs_cube && NC == 2 && slot_cube[sp] == 1;
+                if (vs_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+                f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // accumulated change of the cube acceleration
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
+                    float gy = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) gy = fmaf(g[r][j], y[j], gy);
+                    f3 rxd = mk(0.f, 0.f, 0.f);
+                    float jc_a = 0.f;
+                    if (vs_cube) {
+                        if (r < 3) { rxd = cross(T.rc, d); jc_a = -(dot(d, a_lin + dl_lin) + dot(rxd, a_ang + dl_ang)); }
+                        else jc_a = -dot(d, a_ang + dl_ang);
+                    }
+                    const float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    float res = gy + jc_a - T.aref[r] + Rr * T.f[r];
+                    float nf = T.f[r] - res * T.inv[r];
+                    if (r == 0) nf = fmaxf(nf, 0.f);
+                    float dlt = T.act ? nf - T.f[r] : 0.f;
+                    T.f[r] += dlt;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) y[j] = fmaf(g[r][j], dlt, y[j]);
+                    if (vs_cube) {
+                        if (r < 3) { dl_lin = axpy(-minv * dlt, d, dl_lin); dl_ang = axpy(-iinv * dlt, rxd, dl_ang); }
+                        else dl_ang = axpy(-iinv * dlt, d, dl_ang);
+                    }
+                }
+                // cone projection
+                {
+                    float fn = T.f[0];
+                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * (1.f / (MU_FINGER * MU_FINGER)) + T.f[3] * T.f[3] * (1.f / (MU_TORS * MU_TORS));
+                    float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+#pragma unroll
+                    for (int r = 1; r < 4; r++) {
+                        const f3 d = r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n);
+                        float dlt = T.f[r] * sc - T.f[r];
+                        T.f[r] += dlt;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) y[j] = fmaf(g[r][j], dlt, y[j]);
+                        if (vs_cube) {
+                            if (r < 3) { dl_lin = axpy(-minv * dlt, d, dl_lin); dl_ang = axpy(-iinv * dlt, cross(T.rc, d), dl_ang); }
+                            else dl_ang = axpy(-iinv * dlt, d, dl_ang);
+                        }
+                    }
+                }
+                if (vs_cube) {
+                    if (NC == 2) {
+                        if (second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }
+                        else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
+                    } else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
+                }
+            }
+        }
+    }
+
+    // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y -------------------
+    float rhs[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float s = rcp(CL.id[i]) * y[i];  // L_ii y_i
+#pragma unroll
+        for (int k = 0; k < i; k++) s = fmaf(CL.L[i][k], y[k], s);
+        rhs[i] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) Mm[j][j] += H * (DAMPING + KV);
+    chol6(Mm, CL);
+    fsub(CL, rhs);
+    bsub(CL, rhs);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        S.qd[j] = fmaf(H, rhs[j], S.qd[j]);
+        S.q[j] = fmaf(H, S.qd[j], S.q[j]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        S.cv[c] = axpy(H, ca[c], S.cv[c]);
+        // body-frame angular acceleration = R^T alpha_world
+        f3 ab = mk(dot(CR[c].X, cal[c]), dot(CR[c].Y, cal[c]), dot(CR[c].Z, cal[c]));
+        S.cw[c] = axpy(H, ab, S.cw[c]);
+        S.cp[c] = axpy(H, S.cv[c], S.cp[c]);
+        // q <- q * exp(h w / 2), normalise  (MuJoCo mju_quatIntegrate)
+        f3 w = S.cw[c];
+        float wn2 = dot(w, w);
+        if (wn2 > 0.f) {
+            float iw = rsq(wn2), wn = wn2 * iw;
+            float sh, chf;
+            sincosf(0.5f * H * wn, &sh, &chf);
+            float s = sh * iw;
+            float dq0 = chf, dq1 = w.x * s, dq2 = w.y * s, dq3 = w.z * s;
+            float q0 = S.cq[c][0], q1 = S.cq[c][1], q2 = S.cq[c][2], q3 = S.cq[c][3];
+            float r0 = q0 * dq0 - q1 * dq1 - q2 * dq2 - q3 * dq3;
+            float r1 = q0 * dq1 + q1 * dq0 + q2 * dq3 - q3 * dq2;
+            float r2 = q0 * dq2 - q1 * dq3 + q2 * dq0 + q3 * dq1;
+            float r3 = q0 * dq3 + q1 * dq2 - q2 * dq1 + q3 * dq0;
+            float in = rsq(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            S.cq[c][0] = r0 * in; S.cq[c][1] = r1 * in; S.cq[c][2] = r2 * in; S.cq[c][3] = r3 * in;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset of one env (reach_cube_env.py:297-311 etc.); sampling in fp64 exactly as numpy does
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+DEV void reset_env(const LcrDev &P, EnvState<NC> &S, Pcg &g, f3 &target, f3 &ee_lag) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        double x = P.cube_lo[0] + P.cube_rng[0] * pcg_double(g);
+        double yv = P.cube_lo[1] + P.cube_rng[1] * pcg_double(g);
+        double zv = P.cube_lo[2] + P.cube_rng[2] * pcg_double(g);
+        S.cp[c] = mk((float)x, (float)yv, (float)zv);
+        S.cq[c][0] = 1.f; S.cq[c][1] = 0.f; S.cq[c][2] = 0.f; S.cq[c][3] = 0.f;
+    }
+    if (P.has_target) {
+        double x = P.tgt_lo[0] + P.tgt_rng[0] * pcg_double(g);
+        double yv = P.tgt_lo[1] + P.tgt_rng[1] * pcg_double(g);
+        double zv = P.tgt_lo[2] + P.tgt_rng[2] * pcg_double(g);
+        target = mk((float)x, (float)yv, (float)zv);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) S.q[j] = 0.f;
+    if (P.compat & 1u) {  // LCR_COMPAT_ZERO_QVEL_ON_RESET; default keeps qvel (the reference has no mj_resetData)
+#pragma unroll
+        for (int j = 0; j < 6; j++) S.qd[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) { S.cv[c] = mk(0.f, 0.f, 0.f); S.cw[c] = mk(0.f, 0.f, 0.f); }
+    }
+    // mj_forward at q = 0 refreshes site_xpos (reach_cube_env.py:309)
+    float q0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ArmFrames F;
+    arm_frames(q0, F);
+    ee_lag = site_pos(F);
+}
+
+DEV Pcg load_rng(const LcrDev &P, int e) {
+    const size_t N = (size_t)P.n;
+    Pcg g;
+    g.st = ((u128)P.rng[e] << 64) | P.rng[N + e];
+    g.inc = ((u128)P.rng[2 * N + e] << 64) | P.rng[3 * N + e];
+    return g;
+}
+DEV void store_rng(const LcrDev &P, int e, const Pcg &g) {
+    const size_t N = (size_t)P.n;
+    P.rng[e] = (unsigned long long)(g.st >> 64);
+    P.rng[N + e] = (unsigned long long)g.st;
+    P.rng[2 * N + e] = (unsigned long long)(g.inc >> 64);
+    P.rng[3 * N + e] = (unsigned long long)g.inc;
+}
+
+// observation vector of the reference (get_observation reach:281-295, push:291-306, stack:290-305)
+template <int NC>
+DEV void write_obs18(const LcrDev &P, float *dst, int e, const EnvState<NC> &S, f3 target) {
+    const int N = P.n;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { dst[j * N + e] = S.q[j]; dst[(6 + j) * N + e] = S.qd[j]; }
+    dst[12 * N + e] = S.cp[0].x; dst[13 * N + e] = S.cp[0].y; dst[14 * N + e] = S.cp[0].z;
+    f3 aux = P.has_target ? target : (NC == 2 ? S.cp[NC - 1] : mk(0.f, 0.f, 0.f));
+    dst[15 * N + e] = aux.x; dst[16 * N + e] = aux.y; dst[17 * N + e] = aux.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the step kernel
+// ------------------------------------------------------------------------------------------------
+template <int NC, bool EE>
+__global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
+    __shared__ float lds[LDS_FLOATS];
+    const int lane = threadIdx.x;
+    const int e_raw = blockIdx.x * 64 + lane;
+    const bool valid = e_raw < P.n;
+    const int e = valid ? e_raw : P.n - 1;  // tail lanes shadow the last env, their stores are masked
+    const int N = P.n;
+
+    EnvState<NC> S;
+    load_state<NC>(P, e, S);
+    f3 target = mk(0.f, 0.f, 0.f);
+    if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
+    int elapsed = P.elapsed[e];
+
+    // ---- apply_action (reach_cube_env.py:223-273) ------------------------------------------------
+    float act[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) act[i] = i < P.k ? clampf(action[(size_t)i * N + e], -1.f, 1.f) : 0.f;  // np.clip reach:234
+    float ctrl[6];
+    f3 lag_ee = mk(0.f, 0.f, 0.f);
+    if (EE) {
+        f3 eel = mk(P.ee_lag[e], P.ee_lag[N + e], P.ee_lag[2 * N + e]);
+        f3 tgt = mk(eel.x + act[0] * 0.05f, eel.y + act[1] * 0.05f, fmaxf(eel.z + act[2] * 0.05f, 0.f));  // reach:241-242
+        // inverse_kinematics (reach:148-221): fixed 10 iterations with a per-lane "frozen" mask instead of break
+        float qk[6], qstate[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { qk[j] = S.q[j]; qstate[j] = S.q[j]; }
+        bool done = false;
+        for (int it = 0; it < 10; it++) {
+            ArmFrames F;
+            arm_frames(qk, F);
+            f3 site = site_pos(F);
+            f3 err = tgt - site;
+            if (!done) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) qstate[j] = qk[j];  // reach:185 writes the sim state (REF-QUIRK-3)
+            }
+            done = done || (dot(err, err) < 0.01f * 0.01f);  // reach:193
+            // translational site Jacobian, site on link_5 => column 6 is zero (reach:197)
+            f3 Jc[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) Jc[j] = cross(joint_axis(F, j), site - F.p[j]);
+            // (J^T J + 0.15 I) qdot = J^T e  (reach:200-202); the 6th equation is 0.15 qdot_6 = 0
+            float A[6][6], b[6];
+#pragma unroll
+            for (int a = 0; a < 5; a++) {
+#pragma unroll
+                for (int c2 = 0; c2 <= a; c2++) A[a][c2] = dot(Jc[a], Jc[c2]) + (a == c2 ? 0.15f : 0.f);
+                b[a] = dot(Jc[a], err);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 5; c2++) A[5][c2] = 0.f;
+            A[5][5] = 0.15f; b[5] = 0.f;
+            Chol6 C;
+            chol6(A, C);
+            fsub(C, b);
+            bsub(C, b);
+            float nn = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) nn = fmaf(b[j], b[j], nn);
+            float scale = nn > 1.f ? rsq(nn) : 1.f;  // reach:210-212
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                float qn = clampf(fmaf(b[j] * scale, 0.5f, qk[j]), JLO[j], JHI[j]);  // reach:215, 141-146
+                qk[j] = done ? qk[j] : qn;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ctrl[j] = qk[j]; S.q[j] = qstate[j]; }
+        if (P.gripper_active) ctrl[5] = clampf(S.q[5] + act[3] * 0.2f, JLO[5], JHI[5]);  // lift:253-257
+        else ctrl[5] = 0.f;                                                                  // reach:247
+    } else {
+        const float TLO[6] = {-3.14159f, -1.5708f, -1.48353f, -1.91986f, -2.96706f, -1.74533f};  // reach:249-250
+        const float THI[6] = {3.14159f, 1.22173f, 1.74533f, 1.91986f, 2.96706f, 0.0523599f};
+#pragma unroll
+        for (int j = 0; j < 5; j++) ctrl[j] = clampf(act[j] + S.q[j], TLO[j], THI[j]);
+        float ga = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) ga = (i == P.k - 1) ? act[i] : ga;  // lift:264 action[-1]
+        ctrl[5] = P.gripper_active ? clampf(ga + S.q[5], TLO[5], THI[5]) : 0.f;
+    }
+
+    // ---- n_substeps x mj_step (reach:276-279) -----------------------------------------------------
+    f3 lag_cube[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) lag_cube[c] = S.cp[c];
+    for (int s = 0; s < P.n_substeps; s++) substep<NC>(P, S, ctrl, lds, lane, lag_ee, lag_cube);
+
+    // ---- reward / success / termination (reach:313-348 and per-task deltas), lagged kinematics (P8) ----
+    f3 a3, b3;
+    float reward;
+    bool success, terminated;
+    {
+        const int task = P.task;
+        if (task == 0) { a3 = lag_ee; b3 = lag_cube[0]; }
+        else if (task == 4) { a3 = lag_cube[NC - 1]; b3 = mk(lag_cube[0].x, lag_cube[0].y, lag_cube[0].z + 0.03f); }
+        else if (task == 1) { a3 = lag_ee; b3 = lag_cube[0]; }
+        else { a3 = lag_cube[0]; b3 = target; }
+        f3 df = a3 - b3;
+        float d = sqrtf(dot(df, df));
+        if (task == 1) {  // lift:341-345: (cube_z - height_threshold) + distance, never terminates, info = {}
+            reward = (lag_cube[0].z - P.height_thr) + d;
+            success = false; terminated = false;
+        } else {
+            success = d < P.dist_thr;
+            terminated = success;
+            // sparse: -(d > thr) as float32, i.e. -0.0f inside the threshold (reach:345-346); bit pattern built explicitly
+            reward = P.reward_type == 0 ? __uint_as_float(0x80000000u | (d > P.dist_thr ? 0x3f800000u : 0u)) : -d;
+        }
+    }
+    elapsed += 1;
+    const bool truncated = P.max_steps > 0 && elapsed >= P.max_steps;  // gymnasium TimeLimit
+    const bool do_reset = P.auto_reset && (terminated || truncated);
+    if (valid) {
+        P.reward[e] = reward;
+        P.terminated[e] = terminated;
+        P.truncated[e] = truncated;
+        P.is_success[e] = success;
+        P.did_reset[e] = do_reset;
+    }
+    if (do_reset) {  // SB3 VecEnv semantics: keep the terminal observation, then reset in place
+        if (valid) write_obs18<NC>(P, P.term_obs, e, S, target);
+        Pcg g = load_rng(P, e);
+        reset_env<NC>(P, S, g, target, lag_ee);
+        if (valid) {
+            store_rng(P, e, g);
+            if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }
+        }
+        elapsed = 0;
+    }
+    if (valid) {
+        store_state<NC>(P, e, S);
+        P.elapsed[e] = elapsed;
+        P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// explicit reset kernel
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void lcr_reset_kernel(LcrDev P, const unsigned char *mask, const unsigned long long *seeds,
+                                                          int seed_from_base, unsigned long long base_seed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n) return;
+    if (mask && !mask[e]) return;
+    const int N = P.n;
+    EnvState<NC> S;
+    load_state<NC>(P, e, S);
+    Pcg g;
+    if (seeds) g = pcg_seed(seeds[e]);
+    else if (seed_from_base) g = pcg_seed(base_seed + (unsigned long long)(P.env_off + e));
+    else g = load_rng(P, e);
+    f3 target = mk(0.f, 0.f, 0.f), ee;
+    if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
+    reset_env<NC>(P, S, g, target, ee);
+    store_rng(P, e, g);
+    store_state<NC>(P, e, S);
+    if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }
+    P.ee_lag[e] = ee.x; P.ee_lag[N + e] = ee.y; P.ee_lag[2 * N + e] = ee.z;
+    P.elapsed[e] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic policy: U(-1,1) from Philox4x32-10 keyed (seed, global env id, step)
+// ------------------------------------------------------------------------------------------------
+DEV void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ __launch_bounds__(256) void lcr_fill_actions_kernel(float *action, int n, int k, long long env_off, unsigned long long seed,
+                                                                 unsigned long long step) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const unsigned long long gid = (unsigned long long)(env_off + e);
+    for (int blk = 0; blk * 4 < k; blk++) {
+        uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)blk << 24)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; r++) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int comp = blk * 4 + i;
+            if (comp < k) action[(size_t)comp * n + e] = (float)(c[i] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// image observation STUB (observation_mode image/both): two 240x320x3 uint8 frames per env.  Not a
+// renderer -- a flat background with the cube(s) splatted as a small square under a fixed orthographic
+// map; exists so that the HBM-write-bound shape of the image configs can be measured.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lcr_image_stub_kernel(LcrDev P, int ncube) {
+    const int env = blockIdx.x;
+    const int N = P.n;
+    const size_t img_bytes = (size_t)240 * 320 * 3;
+    // cube centres -> pixel centres (front: x,z ; top: x,y), 800 px per metre
+    float cx[2], cy[2], cz[2];
+    for (int c = 0; c < 2; c++) {
+        int cc = c < ncube ? c : 0;
+        cx[c] = P.qpos[(size_t)(6 + 7 * cc) * N + env];
+        cy[c] = P.qpos[(size_t)(7 + 7 * cc) * N + env];
+        cz[c] = P.qpos[(size_t)(8 + 7 * cc) * N + env];
+    }
+    // each thread writes 16 bytes (uint4) at a time: 230400 B / 16 = 14400 vectors per image
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 *front = reinterpret_cast<u32x4 *>(P.img_front + (size_t)env * img_bytes);
+    u32x4 *top = reinterpret_cast<u32x4 *>(P.img_top + (size_t)env * img_bytes);
+    for (int v = blockIdx.y * blockDim.x + threadIdx.x; v < 14400; v += gridDim.y * blockDim.x) {
+        unsigned char fb[16], tb[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            int byte = v * 16 + b, pix = byte / 3, ch = byte - pix * 3;
+            int py = pix / 320, px = pix - py * 320;
+            unsigned char bgf = py < 160 ? (unsigned char)(60 + ch * 30) : (unsigned char)(40 + ch * 10);
+            unsigned char bgt = (unsigned char)(50 + ch * 12);
+            unsigned char vf = bgf, vt = bgt;
+            for (int c = 0; c < 2; c++) {
+                if (c >= ncube) break;
+                float fx = 160.f + 800.f * cx[c], fz = 200.f - 800.f * cz[c];
+                float tx = 160.f + 800.f * cx[c], ty = 200.f - 800.f * cy[c];
+                unsigned char col = (c == 0) ? (ch == 0 ? 200 : 20) : (ch == 2 ? 200 : 20);
+                if (fabsf(px - fx) < 12.f && fabsf(py - fz) < 12.f) vf = col;
+                if (fabsf(px - tx) < 12.f && fabsf(py - ty) < 12.f) vt = col;
+            }
+            fb[b] = vf; tb[b] = vt;
+        }
+        u32x4 f4, t4;
+        f4.x = fb[0] | (fb[1] << 8) | (fb[2] << 16) | ((unsigned)fb[3] << 24);
+        f4.y = fb[4] | (fb[5] << 8) | (fb[6] << 16) | ((unsigned)fb[7] << 24);
+        f4.z = fb[8] | (fb[9] << 8) | (fb[10] << 16) | ((unsigned)fb[11] << 24);
+        f4.w = fb[12] | (fb[13] << 8) | (fb[14] << 16) | ((unsigned)fb[15] << 24);
+        t4.x = tb[0] | (tb[1] << 8) | (tb[2] << 16) | ((unsigned)tb[3] << 24);
+        t4.y = tb[4] | (tb[5] << 8) | (tb[6] << 16) | ((unsigned)tb[7] << 24);
+        t4.z = tb[8] | (tb[9] << 8) | (tb[10] << 16) | ((unsigned)tb[11] << 24);
+        t4.w = tb[12] | (tb[13] << 8) | (tb[14] << 16) | ((unsigned)tb[15] << 24);
+        __builtin_nontemporal_store(f4, front + v);
+        __builtin_nontemporal_store(t4, top + v);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int check_launch() {
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : (int)err;
+}
+
+int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (P.n + 63) / 64;
+    const bool stack = P.task == 4;
+    if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    return check_launch();
+}
+
+int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,
+                     unsigned long long base_seed, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (P.n + 255) / 256;
+    if (P.task == 4) hipLaunchKernelGGL((lcr_reset_kernel<2>), dim3(blocks), dim3(256), 0, st, P, mask_dev, seeds_dev, seed_from_base, base_seed);
+    else hipLaunchKernelGGL((lcr_reset_kernel<1>), dim3(blocks), dim3(256), 0, st, P, mask_dev, seeds_dev, seed_from_base, base_seed);
+    return check_launch();
+}
+
+int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed, unsigned long long step,
+                            void *stream) {
+    hipLaunchKernelGGL(lcr_fill_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, action_dev, n, k, env_off, seed, step);
+    return check_launch();
+}
+
+int lcr_launch_image_stub(const LcrDev &P, void *stream) {
+    if (!P.img_front || !P.img_top) return 0;
+    hipLaunchKernelGGL(lcr_image_stub_kernel, dim3(P.n, 8), dim3(256), 0, (hipStream_t)stream, P, P.task == 4 ? 2 : 1);
+    return check_launch();
+}

@@ -1,0 +1,239 @@
+"""VecSim: N independent low-cost-robot environments stepped in lockstep on one MI355X.
+
+Thin host-side mirror of the reference env classes' reset()/step() for a batch (reference:
+gym_lowcostrobot/envs/reach_cube_env.py:297-333 and the four sibling files).  All arithmetic happens in
+the HIP kernels behind the C ABI (include/lcr.h); this file only owns handles and moves bytes.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _capi
+from ._capi import ACTION_MODES, OBS_MODES, REWARD_TYPES, TASKS, LcrConfig, LcrObsView, LcrOutView, check
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class DeviceArray:
+    """A typed view of device memory exposing __cuda_array_interface__ (zero-copy into torch on ROCm)."""
+
+    def __init__(self, sim, ptr, shape, dtype, readonly=True):
+        self._sim = sim  # keeps the owner alive
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.__cuda_array_interface__ = {
+            "shape": self.shape,
+            "typestr": self.dtype.str,
+            "data": (self.ptr, bool(readonly)),
+            "version": 3,
+            "strides": None,
+        }
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        check(self._sim.L.lcr_memcpy_d2h(self._sim.handle, _vp(out), ctypes.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def torch(self):
+        import torch
+
+        return torch.as_tensor(self, device=f"cuda:{self._sim.device}")
+
+
+class VecSim:
+    def __init__(
+        self,
+        task,
+        n_envs=1,
+        *,
+        device=0,
+        env_id_offset=0,
+        observation_mode="state",
+        action_mode="joint",
+        reward_type="sparse",
+        block_gripper=None,
+        distance_threshold=0.05,
+        cube_xy_range=0.3,
+        target_xy_range=0.3,
+        goal_z_range=0.1,
+        height_threshold=0.1,
+        n_substeps=20,
+        max_episode_steps=50,
+        impratio=100.0,
+        pgs_iters=10,
+        compat=0,
+        auto_reset=True,
+        base_seed=0,
+    ):
+        self.L = _capi.load()
+        if action_mode not in ACTION_MODES:
+            raise ValueError("Invalid action mode, must be 'ee' or 'joint'")  # reach_cube_env.py:269-270
+        if observation_mode not in OBS_MODES:
+            raise ValueError(f"invalid observation_mode {observation_mode!r}")
+        if reward_type not in REWARD_TYPES:
+            raise ValueError(f"invalid reward_type {reward_type!r}")
+        self.task_name = task if isinstance(task, str) else {v: k for k, v in TASKS.items()}[task]
+        cfg = LcrConfig()
+        check(self.L.lcr_config_default(ctypes.byref(cfg), TASKS[self.task_name]))
+        cfg.n_envs = int(n_envs)
+        cfg.device = int(device)
+        cfg.env_id_offset = int(env_id_offset)
+        cfg.action_mode = ACTION_MODES[action_mode]
+        cfg.obs_mode = OBS_MODES[observation_mode]
+        cfg.reward_type = REWARD_TYPES[reward_type]
+        cfg.block_gripper = -1 if block_gripper is None else int(bool(block_gripper))
+        cfg.distance_threshold = distance_threshold
+        cfg.cube_xy_range = cube_xy_range
+        cfg.target_xy_range = target_xy_range
+        cfg.goal_z_range = goal_z_range
+        cfg.height_threshold = height_threshold
+        cfg.impratio = impratio
+        cfg.n_substeps = int(n_substeps)
+        cfg.max_episode_steps = int(max_episode_steps)
+        cfg.pgs_iters = int(pgs_iters)
+        cfg.compat = int(compat)
+        cfg.auto_reset = int(bool(auto_reset))
+        cfg.base_seed = int(base_seed)
+        self.cfg = cfg
+        self.n = int(n_envs)
+        self.device = int(device)
+        self.action_dim = check(self.L.lcr_action_dim(ctypes.byref(cfg)))
+        self.nq = self.L.lcr_nq(cfg.task)
+        self.nv = self.L.lcr_nv(cfg.task)
+        h = ctypes.c_void_p()
+        check(self.L.lcr_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.handle = h
+        ov, out = LcrObsView(), LcrOutView()
+        check(self.L.lcr_get_obs(self.handle, ctypes.byref(ov)))
+        check(self.L.lcr_get_outputs(self.handle, ctypes.byref(out)))
+        N = self.n
+        self.has_aux = bool(ov.has_aux)
+        self.aux_name = {"push": "target_pos", "pick_place": "target_pos", "stack": "cube_blue_pos"}.get(self.task_name)
+        self.cube_name = "cube_red_pos" if self.task_name == "stack" else "cube_pos"
+        self.arm_qpos = DeviceArray(self, ov.arm_qpos, (6, N), np.float32)
+        self.arm_qvel = DeviceArray(self, ov.arm_qvel, (6, N), np.float32)
+        self.cube_pos = DeviceArray(self, ov.cube_pos, (3, N), np.float32)
+        self.aux_pos = DeviceArray(self, ov.aux_pos, (3, N), np.float32) if ov.has_aux else None
+        img = (N, _capi.IMG_H, _capi.IMG_W, 3)
+        self.image_front = DeviceArray(self, ov.image_front, img, np.uint8) if ov.image_front else None
+        self.image_top = DeviceArray(self, ov.image_top, img, np.uint8) if ov.image_top else None
+        self.reward = DeviceArray(self, out.reward, (N,), np.float32)
+        self.terminated = DeviceArray(self, out.terminated, (N,), np.uint8)
+        self.truncated = DeviceArray(self, out.truncated, (N,), np.uint8)
+        self.is_success = DeviceArray(self, out.is_success, (N,), np.uint8)
+        self.did_reset = DeviceArray(self, out.did_reset, (N,), np.uint8)
+        self.terminal_obs = DeviceArray(self, out.terminal_obs, (18, N), np.float32)
+
+    # ---- lifecycle ----
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.lcr_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        check(self.L.lcr_set_stream(self.handle, ctypes.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+    def sync(self):
+        check(self.L.lcr_sync(self.handle))
+
+    # ---- reset / step ----
+    def reset(self, seeds=None, mask=None):
+        s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        if s is not None and s.shape != (self.n,):
+            raise ValueError("seeds must have shape (n_envs,)")
+        if m is not None and m.shape != (self.n,):
+            raise ValueError("mask must have shape (n_envs,)")
+        check(self.L.lcr_reset(self.handle, _vp(m), _vp(s)))
+
+    def step_device(self, action_ptr):
+        """action_ptr: device pointer to float32 [k][N] (e.g. tensor.data_ptr())."""
+        check(self.L.lcr_step(self.handle, ctypes.c_void_p(int(action_ptr))))
+
+    def step(self, action):
+        """action: host array, shape (N, k) (env-major, as a VecEnv passes it) -> transposed to [k][N]."""
+        a = np.asarray(action, np.float32)
+        if a.shape != (self.n, self.action_dim):
+            raise ValueError("Action dimension mismatch")  # reach_cube_env.py:231-232
+        at = np.ascontiguousarray(a.T)
+        check(self.L.lcr_step_host(self.handle, _vp(at)))
+
+    # ---- device helpers ----
+    def alloc_actions(self):
+        p = ctypes.c_void_p()
+        check(self.L.lcr_malloc(self.handle, 4 * self.action_dim * self.n, ctypes.byref(p)))
+        return DeviceArray(self, p.value, (self.action_dim, self.n), np.float32, readonly=False)
+
+    def free(self, arr):
+        check(self.L.lcr_free(self.handle, ctypes.c_void_p(arr.ptr)))
+
+    def fill_random_actions(self, arr, seed, step):
+        check(self.L.lcr_fill_random_actions(self.handle, ctypes.c_void_p(arr.ptr), int(seed), int(step)))
+
+    def timer_begin(self):
+        check(self.L.lcr_timer_begin(self.handle))
+
+    def timer_end(self):
+        ms = ctypes.c_float()
+        check(self.L.lcr_timer_end(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- host-side views ----
+    def observations(self):
+        """dict of (N, .) float32 numpy arrays with the reference's keys (get_observation reach:281-295)."""
+        obs = {"arm_qpos": self.arm_qpos.numpy().T.copy(), "arm_qvel": self.arm_qvel.numpy().T.copy()}
+        if OBS_MODES["state"] == self.cfg.obs_mode or OBS_MODES["both"] == self.cfg.obs_mode:
+            obs[self.cube_name] = self.cube_pos.numpy().T.copy()
+            if self.task_name == "stack":
+                obs["cube_blue_pos"] = self.aux_pos.numpy().T.copy()
+        if self.task_name in ("push", "pick_place"):
+            obs["target_pos"] = self.aux_pos.numpy().T.copy()  # always present (push_cube_env.py:297)
+        if self.image_front is not None:
+            obs["image_front"] = self.image_front.numpy()
+            obs["image_top"] = self.image_top.numpy()
+        return obs
+
+    def outputs(self):
+        return {
+            "reward": self.reward.numpy(),
+            "terminated": self.terminated.numpy().astype(bool),
+            "truncated": self.truncated.numpy().astype(bool),
+            "is_success": self.is_success.numpy().astype(bool),
+            "did_reset": self.did_reset.numpy().astype(bool),
+        }
+
+    def get_state(self):
+        N = self.n
+        st = {
+            "qpos": np.zeros((self.nq, N)), "qvel": np.zeros((self.nv, N)), "ee_lag": np.zeros((3, N)),
+            "target": np.zeros((3, N), np.float32), "elapsed": np.zeros(N, np.int32), "rng": np.zeros((4, N), np.uint64),
+        }
+        check(self.L.lcr_get_state(self.handle, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["ee_lag"]), _vp(st["target"]),
+                                   _vp(st["elapsed"]), _vp(st["rng"])))
+        return st
+
+    def set_state(self, qpos=None, qvel=None, ee_lag=None, target=None, elapsed=None, rng=None):
+        N = self.n
+
+        def prep(a, shape, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            if a.shape != shape:
+                raise ValueError(f"bad state shape {a.shape}, want {shape}")
+            return a
+
+        qpos, qvel = prep(qpos, (self.nq, N), np.float64), prep(qvel, (self.nv, N), np.float64)
+        ee_lag, target = prep(ee_lag, (3, N), np.float64), prep(target, (3, N), np.float32)
+        elapsed, rng = prep(elapsed, (N,), np.int32), prep(rng, (4, N), np.uint64)
+        check(self.L.lcr_set_state(self.handle, _vp(qpos), _vp(qvel), _vp(ee_lag), _vp(target), _vp(elapsed), _vp(rng)))

@@ -1,0 +1,174 @@
+/*
+ * lcr.h -- C ABI of the MI355X-native batched low-cost-robot simulator (liblcr_hip.so).
+ *
+ * Drop-in boundary for the ONE hot path of perezjln/gym-lowcostrobot: batched reset()/step() of the
+ * ReachCube / LiftCube / PushCube / PickPlaceCube / StackTwoCubes environments.  Each entry point
+ * cites the reference interface it replaces (paths relative to /root/reference/gym_lowcostrobot/).
+ *
+ * Conventions
+ *   - one handle (lcr_sim) per GPU; a handle is NOT thread-safe, distinct handles may be driven from
+ *     distinct threads / processes (one process per GPU is the intended multi-GPU mode, no collectives).
+ *   - every function returns 0 on success or a negative lcr_status; nothing throws across the boundary;
+ *     lcr_last_error() gives a thread-local message for the last failure.
+ *   - "dev" pointers are HIP device pointers on the handle's device; "host" pointers are ordinary memory.
+ *   - all per-env arrays are SoA  [component][env]  with env fastest (coalesced: lane == env), fp32.
+ *   - work is enqueued on the handle's HIP stream (lcr_set_stream) and is asynchronous unless stated.
+ *   - there is NO CPU fallback: without a gfx950 device lcr_create fails with LCR_ERR_NO_DEVICE.
+ */
+#ifndef LCR_H
+#define LCR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCR_ABI_VERSION 1
+
+typedef enum lcr_status {
+    LCR_OK = 0,
+    LCR_ERR_INVALID = -1,     /* bad argument / config (maps to ValueError in the Python facade) */
+    LCR_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture */
+    LCR_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    LCR_ERR_OOM = -4,
+    LCR_ERR_UNSUPPORTED = -5
+} lcr_status;
+
+/* gym_lowcostrobot/__init__.py:9-43 registry ids */
+typedef enum lcr_task {
+    LCR_TASK_REACH = 0,       /* ReachCube-v0       envs/reach_cube_env.py */
+    LCR_TASK_LIFT = 1,        /* LiftCube-v0        envs/lift_cube_env.py */
+    LCR_TASK_PUSH = 2,        /* PushCube-v0        envs/push_cube_env.py */
+    LCR_TASK_PICK_PLACE = 3,  /* PickPlaceCube-v0   envs/pick_place_cube_env.py */
+    LCR_TASK_STACK = 4        /* StackTwoCubes-v0   envs/stack_two_cubes_env.py */
+} lcr_task;
+
+enum { LCR_ACTION_JOINT = 0, LCR_ACTION_EE = 1 };            /* action_mode   reach_cube_env.py:80 */
+enum { LCR_OBS_IMAGE = 0, LCR_OBS_STATE = 1, LCR_OBS_BOTH = 2 }; /* observation_mode reach_cube_env.py:79 */
+enum { LCR_REWARD_SPARSE = 0, LCR_REWARD_DENSE = 1 };        /* reward_type   reach_cube_env.py:81 */
+
+/* compat bits: every reference quirk is reproduced when the bit is CLEAR */
+enum {
+    LCR_COMPAT_ZERO_QVEL_ON_RESET = 1u << 0 /* set: zero qvel in reset (deviates from reach_cube_env.py:297-311) */
+};
+
+#define LCR_IMG_H 240
+#define LCR_IMG_W 320
+
+/* Constructor kwargs of the reference env classes (reach_cube_env.py:77-87, lift_cube_env.py:77-88,
+ * push_cube_env.py:79-90, pick_place_cube_env.py:79-91, stack_two_cubes_env.py:78-88) plus the batch
+ * / device placement the reference does not have. */
+typedef struct lcr_config {
+    uint32_t struct_size;      /* = sizeof(lcr_config), ABI check */
+    int32_t task;              /* lcr_task */
+    int32_t n_envs;            /* envs on this GPU */
+    int32_t device;            /* HIP device ordinal */
+    int64_t env_id_offset;     /* global id of env 0 (sharding: GPU g owns [g*N/G, (g+1)*N/G)) */
+    int32_t action_mode;
+    int32_t obs_mode;
+    int32_t reward_type;
+    int32_t block_gripper;     /* -1 = task default (reach/push: 1, others: 0) */
+    double distance_threshold; /* 0.05  (doubles: the reset sampling boxes are built in fp64 exactly as the */
+    double cube_xy_range;      /* 0.3    reference does, reach_cube_env.py:132-139)                        */
+    double target_xy_range;    /* 0.3 */
+    double goal_z_range;       /* 0.1  (pick_place) */
+    double height_threshold;   /* 0.1  (lift) */
+    double impratio;           /* 100, follower.xml:3 */
+    int32_t n_substeps;        /* 20 */
+    int32_t max_episode_steps; /* 50, gymnasium TimeLimit configured at __init__.py:12-42; <=0 disables */
+    int32_t pgs_iters;         /* contact solver sweeps per substep, 10 */
+    uint32_t compat;
+    int32_t auto_reset;        /* 1: SB3 VecEnv semantics fused in the step kernel */
+    int32_t _pad;
+    uint64_t base_seed;        /* envs never explicitly seeded use SeedSequence(base_seed + global env id) */
+} lcr_config;
+
+typedef struct lcr_sim lcr_sim;
+
+/* Read-only device views.  arm_qpos/arm_qvel/cube_pos (and cube_blue_pos for Stack) alias the state
+ * arrays themselves (get_observation() reach_cube_env.py:281-295 returns exactly those qpos/qvel
+ * slices cast to float32); target_pos aliases the per-env target (push_cube_env.py:297). */
+typedef struct lcr_obs_view {
+    int32_t n_envs;
+    int32_t has_aux;            /* 1 if aux_pos is meaningful (push/pick_place: target_pos; stack: cube_blue_pos) */
+    const float *arm_qpos;      /* [6][N] */
+    const float *arm_qvel;      /* [6][N] */
+    const float *cube_pos;      /* [3][N]  (stack: cube_red_pos) */
+    const float *aux_pos;       /* [3][N]  or NULL */
+    const uint8_t *image_front; /* [N][240][320][3] or NULL (observation_mode image/both) -- render STUB */
+    const uint8_t *image_top;   /* [N][240][320][3] or NULL */
+} lcr_obs_view;
+
+/* step() return values (reach_cube_env.py:313-333) + SB3 auto-reset bookkeeping */
+typedef struct lcr_out_view {
+    int32_t n_envs;
+    int32_t _pad;
+    const float *reward;        /* [N] */
+    const uint8_t *terminated;  /* [N] */
+    const uint8_t *truncated;   /* [N]  TimeLimit */
+    const uint8_t *is_success;  /* [N]  info["is_success"] (lift: always 0, reference returns info={}) */
+    const uint8_t *did_reset;   /* [N]  1 where the env was auto-reset at the end of this step */
+    const float *terminal_obs;  /* [18][N] arm_qpos6, arm_qvel6, cube_pos3, aux3 -- valid where did_reset */
+} lcr_out_view;
+
+int lcr_abi_version(void);
+const char *lcr_last_error(void);
+
+/* Fill `cfg` with the reference constructor defaults for `task`. */
+int lcr_config_default(lcr_config *cfg, int task);
+/* Number of action components k for a config: {joint:5, ee:3} + (0 if block_gripper else 1)  (reach_cube_env.py:95-96) */
+int lcr_action_dim(const lcr_config *cfg);
+int lcr_nq(int task); /* 13, stack 20 */
+int lcr_nv(int task); /* 12, stack 18 */
+
+/* == EnvClass.__init__ (reach_cube_env.py:77-139): allocate device state for n_envs envs.  The envs are
+ * left in the post-reset state of seed (base_seed + global env id). */
+int lcr_create(const lcr_config *cfg, lcr_sim **out);
+void lcr_destroy(lcr_sim *sim); /* == close() reach_cube_env.py:357-363 */
+
+/* HIP stream (hipStream_t passed as void*) all later work is enqueued on; NULL = default stream. */
+int lcr_set_stream(lcr_sim *sim, void *hip_stream);
+int lcr_sync(lcr_sim *sim); /* hipStreamSynchronize on the handle's stream */
+
+/* == reset(seed) (reach_cube_env.py:297-311, push:308-328, pick_place:316-336, stack:307-324).
+ * mask_host: N bytes, nonzero = reset that env, NULL = all.  seeds_host: N uint64, env i is re-seeded
+ * with numpy's Generator(PCG64(SeedSequence(seeds[i]))) before sampling; NULL = continue each env's
+ * generator stream (gymnasium reset(seed=None) semantics). */
+int lcr_reset(lcr_sim *sim, const uint8_t *mask_host, const uint64_t *seeds_host);
+
+/* == step(action) (reach_cube_env.py:313-333) for all envs: apply_action (joint or ee+IK) -> 20 physics
+ * substeps -> reward / terminated / truncated -> fused auto-reset.  action_dev: [k][N] float32. */
+int lcr_step(lcr_sim *sim, const float *action_dev);
+/* Convenience for host callers (single-env facade): copies [k][N] host floats then steps. */
+int lcr_step_host(lcr_sim *sim, const float *action_host);
+
+int lcr_get_obs(lcr_sim *sim, lcr_obs_view *out);
+int lcr_get_outputs(lcr_sim *sim, lcr_out_view *out);
+
+/* Full simulator state (replaces poking env.data.qpos / env.data.qvel, e.g. examples/dynamixel_gym_leader.py:96-98;
+ * also checkpoint/resume and the "(qpos, qvel, action) triple" parity tests).  Host pointers, any may be
+ * NULL, SoA [component][N]; synchronous. */
+int lcr_get_state(lcr_sim *sim, double *qpos /*[nq][N]*/, double *qvel /*[nv][N]*/, double *ee_lag /*[3][N]*/,
+                  float *target /*[3][N]*/, int32_t *elapsed /*[N]*/, uint64_t *rng /*[4][N]*/);
+int lcr_set_state(lcr_sim *sim, const double *qpos, const double *qvel, const double *ee_lag, const float *target,
+                  const int32_t *elapsed, const uint64_t *rng);
+
+/* small device-memory helpers so a ctypes/numpy caller needs no other GPU library */
+int lcr_malloc(lcr_sim *sim, size_t bytes, void **dev_out);
+int lcr_free(lcr_sim *sim, void *dev);
+int lcr_memcpy_h2d(lcr_sim *sim, void *dst_dev, const void *src_host, size_t bytes); /* synchronous */
+int lcr_memcpy_d2h(lcr_sim *sim, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
+
+/* HIP-event timing on the handle's stream: begin, enqueue work, end (synchronises) -> milliseconds */
+int lcr_timer_begin(lcr_sim *sim);
+int lcr_timer_end(lcr_sim *sim, float *ms_out);
+
+/* Fill action_dev [k][N] with U(-1,1) from a counter-based generator keyed (seed, global env id, step):
+ * the synthetic policy of the benchmark; shard-invariant by construction. */
+int lcr_fill_random_actions(lcr_sim *sim, float *action_dev, uint64_t seed, uint64_t step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCR_H */

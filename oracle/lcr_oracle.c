@@ -74,13 +74,14 @@ static const double TGT_LO[6] = {-3.14159, -1.5708, -1.48353, -1.91986, -2.96706
 static const double TGT_HI[6] = {3.14159, 1.22173, 1.74533, 1.91986, 2.96706, 0.0523599};
 static const double SITE_POS[3] = {-0.06429, 0.00327, 0.0011}; /* follower.xml:91, on link_5 */
 
-/* (D3) finger proxies: spheres fitted to the fixed-finger part of the link_5_collision hull and to the
+/* (D3) finger proxies: ONE sphere per finger geom (MuJoCo's convex mesh collider also yields one contact
+ * point per geom pair), fitted to the tip of the fixed finger of the link_5_collision hull and to the
  * jaw tip of the link_6_collision hull (follower.xml:89,97; extents in SURVEY.md 8(c)).
  * {link index 0..5, centre in link frame, radius} */
-static const int SPH_LINK[4] = {4, 4, 5, 5};
-static const double SPH_POS[4][3] = {
-    {-0.0620, 0.0140, 0.0005}, {-0.0440, 0.0150, 0.0000}, {-0.0500, 0.0075, -0.0140}, {-0.0350, 0.0012, -0.0140}};
-static const double SPH_RAD[4] = {0.0057, 0.0057, 0.0057, 0.0060};
+#define NSPH 2
+static const int SPH_LINK[NSPH] = {4, 5};
+static const double SPH_POS[NSPH][3] = {{-0.0610, 0.0142, 0.0005}, {-0.0490, 0.0072, -0.0140}};
+static const double SPH_RAD[NSPH] = {0.0065, 0.0065};
 
 /* default solver parameters (MJ-DOC XML reference): solref=(0.02,1) solimp=(0.9,0.95,0.001,0.5,2) */
 static const double SOLREF[2] = {0.02, 1.0};
@@ -194,7 +195,7 @@ typedef struct {
     real com[6][3]; /* world inertial-frame origins (xipos) */
     real Iw[6][9];  /* world inertia about com */
     real site[3];
-    real sph[4][3];
+    real sph[NSPH][3];
     int ncube;
     real cR[2][9], cp[2][3];
 } kin_t;
@@ -235,7 +236,7 @@ static void arm_kinematics(const real *q, kin_t *K) {
     real sp[3] = {(real)SITE_POS[0], (real)SITE_POS[1], (real)SITE_POS[2]}, t[3];
     m3v(t, K->R[5], sp);
     v3add(K->site, K->p[5], t);
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < NSPH; s++) {
         real c[3] = {(real)SPH_POS[s][0], (real)SPH_POS[s][1], (real)SPH_POS[s][2]};
         m3v(t, K->R[SPH_LINK[s] + 1], c);
         v3add(K->sph[s], K->p[SPH_LINK[s] + 1], t);
@@ -616,12 +617,18 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     int ncon = 0;
     for (int c = 0; c < nc; c++) ncon += collide_plane_box(&K, c, con + ncon);
     if (nc == 2) ncon += collide_box_box(&K, con + ncon);
-    int narm = 0;
-    for (int c = 0; c < nc; c++)
-        for (int s = 0; s < 4; s++)
-            if (narm < ORC_MAX_ARM_CONTACTS && collide_box_sphere(&K, c, s, con + ncon)) { ncon++; narm++; }
-    for (int s = 0; s < 4; s++)
-        if (narm < ORC_MAX_ARM_CONTACTS && collide_plane_sphere(&K, s, con + ncon)) { ncon++; narm++; }
+    /* one contact per finger sphere against the cube it penetrates deepest (tie: cube 0), then the floor */
+    for (int s = 0; s < NSPH; s++) {
+        contact_t cand[2];
+        int have = 0;
+        for (int c = 0; c < nc; c++) {
+            contact_t tmp;
+            if (collide_box_sphere(&K, c, s, &tmp) && (!have || tmp.dist < cand[0].dist)) { cand[0] = tmp; have = 1; }
+        }
+        if (have) con[ncon++] = cand[0];
+    }
+    for (int s = 0; s < NSPH; s++)
+        if (collide_plane_sphere(&K, s, con + ncon)) ncon++;
 
     /* -- constraint rows: joint limits first, then contacts (4 rows each: n, t1, t2, torsion) */
     static const int ROWDIM = 4;
@@ -999,7 +1006,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
         orc_reward(P, a3, b3, &r32, &r64, &succ); term = succ; break;
     }
     io->elapsed[e] += 1;
-    uint8_t trunc = io->elapsed[e] >= P->max_episode_steps; /* gymnasium TimeLimit */
+    uint8_t trunc = P->max_episode_steps > 0 && io->elapsed[e] >= P->max_episode_steps; /* gymnasium TimeLimit; <=0 disables */
     io->reward[e] = r32; io->reward64[e] = r64; io->terminated[e] = term; io->truncated[e] = trunc; io->is_success[e] = succ;
     memcpy(io->term_obs + 18 * e, obs, sizeof(float) * 18);
     io->did_reset[e] = 0;
@@ -1040,7 +1047,7 @@ void orc_fk(const double *q6, double *link_pos, double *site, double *spheres) {
     arm_kinematics(q, &K);
     for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) link_pos[3 * i + k] = (double)K.p[i + 1][k];
     for (int k = 0; k < 3; k++) site[k] = (double)K.site[k];
-    if (spheres) for (int s = 0; s < 4; s++) for (int k = 0; k < 3; k++) spheres[3 * s + k] = (double)K.sph[s][k];
+    if (spheres) for (int s = 0; s < NSPH; s++) for (int k = 0; k < 3; k++) spheres[3 * s + k] = (double)K.sph[s][k];
 }
 void orc_mass_matrix(const double *q6, int with_armature, double *M) {
     real q[6], Mr[36]; kin_t K;

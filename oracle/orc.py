@@ -144,7 +144,7 @@ class Oracle:
 # ---- model queries ----
 def fk(q):
     q = np.ascontiguousarray(q, np.float64)
-    lp, site, sph = np.zeros((6, 3)), np.zeros(3), np.zeros((4, 3))
+    lp, site, sph = np.zeros((6, 3)), np.zeros(3), np.zeros((2, 3))
     lib().orc_fk(_p(q), _p(lp), _p(site), _p(sph))
     return lp, site, sph
 
