@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused HIP step kernel (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one launch of the fused step kernel over this GPU's batch of envs (apply_action -> 20 physics
+substeps -> reward/termination/TimeLimit -> auto-reset).  Workload = BASELINE.json configs[1]:
+ReachCube-v0, 65 536 envs per GPU, joint control, state-only observations, sparse reward.  Envs are
+independent: ranks own disjoint global env-id ranges, there is no data-path collective (weak scaling).
+Synthetic actions (Philox keyed on (seed, global env id, step)) are generated on the device BEFORE the
+timed region, so inputs are resident in HBM when timing starts.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (task, action_mode, algorithmic bytes per env-step)
+    "ReachCube-v0": ("reach", "joint", 294),
+    "PushCube-v0": ("push", "joint", 318),
+    "PickPlaceCube-v0": ("pick_place", "ee", 338),
+    "LiftCube-v0": ("lift", "joint", 294),
+    "StackTwoCubes-v0": ("stack", "joint", 414),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
+
+
+def cpu_baseline(task, action_mode, budget_s=12.0):
+    """Time the CPU oracle (a port: the reference's MuJoCo path cannot run here) on a bounded sample."""
+    import numpy as np
+    from oracle import orc
+
+    threads = orc.lib().orc_max_threads()
+    rng = np.random.default_rng(0)
+    n = 64 * threads
+    o = orc.Oracle(task, n, action_mode={"joint": 0, "ee": 1}[action_mode])
+    o.reset(seeds=np.arange(n, dtype=np.uint64))
+    a = rng.uniform(-1, 1, (n, o.action_dim)).astype(np.float32)
+    t0 = time.perf_counter()
+    o.step(a, threads=threads)
+    per_step = time.perf_counter() - t0
+    steps = max(2, min(200, int(budget_s / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        a = rng.uniform(-1, 1, (n, o.action_dim)).astype(np.float32)
+        o.step(a, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * steps / dt,
+        "unit": "env-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n} envs x {steps} control steps of {task} ({action_mode}), fp64 C oracle, OpenMP over envs, "
+                  f"{dt:.1f} s; reference MuJoCo unavailable in this image",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--workload", default="ReachCube-v0", choices=sorted(WORKLOADS))
+    ap.add_argument("--pgs-iters", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from gym_lowcostrobot_amd import VecSim, build
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rank == 0:
+        build.build()  # no-op when the in-tree .so is current
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    else:
+        torch.cuda.set_device(local_rank)
+
+    task, action_mode, alg_bytes = WORKLOADS[args.workload]
+    n = args.envs_per_gpu
+    sim = VecSim(task, n, device=local_rank, env_id_offset=rank * n, observation_mode="state", action_mode=action_mode,
+                 pgs_iters=args.pgs_iters, base_seed=0)
+    stream = torch.cuda.current_stream()
+    sim.set_stream(stream.cuda_stream)
+
+    # inputs resident in HBM before timing: a ring of pre-generated action buffers
+    ring = min(args.steps + args.warmup, 64)
+    bufs = [sim.alloc_actions() for _ in range(ring)]
+    for i, b in enumerate(bufs):
+        sim.fill_random_actions(b, seed=0, step=i)
+    sim.sync()
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        sim.step_device(bufs[i % ring].ptr)
+    sync_all()
+    t0 = time.perf_counter()
+    sim.timer_begin()  # HIP events on the stream the kernel is launched on
+    for i in range(args.steps):
+        sim.step_device(bufs[(args.warmup + i) % ring].ptr)
+    ev_ms = sim.timer_end()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: the timed work must have produced finite state and episodes must have cycled
+    st = sim.get_state()
+    import numpy as np
+
+    finite = bool(np.isfinite(st["qpos"]).all() and np.isfinite(st["qvel"]).all())
+
+    if rank == 0:
+        total_steps = n * world * args.steps
+        kern_ms = ev_ms / args.steps
+        achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                with open(prof) as f:
+                    traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec",
+            "value": total_steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}, {n} envs/GPU, {action_mode} control, state-only obs, sparse reward, "
+                            f"n_substeps=20, max_episode_steps=50, auto-reset on, pgs_iters={args.pgs_iters}",
+                "envs_per_gpu": n,
+                "global_envs": n * world,
+                "parallelism": f"env-sharded x{world}, no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "lcr_step_kernel",
+                "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_env_step": alg_bytes,
+                "note": "state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick",
+            },
+            "state_finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(task, action_mode)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    for b in bufs:
+        sim.free(b)
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,269 @@
+"""CPU tests: pin the oracle (oracle/lcr_oracle.c) to
+  (i)  the golden vectors produced by the reference's own numpy methods (tests/golden/glue_golden.json),
+  (ii) the known-answer table of SURVEY.md 8(c) (derived independently from the MJCF constants),
+  (iii) numpy's Generator(PCG64(SeedSequence(seed))) streams,
+and check internal consistency of the dynamics it restates (the MuJoCo substep itself is "parity unpinned").
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "glue_golden.json")))
+
+
+def _params(task, **kw):
+    p = orc.OrcParams()
+    orc.lib().orc_default_params(__import__("ctypes").byref(p), orc.TASKS[task])
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+# ---------------------------------------------------------------- (i) golden: rewards
+@pytest.mark.parametrize("rec", GOLD["rewards"], ids=lambda r: f"{r['task']}-{r['reward_type']}")
+def test_reward_golden(rec):
+    import ctypes
+
+    p = _params(rec["task"], reward_type=orc.lib() and {"sparse": 0, "dense": 1}[rec["reward_type"]])
+    a = np.array(rec["a"], np.float64)
+    b = np.array(rec["b"], np.float64)  # float32 targets were stored as their exact float64 value
+    r32, r64, s = ctypes.c_float(), ctypes.c_double(), ctypes.c_uint8()
+    orc.lib().orc_reward(ctypes.byref(p), orc._p(a), orc._p(b), ctypes.byref(r32), ctypes.byref(r64), ctypes.byref(s))
+    assert bool(s.value) == rec["is_success"]
+    if rec["reward_type"] == "sparse":
+        assert rec["reward_dtype"] == "float32"
+        assert r32.value == rec["reward"]
+        assert np.signbit(np.float32(r32.value)) == rec["reward_signbit"]  # -0.0 inside the threshold
+    else:
+        assert rec["reward_dtype"] == "float64"
+        # same fp64 expression; numpy's BLAS dot may fuse multiply-adds, so allow 2 ulp
+        assert abs(r64.value - rec["reward"]) <= 2 * np.spacing(abs(rec["reward"]))
+
+
+# ---------------------------------------------------------------- (i) golden: reset sampling streams
+@pytest.mark.parametrize("rec", GOLD["resets"], ids=lambda r: f"{r['task']}-seed{r['seed']}")
+def test_reset_golden(rec):
+    o = orc.Oracle(rec["task"], 1)
+    o.qpos[:] = 0.123
+    nq = o.nq
+    for i, step in enumerate(rec["sequence"]):
+        if i == 0:
+            o.reset(seeds=[rec["seed"]])
+        else:
+            o.reset()
+        np.testing.assert_array_equal(o.qpos[0, :nq], np.array(step["qpos"])[:nq])
+        if "target_pos" in step:
+            np.testing.assert_array_equal(o.target[0], np.array(step["target_pos"], np.float32))
+        ob = step["obs"]
+        np.testing.assert_array_equal(o.obs[0, 0:6], np.array(ob["arm_qpos"], np.float32))
+        key = "cube_red_pos" if rec["task"] == "stack" else "cube_pos"
+        np.testing.assert_array_equal(o.obs[0, 12:15], np.array(ob[key], np.float32))
+        if rec["task"] == "stack":
+            np.testing.assert_array_equal(o.obs[0, 15:18], np.array(ob["cube_blue_pos"], np.float32))
+        if "target_pos" in ob:
+            np.testing.assert_array_equal(o.obs[0, 15:18], np.array(ob["target_pos"], np.float32))
+        assert o.elapsed[0] == 0
+
+
+def test_reset_survey_known_draws():
+    # first draw of seeds 0 / 1 / 42
+    for seed, want in [(0, (0.04108851, 0.07839988, 0)), (1, (0.00354649, 0.23835897, 0)), (42, (0.08218681, 0.11813643, 0))]:
+        o = orc.Oracle("reach", 1)
+        o.reset(seeds=[seed])
+        np.testing.assert_allclose(o.qpos[0, 6:9], want, atol=5e-9)
+
+
+# ---------------------------------------------------------------- (i) golden: joint-mode control targets
+@pytest.mark.parametrize("rec", GOLD["joint_targets"], ids=lambda r: r["task"])
+def test_joint_ctrl_golden(rec):
+    import ctypes
+
+    p = _params(rec["task"])
+    q = np.array(rec["qpos"], np.float64)
+    a = np.array(rec["action"], np.float32)
+    c = np.zeros(6)
+    orc.lib().orc_joint_ctrl(ctypes.byref(p), orc._p(q), orc._p(a), orc._p(c))
+    np.testing.assert_array_equal(c, np.array(rec["ctrl"]))
+
+
+# ---------------------------------------------------------------- (iii) RNG
+@pytest.mark.parametrize("seed", [0, 1, 42, 12345, 2**31 - 1, 2**32, 2**40 + 7, 2**63 + 11])
+def test_rng_matches_numpy(seed):
+    r = orc.rng_seed(seed)
+    ref = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))).random(16)
+    mine = np.array([orc.rng_double(r) for _ in range(16)])
+    np.testing.assert_array_equal(mine, ref)
+
+
+# ---------------------------------------------------------------- (ii) known answers from SURVEY.md 8(c)
+def test_fk_known_answers():
+    lp, site, _ = orc.fk(np.zeros(6))
+    np.testing.assert_allclose(site, (0.002017, 0.212570, 0.168400), atol=1e-6)
+    want = [(0, -0.012, 0.0409), (-0.0209, -0.012, 0.0563), (-0.0144, 0.0028, 0.1646), (-0.01435, 0.10328, 0.1673),
+            (-0.001253, 0.14828, 0.1673), (-0.008753, 0.16143, 0.1818)]
+    np.testing.assert_allclose(lp, want, atol=1e-6)
+    np.testing.assert_allclose(orc.fk([0.3, -0.5, 0.8, 0.4, -0.2, -0.5])[1], (0.050143, 0.142755, -0.037193), atol=1e-6)
+    np.testing.assert_allclose(orc.fk([1, 1, 1, 1, 1, 0])[1], (0.061692, 0.028102, 0.223741), atol=1e-6)
+
+
+def test_site_jacobian_known_and_finite_difference():
+    J = orc.site_jac(np.zeros(6))
+    want = [[0.22457, 0, 0, 0, -0.0011, 0], [-0.002017, -0.1121, 0.0038, -0.0011, 0, 0], [0, 0.22457, -0.20977, 0.10929, 0.00327, 0]]
+    np.testing.assert_allclose(J, want, atol=6e-6)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q = rng.uniform(-1, 1, 6)
+        J = orc.site_jac(q)
+        for j in range(6):
+            d = np.zeros(6); d[j] = 1e-6
+            fd = (orc.fk(q + d)[1] - orc.fk(q - d)[1]) / 2e-6
+            np.testing.assert_allclose(J[:, j], fd, atol=1e-9)
+        assert np.all(J[:, 5] == 0)  # site is on link_5
+
+
+def test_mass_matrix_known_answers():
+    M = orc.mass_matrix(np.zeros(6), armature=False)
+    np.testing.assert_allclose(np.diag(M), (2.229e-3, 4.037e-3, 1.776e-3, 2.34e-4, 6e-6, 1.1e-5), rtol=0.08)
+    assert abs(M[1, 2] - (-2.010e-3)) < 2e-6
+    Ma = orc.mass_matrix(np.zeros(6), armature=True)
+    np.testing.assert_allclose(Ma - M, 0.1 * np.eye(6), atol=1e-15)
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        M = orc.mass_matrix(rng.uniform(-2, 2, 6))
+        np.testing.assert_allclose(M, M.T, atol=1e-15)
+        assert np.linalg.eigvalsh(M).min() > 0.09
+
+
+def test_gravity_torque_known_answer_and_potential():
+    b = orc.bias(np.zeros(6), np.zeros(6))
+    np.testing.assert_allclose(-b, (0, -0.147385, 0.129713, -0.034035, -0.000725, 0), atol=2e-6)
+
+
+def test_bias_is_consistent_with_mass_matrix():
+    """Coriolis/centrifugal part of the RNE bias equals Mdot qd - 0.5 d(qd^T M qd)/dq (finite differences of M)."""
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        q, qd = rng.uniform(-1.5, 1.5, 6), rng.uniform(-3, 3, 6)
+        c = orc.bias(q, qd) - orc.bias(q, np.zeros(6))
+        eps = 1e-6
+        dM = []
+        for j in range(6):
+            d = np.zeros(6); d[j] = eps
+            dM.append((orc.mass_matrix(q + d) - orc.mass_matrix(q - d)) / (2 * eps))
+        dM = np.array(dM)  # dM[j] = dM/dq_j
+        Mdot = np.tensordot(qd, dM, axes=(0, 0))
+        want = Mdot @ qd - 0.5 * np.array([qd @ dM[j] @ qd for j in range(6)])
+        np.testing.assert_allclose(c, want, atol=2e-8)
+
+
+def test_first_ik_step_known_answer():
+    # first DLS-IK qdot at q=0 for e=(0.05,0,0); one iteration moves q by 0.5*qdot
+    _, site, _ = orc.fk(np.zeros(6))
+    it, qc, qs, sl = orc.ik(np.zeros(6), site + np.array([0.05, 0, 0]))
+    assert it == 10
+    # reproduce the full loop in numpy from the oracle's own Jacobian (independent linear algebra: np.linalg.inv)
+    q = np.zeros(6)
+    tgt = site + np.array([0.05, 0, 0])
+    first = None
+    for k in range(10):
+        q_state = q.copy()
+        e = tgt - orc.fk(q)[1]
+        if np.linalg.norm(e) < 0.01:
+            break
+        J = orc.site_jac(q)
+        qdot = np.linalg.inv(J.T @ J + 0.15 * np.eye(6)) @ J.T @ e
+        if first is None:
+            first = qdot.copy()
+        n = np.linalg.norm(qdot)
+        if n > 1:
+            qdot /= n
+        q = np.clip(q + 0.5 * qdot, [-3.14] * 5 + [-2.45], [3.14] * 5 + [0.032])
+    np.testing.assert_allclose(first, (0.05602, -6.2e-5, -1.3e-5, 7e-6, -2.74e-4, 0), atol=2e-6)
+    np.testing.assert_allclose(qc, q, atol=1e-12)
+    np.testing.assert_allclose(qs, q_state, atol=1e-12)  # REF-QUIRK-3: sim state = q at the top of the last iteration
+
+
+def test_invweight0_three_way():
+    """oracle (C) == tools/gen_model_header.py (numpy) == constants compiled into the kernel header"""
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import gen_model_header as g
+
+    tran, rot, dof = g.invweight0()
+    t, r, d = orc.invweight0()
+    np.testing.assert_allclose(t, tran, rtol=1e-10)
+    np.testing.assert_allclose(r, rot, rtol=1e-10)
+    np.testing.assert_allclose(d, dof, rtol=1e-10)
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "gym_lowcostrobot_amd", "csrc", "lcr_model_gen.h")).read()
+    vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"constexpr float (\w+) = ([-0-9.e]+)f;", hdr)}
+    assert abs(vals["INVW_TRAN_L5"] - tran[4]) < 1e-6 and abs(vals["INVW_TRAN_L6"] - tran[5]) < 1e-6
+    for j in range(6):
+        assert abs(vals[f"INVW_DOF{j + 1}"] - dof[j]) < 1e-5
+    # sphere proxies and site in the header are the ones the oracle uses
+    _, site, sph = orc.fk(np.zeros(6))
+    np.testing.assert_allclose(site, (0.002017, 0.21257, 0.1684), atol=1e-6)
+    assert vals["SPH0r"] == pytest.approx(0.0065) and vals["SPH1r"] == pytest.approx(0.0065)
+
+
+# ---------------------------------------------------------------- dynamics sanity (self-consistency only)
+def test_cube_settles_on_floor_and_arm_holds():
+    o = orc.Oracle("reach", 1, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[0])
+    assert o.qpos[0, 8] == 0.0  # REF-QUIRK-2: spawned half-embedded
+    for _ in range(15):
+        o.step(np.zeros((1, 5), np.float32))
+    assert 0.0145 < o.qpos[0, 8] < 0.0151
+    assert np.abs(o.qvel[0, 6:12]).max() < 1e-3
+    assert np.abs(o.qpos[0, :6]).max() < 0.01
+    np.testing.assert_allclose(np.linalg.norm(o.qpos[0, 9:13]), 1.0, atol=1e-12)
+
+
+def test_push_moves_cube_and_limits_hold():
+    o = orc.Oracle("push", 1, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[3])
+    o.qpos[0, :6] = [0, -0.25, 0.6, 0.07, 0, 0]
+    o.qpos[0, 6:9] = [0.06, 0.17, 0.015]
+    x0 = o.qpos[0, 6]
+    for _ in range(30):
+        a = np.zeros((1, 5), np.float32); a[0, 0] = 0.15
+        o.step(a)
+    assert o.qpos[0, 6] > x0 + 0.05          # the finger pushed the cube along +x
+    assert abs(o.qpos[0, 8] - 0.0149) < 5e-4  # it stayed on the floor
+    assert o.qpos[0, 0] < 3.14 + 2e-3         # joint limit row held the pan joint
+
+
+def test_fp32_oracle_tracks_fp64_oracle():
+    """the same C source built with float arithmetic: bounds the rounding-only part of the GPU/oracle gap"""
+    n = 64
+    rng = np.random.default_rng(4)
+    a = orc.Oracle("push", n, auto_reset=0, max_episode_steps=0)
+    b = orc.Oracle("push", n, f32=True, auto_reset=0, max_episode_steps=0)
+    seeds = np.arange(n, dtype=np.uint64)
+    a.reset(seeds=seeds); b.reset(seeds=seeds)
+    for _ in range(3):
+        a.qpos[:] = a.qpos.astype(np.float32); a.qvel[:] = a.qvel.astype(np.float32)
+        b.qpos[:] = a.qpos; b.qvel[:] = a.qvel
+        act = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+        a.step(act); b.step(act)
+        dq = np.abs(a.qpos - b.qpos).max(axis=1)
+        assert (dq < 2e-5).mean() >= 0.98, np.sort(dq)[-4:]
+
+
+def test_auto_reset_timelimit_semantics():
+    o = orc.Oracle("reach", 3, max_episode_steps=4)
+    o.reset(seeds=[5, 6, 7])
+    first = o.qpos[:, 6:8].copy()
+    for t in range(4):
+        o.qpos[:, 6:9] = [0.3, 0.3, 0.5]  # keep the cube away so nobody succeeds
+        o.step(np.zeros((3, 5), np.float32))
+        assert o.truncated.tolist() == [int(t == 3)] * 3
+    assert o.did_reset.tolist() == [1, 1, 1] and o.elapsed.tolist() == [0, 0, 0]
+    assert not np.allclose(o.qpos[:, 6:8], first)      # a NEW cube position from the continued stream
+    np.testing.assert_array_equal(o.obs[:, 12:15], o.qpos[:, 6:9].astype(np.float32))
+    assert np.all(o.term_obs[:, 14] > 0.1)             # terminal observation is the pre-reset one
