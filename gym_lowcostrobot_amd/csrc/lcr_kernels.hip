@@ -336,7 +336,11 @@ struct ArmSlot {
 
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
 constexpr int LDS_SLOT = 4 * LDS_ROW;      // four rows
-constexpr int LDS_FLOATS = 4 * LDS_SLOT;   // four slots -> 24 KiB per wave
+constexpr int LDS_G_FLOATS = 4 * LDS_SLOT;  // four slots -> 24 KiB per wave
+// Stack only: cube<->cube contact records, 4 slots x 16 floats per lane: pos3 f4 aref4 inv4 Rn  (16 KiB per wave)
+constexpr int CC_REC = 16;
+constexpr int LDS_CC_FLOATS = 4 * CC_REC * 64;
+template <int NC> struct LdsSize { static constexpr int value = LDS_G_FLOATS + (NC == 2 ? LDS_CC_FLOATS : 0); };
 
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
@@ -496,6 +500,100 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
             T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
             T.inv[3] = rcp(iinv + Rt);
+        }
+    }
+
+
+    // ---- collision: cube <-> cube (Stack).  Face-axis SAT (6 axes), then vertices of each box below the other's
+    //      reference face and inside its footprint; first 4 found (box1's vertices first).  Records live in LDS. ----
+    bool cc_act[4] = {false, false, false, false};
+    bool cc_any = false;
+    f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
+    float *ccl = lds + LDS_G_FLOATS + lane;  // record field k of slot s at ccl[(s*CC_REC + k)*64]
+    if constexpr (NC == 2) {
+        const f3 dc = S.cp[1] - S.cp[0];
+        const f3 ax0[3] = {CR[0].X, CR[0].Y, CR[0].Z}, ax1[3] = {CR[1].X, CR[1].Y, CR[1].Z};
+        float best = -1e30f, bsgn = 1.f;
+        f3 bn = mk(0.f, 0.f, 1.f);
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const f3 n = a < 3 ? ax0[a] : ax1[a - 3];
+            float ext = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) ext += fabsf(dot(n, a < 3 ? ax1[j] : ax0[j])) * CH;
+            float dd = dot(n, dc);
+            float sep = fabsf(dd) - CH - ext;
+            if (sep > best) { best = sep; bn = n; bsgn = dd < 0.f ? -1.f : 1.f; }
+        }
+        const bool touching = best < 0.f;
+        ccn = bsgn * bn;  // points cube0 -> cube1
+        float refext[2];
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            float e = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) e += fabsf(dot(ccn, b == 0 ? ax0[j] : ax1[j])) * CH;
+            refext[b] = e;
+        }
+        f3 cpos[4];
+        float cdist[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; s++) cpos[s] = mk(0.f, 0.f, 0.f);
+        int cnt = 0;
+        const float tol = 1e-4f;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int inc = pass == 0 ? 1 : 0, ref = 1 - inc;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
+                f3 w = axpy(sx, CR[inc].X, axpy(sy, CR[inc].Y, axpy(sz, CR[inc].Z, S.cp[inc])));
+                f3 d = w - S.cp[ref];
+                f3 l = mk(dot(CR[ref].X, d), dot(CR[ref].Y, d), dot(CR[ref].Z, d));
+                bool inside = !(fabsf(l.x) > CH + tol || fabsf(l.y) > CH + tol || fabsf(l.z) > CH + tol);
+                float nd = dot(ccn, d);
+                float dist = ref == 0 ? nd - refext[0] : -nd - refext[1];
+                bool take = touching && inside && dist < 0.f && cnt < 4;
+                float sh = ref == 0 ? -0.5f * dist : 0.5f * dist;
+                f3 pc = axpy(sh, ccn, w);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    bool t = take && cnt == s;
+                    cpos[s].x = t ? pc.x : cpos[s].x; cpos[s].y = t ? pc.y : cpos[s].y; cpos[s].z = t ? pc.z : cpos[s].z;
+                    cdist[s] = t ? dist : cdist[s];
+                    cc_act[s] = cc_act[s] || t;
+                }
+                cnt += take ? 1 : 0;
+            }
+        }
+        cc_any = __any(cnt > 0) != 0;
+        if (cc_any) {
+            make_frame(ccn, cct1, cct2);
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const f3 r0 = cpos[s] - S.cp[0], r1 = cpos[s] - S.cp[1];
+                float imp = impedance(cdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
+                float Rn = fmaxf((1.f - imp) * rcp(imp) * (2.f * minv), 1e-15f);
+                float Rf = Rn * P.inv_impratio;
+                float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+                f3 vrel = (S.cv[1] + cross(cww[1], r1)) - (S.cv[0] + cross(cww[0], r0));
+                f3 wrel = cww[1] - cww[0];
+                ccl[(s * CC_REC + 0) * 64] = cpos[s].x; ccl[(s * CC_REC + 1) * 64] = cpos[s].y; ccl[(s * CC_REC + 2) * 64] = cpos[s].z;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
+                    float vel = r < 3 ? dot(d, vrel) : dot(d, wrel);
+                    float aref = -B_DEF * vel - (r == 0 ? K_DEF * imp * cdist[s] : 0.f);
+                    float diag;
+                    if (r < 3) { f3 a0 = cross(r0, d), a1 = cross(r1, d); diag = 2.f * minv + iinv * (dot(a0, a0) + dot(a1, a1)); }
+                    else diag = 2.f * iinv;
+                    float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                    ccl[(s * CC_REC + 3 + r) * 64] = 0.f;               // f
+                    ccl[(s * CC_REC + 7 + r) * 64] = aref;
+                    ccl[(s * CC_REC + 11 + r) * 64] = rcp(diag + Rr);
+                }
+                ccl[(s * CC_REC + 15) * 64] = Rn;
+            }
         }
     }
 
@@ -699,6 +797,57 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
             }
         }
+        // cube <-> cube (Stack)
+        if constexpr (NC == 2) {
+            if (cc_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const f3 pos = mk(ccl[(s * CC_REC + 0) * 64], ccl[(s * CC_REC + 1) * 64], ccl[(s * CC_REC + 2) * 64]);
+                    const f3 r0 = pos - S.cp[0], r1 = pos - S.cp[1];
+                    const float Rn = ccl[(s * CC_REC + 15) * 64];
+                    const float Rf = Rn * P.inv_impratio;
+                    const float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+                    float f[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) f[r] = ccl[(s * CC_REC + 3 + r) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
+                        const float aref = ccl[(s * CC_REC + 7 + r) * 64], inv = ccl[(s * CC_REC + 11 + r) * 64];
+                        const float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                        f3 a0 = mk(0.f, 0.f, 0.f), a1 = mk(0.f, 0.f, 0.f);
+                        float ja;
+                        if (r < 3) { a0 = cross(r0, d); a1 = cross(r1, d); ja = dot(d, ca[1] - ca[0]) + dot(a1, cal[1]) - dot(a0, cal[0]); }
+                        else ja = dot(d, cal[1] - cal[0]);
+                        float res = ja - aref + Rr * f[r];
+                        float nf = f[r] - res * inv;
+                        if (r == 0) nf = fmaxf(nf, 0.f);
+                        float dlt = cc_act[s] ? nf - f[r] : 0.f;
+                        f[r] += dlt;
+                        if (r < 3) {
+                            ca[1] = axpy(minv * dlt, d, ca[1]); ca[0] = axpy(-minv * dlt, d, ca[0]);
+                            cal[1] = axpy(iinv * dlt, a1, cal[1]); cal[0] = axpy(-iinv * dlt, a0, cal[0]);
+                        } else { cal[1] = axpy(iinv * dlt, d, cal[1]); cal[0] = axpy(-iinv * dlt, d, cal[0]); }
+                    }
+                    float fn = f[0];
+                    float s2 = (f[1] * f[1] + f[2] * f[2]) * (1.f / (MU_CUBE * MU_CUBE)) + f[3] * f[3] * (1.f / (MU_TORS * MU_TORS));
+                    float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+#pragma unroll
+                    for (int r = 1; r < 4; r++) {
+                        const f3 d = r == 1 ? cct1 : (r == 2 ? cct2 : ccn);
+                        float dlt = f[r] * sc - f[r];
+                        f[r] += dlt;
+                        if (r < 3) {
+                            f3 a0 = cross(r0, d), a1 = cross(r1, d);
+                            ca[1] = axpy(minv * dlt, d, ca[1]); ca[0] = axpy(-minv * dlt, d, ca[0]);
+                            cal[1] = axpy(iinv * dlt, a1, cal[1]); cal[0] = axpy(-iinv * dlt, a0, cal[0]);
+                        } else { cal[1] = axpy(iinv * dlt, d, cal[1]); cal[0] = axpy(-iinv * dlt, d, cal[0]); }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) ccl[(s * CC_REC + 3 + r) * 64] = f[r];
+                }
+            }
+        }
         // finger spheres
         if (wave_arm) {
 #pragma unroll
@@ -883,7 +1032,7 @@ DEV void write_obs18(const LcrDev &P, float *dst, int e, const EnvState<NC> &S, 
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[LDS_FLOATS];
+    __shared__ float lds[LdsSize<NC>::value];
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;

@@ -449,7 +449,8 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     return 1;
 }
 /* (D5) box0 (geom1) vs box1 (geom2): face axis of minimum overlap among the 6 face normals, then the
- * vertices of each box that lie below the other's reference face inside its footprint; <= 4 + 4 points */
+ * vertices of each box that lie below the other's reference face inside its footprint; the first 4 found
+ * (box1's vertices against box0 first, then box0's against box1) are kept */
 static int collide_box_box(const kin_t *K, contact_t *out) {
     const real h = (real)CUBE_HALF;
     real dc[3];
@@ -475,8 +476,7 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
     const real tol = (real)1e-4; /* footprint tolerance so that exactly aligned faces keep their corners */
     for (int pass = 0; pass < 2; pass++) {
         int inc = pass == 0 ? 1 : 0, ref = 1 - inc; /* vertices of `inc` against `ref` */
-        int m = 0;
-        for (int i = 0; i < 8 && m < 4; i++) {
+        for (int i = 0; i < 8 && cnt < 4; i++) {
             real v[3] = {(i & 1) ? h : -h, (i & 2) ? h : -h, (i & 4) ? h : -h}, w[3], d[3], l[3];
             m3v(w, K->cR[inc], v);
             v3add(w, w, K->cp[inc]);
@@ -492,7 +492,7 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
             }
             real dist = (ref == 0) ? (nd - refext) : (-nd - refext);
             if (!(dist < 0)) continue;
-            contact_t *ct = &out[cnt++]; m++;
+            contact_t *ct = &out[cnt++];
             ct->b1 = 6; ct->b2 = 7; ct->dist = dist;
             real sh = (ref == 0) ? -dist * (real)0.5 : dist * (real)0.5;
             v3set(ct->pos, w[0] + n[0] * sh, w[1] + n[1] * sh, w[2] + n[2] * sh);

@@ -1,0 +1,120 @@
+"""Host-side mirror of the reference env classes: what reference tests/test_env.py checks with
+gymnasium's check_env (spaces well-formed, reset obs in space & float32, same-seed determinism, step arity
+and types), restated without gymnasium (absent from this image) + the reference's exception behaviour."""
+import numpy as np
+import pytest
+
+import gym_lowcostrobot
+import gym_lowcostrobot.envs as ref_path
+from gym_lowcostrobot_amd import envs, spaces
+
+ENV_IDS = ["LiftCube-v0", "PickPlaceCube-v0", "PushCube-v0", "ReachCube-v0", "StackTwoCubes-v0"]
+
+
+def test_registry_table_matches_reference_ids():
+    assert sorted(envs.REGISTRY) == sorted(ENV_IDS)          # gym_lowcostrobot/__init__.py:9-43 minus PushCubeLoop
+    assert envs.MAX_EPISODE_STEPS == 50
+    for cls in envs.REGISTRY.values():
+        assert getattr(ref_path, cls) is getattr(envs, cls)   # `gym_lowcostrobot.envs:<Class>` entry points resolve
+    assert isinstance(gym_lowcostrobot.REGISTERED, list)
+
+
+def test_constructor_validation_precedes_device_use():
+    with pytest.raises(ValueError, match="Invalid action mode"):
+        envs.ReachCubeEnv(observation_mode="state", action_mode="cartesian")
+    with pytest.raises(AssertionError):
+        envs.PushCubeEnv(observation_mode="state", render_mode="ascii")
+    with pytest.raises(ValueError):
+        envs.LiftCubeEnv(observation_mode="depth")
+
+
+def test_fallback_spaces_behave_like_gymnasium_boxes():
+    b = spaces.Box(-1.0, 1.0, shape=(5,), dtype=np.float32)
+    assert b.shape == (5,) and b.dtype == np.float32
+    x = b.sample()
+    assert b.contains(x) and not b.contains(x.astype(np.float64)) and not b.contains(np.full(5, 2, np.float32))
+    d = spaces.Dict({"a": b})
+    assert d.contains({"a": x}) and not d.contains({"a": x, "b": x})
+
+
+# ----------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ENV_IDS)
+@pytest.mark.parametrize("observation_mode", ["state", "both"])
+def test_env_checker_contract(hip_lib, env_id, observation_mode):
+    cls = getattr(envs, envs.REGISTRY[env_id])
+    env = cls(observation_mode=observation_mode)
+    try:
+        obs, info = env.reset(seed=123)
+        assert info == {}
+        assert set(obs) == set(env.observation_space.keys())
+        for k, v in obs.items():
+            assert env.observation_space[k].contains(v), (k, v.dtype, v.shape)
+        obs2, _ = env.reset(seed=123)
+        for k in obs:
+            if not k.startswith("image"):
+                np.testing.assert_array_equal(obs[k], obs2[k])
+        obs3, _ = env.reset()  # continues the stream: a different cube position
+        ck = "cube_red_pos" if "cube_red_pos" in obs else "cube_pos"
+        assert not np.array_equal(obs3[ck], obs[ck])
+        rng = np.random.default_rng(0)
+        for _ in range(5):
+            a = rng.uniform(-1, 1, env.action_space.shape).astype(np.float32)
+            o, r, term, trunc, info = env.step(a)
+            assert set(o) == set(env.observation_space.keys())
+            for k, v in o.items():
+                assert env.observation_space[k].contains(v), (k, v)
+            assert trunc is False
+            if env_id == "LiftCube-v0":
+                assert isinstance(r, np.float64) and term is False and info == {}
+            else:
+                assert isinstance(r, np.float32) and isinstance(term, (bool, np.bool_)) and "is_success" in info
+                assert float(r) in (-1.0, 0.0)
+        with pytest.raises(ValueError, match="Action dimension mismatch"):
+            env.step(np.zeros(env.action_space.shape[0] + 1, np.float32))
+    finally:
+        env.close()
+
+
+@pytest.mark.gpu
+def test_action_dims_follow_reference_rule(hip_lib):
+    for cls, joint_k in [(envs.ReachCubeEnv, 5), (envs.PushCubeEnv, 5), (envs.LiftCubeEnv, 6), (envs.PickPlaceCubeEnv, 6), (envs.StackTwoCubesEnv, 6)]:
+        e = cls(observation_mode="state")
+        assert e.action_space.shape == (joint_k,)
+        e.close()
+        e = cls(observation_mode="state", action_mode="ee")
+        assert e.action_space.shape == (joint_k - 2,)
+        e.close()
+
+
+@pytest.mark.gpu
+def test_dense_reward_is_float64_negative_distance(hip_lib):
+    env = envs.ReachCubeEnv(observation_mode="state", reward_type="dense")
+    env.reset(seed=0)
+    _, r, _, _, _ = env.step(np.zeros(5, np.float32))
+    assert isinstance(r, np.float64) and r < 0
+    env.close()
+
+
+@pytest.mark.gpu
+def test_vecenv_autoreset_infos(hip_lib):
+    from gym_lowcostrobot_amd import LowCostRobotVecEnv
+
+    n = 64
+    v = LowCostRobotVecEnv("push", n, seed=0, max_episode_steps=6)
+    v.seed(100)
+    obs = v.reset()
+    assert obs["arm_qpos"].shape == (n, 6) and obs["target_pos"].dtype == np.float32
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        obs, rew, dones, infos = v.step(rng.uniform(-1, 1, (n, 5)).astype(np.float32))
+        assert rew.shape == (n,) and dones.dtype == bool and len(infos) == n
+        if t < 5:
+            assert not any("terminal_observation" in i for i in infos if i["TimeLimit.truncated"])
+    assert dones.mean() > 0.8  # envs that succeeded earlier restarted their episode clock
+    for i in np.nonzero(dones)[0]:
+        assert "terminal_observation" in infos[i] and "is_success" in infos[i]
+        assert infos[i]["TimeLimit.truncated"] == (not infos[i]["is_success"])
+        np.testing.assert_array_equal(obs["arm_qpos"][i], np.zeros(6, np.float32))  # reset observation returned
+        assert np.abs(infos[i]["terminal_observation"]["arm_qpos"]).max() > 0
+    v.close()

@@ -44,7 +44,7 @@ def _cmp_step(sim, o, rng, steps, atol_q=2e-5, atol_v=2e-3, frac=0.99, act_scale
     return worst_q, worst_v
 
 
-@pytest.mark.parametrize("task", ["reach", "push", "lift", "pick_place"])
+@pytest.mark.parametrize("task", ["reach", "push", "lift", "pick_place", "stack"])
 def test_reset_bit_exact(hip_lib, task):
     sim, o = util.make_pair(task, N)
     seeds = np.arange(N, dtype=np.uint64) * 7919 + 3
@@ -76,7 +76,7 @@ def test_step_free_flight_no_contact(hip_lib):
 
 
 @pytest.mark.parametrize("task,mode", [("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("pick_place", "joint"),
-                                       ("reach", "ee"), ("pick_place", "ee")])
+                                       ("reach", "ee"), ("pick_place", "ee"), ("stack", "joint"), ("stack", "ee")])
 def test_step_rollout_vs_oracle(hip_lib, task, mode):
     rng = np.random.default_rng(7)
     sim, o = util.make_pair(task, N, action_mode=mode, auto_reset=False, max_episode_steps=0)
@@ -141,3 +141,38 @@ def test_shard_invariance_and_determinism(hip_lib):
     assert np.isfinite(sw["qpos"]).all() and np.isfinite(sw["qvel"]).all()
     for s in (whole, lo, hi):
         s.close()
+
+
+def test_stack_cube_on_cube_contacts(hip_lib):
+    """blue cube dropped onto / resting on / offset on the red cube: cube<->cube rows active in every env"""
+    rng = np.random.default_rng(11)
+    n = 256
+    sim, o = util.make_pair("stack", n, auto_reset=False, max_episode_steps=0)
+    o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+    o.qpos[:, 6:9] = [0.25, 0.25, 0.0149]  # resting penetration (exactly-touching z=0.015 is a knife edge of dist<0)
+    o.qpos[:, 9:13] = [1, 0, 0, 0]
+    off = rng.uniform(-0.012, 0.012, (n, 2))
+    o.qpos[:, 13] = 0.25 + off[:, 0]
+    o.qpos[:, 14] = 0.25 + off[:, 1]
+    o.qpos[:, 15] = 0.0447 + rng.uniform(-0.0005, 0.002, n)
+    yaw = rng.uniform(-0.6, 0.6, n)
+    o.qpos[:, 16] = np.cos(yaw / 2); o.qpos[:, 17:19] = 0; o.qpos[:, 19] = np.sin(yaw / 2)
+    o.qvel[:] = 0
+    o.qvel[:, 12:15] = rng.normal(0, 0.05, (n, 3))
+    _cmp_step(sim, o, rng, 6, act_scale=0.2)
+    rows, cons, _ = o.diag()
+    assert cons >= 5  # 4 floor + at least one cube-cube contact on env 0
+    sim.close()
+
+
+def test_image_stub_written(hip_lib):
+    from gym_lowcostrobot_amd import VecSim
+    sim = VecSim("stack", 8, observation_mode="both")
+    a = np.zeros((8, 6), np.float32)
+    sim.step(a)
+    obs = sim.observations()
+    f, t = obs["image_front"], obs["image_top"]
+    assert f.shape == (8, 240, 320, 3) and f.dtype == np.uint8 and t.shape == f.shape
+    assert (f[..., 0] == 200).any() and (t[..., 2] == 200).any()   # red and blue cube splats
+    assert f.std() > 0 and t.std() > 0
+    sim.close()
