@@ -72,8 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="ReachCube-v0", choices=sorted(WORKLOADS))
-    ap.add_argument("--pgs-iters", type=int, default=10)
+    ap.add_argument("--pgs-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calibrate", type=int, default=0, help="after timing, launch the known-byte-count copy kernel this many times (PMC calibration)")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +133,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    calib_bytes = 0
+    for _ in range(args.calibrate):
+        calib_bytes = sim.calibrate_copy(2 * 1024 * 1024)
+    if args.calibrate:
+        sim.sync()
+
     # sanity: the timed work must have produced finite state and episodes must have cycled
     st = sim.get_state()
     import numpy as np
@@ -183,6 +190,7 @@ def main():
                 "note": "state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick",
             },
             "state_finite": finite,
+            "calibration_bytes_per_launch": calib_bytes or None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(task, action_mode)

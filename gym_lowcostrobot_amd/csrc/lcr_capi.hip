@@ -72,7 +72,7 @@ int lcr_config_default(lcr_config *cfg, int task) {
     cfg->impratio = 100.0;
     cfg->n_substeps = 20;
     cfg->max_episode_steps = 50;
-    cfg->pgs_iters = 10;
+    cfg->pgs_iters = 4;
     cfg->compat = 0;
     cfg->auto_reset = 1;
     cfg->base_seed = 0;
@@ -393,6 +393,15 @@ int lcr_fill_random_actions(lcr_sim *s, float *action_dev, uint64_t seed, uint64
     if (!action_dev) return fail(LCR_ERR_INVALID, "action is NULL");
     int rc = lcr_launch_fill_actions(action_dev, s->dev.n, s->k, s->dev.env_off, seed, step, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "fill kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return LCR_OK;
+}
+
+int lcr_calibrate_copy(lcr_sim *s, float *dst_dev, size_t n_floats) {
+    SIMCHK(s);
+    if (!dst_dev) return fail(LCR_ERR_INVALID, "dst is NULL");
+    if (n_floats * sizeof(float) > s->arena_bytes) return fail(LCR_ERR_INVALID, "n_floats exceeds the state arena (%zu bytes)", s->arena_bytes);
+    int rc = lcr_launch_calib_copy((const float *)s->arena, dst_dev, n_floats, s->stream);
+    if (rc) return fail(LCR_ERR_HIP, "calibration kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return LCR_OK;
 }
 

@@ -44,3 +44,4 @@ int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsig
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,
                             unsigned long long step, void *stream);
 int lcr_launch_image_stub(const LcrDev &P, void *stream);
+int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream);

@@ -334,6 +334,16 @@ struct ArmSlot {
     bool act;
 };
 
+// constraint forces carried from one substep to the next within a control step (zero at its start): warm start of
+// the PGS sweeps, as MuJoCo warm-starts its solver.  Cube<->cube forces (Stack) persist in their LDS records.
+template <int NC>
+struct Warm {
+    float floor[NC][4][4];
+    float arm[4][4];
+    float lim[6];
+    bool cc_prev[4];
+};
+
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
 constexpr int LDS_SLOT = 4 * LDS_ROW;      // four rows
 constexpr int LDS_G_FLOATS = 4 * LDS_SLOT;  // four slots -> 24 KiB per wave
@@ -346,7 +356,7 @@ template <int NC> struct LdsSize { static constexpr int value = LDS_G_FLOATS + (
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
 template <int NC>
-DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, f3 &lag_ee, f3 (&lag_cube)[NC]) {
+DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC> &W) {
     using namespace lcrm;
     // ---- position stage -------------------------------------------------------------------------
     CubeRot CR[NC];
@@ -500,6 +510,16 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
             T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
             T.inv[3] = rcp(iinv + Rt);
+            // warm start: forces of the previous substep if this slot was active then (inactive slots were zeroed)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { T.f[k] = T.act ? W.floor[c][s][k] : 0.f; }
+            const f3 r = T.r;
+            ca[c].z = fmaf(minv, T.f[0], ca[c].z);
+            ca[c].y = fmaf(minv, T.f[1], ca[c].y);
+            ca[c].x = fmaf(-minv, T.f[2], ca[c].x);
+            cal[c].x = fmaf(iinv, r.y * T.f[0] - r.z * T.f[1], cal[c].x);
+            cal[c].y = fmaf(iinv, -r.x * T.f[0] - r.z * T.f[2], cal[c].y);
+            cal[c].z = fmaf(iinv, r.x * T.f[1] + r.y * T.f[2] + T.f[3], cal[c].z);
         }
     }
 
@@ -588,7 +608,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (r < 3) { f3 a0 = cross(r0, d), a1 = cross(r1, d); diag = 2.f * minv + iinv * (dot(a0, a0) + dot(a1, a1)); }
                     else diag = 2.f * iinv;
                     float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
-                    ccl[(s * CC_REC + 3 + r) * 64] = 0.f;               // f
+                    {   // f: keep the previous substep's force if the slot was active then, and apply it
+                        float fw = (cc_act[s] && W.cc_prev[s]) ? ccl[(s * CC_REC + 3 + r) * 64] : 0.f;
+                        ccl[(s * CC_REC + 3 + r) * 64] = fw;
+                        if (r < 3) {
+                            f3 a0 = cross(r0, d), a1 = cross(r1, d);
+                            ca[1] = axpy(minv * fw, d, ca[1]); ca[0] = axpy(-minv * fw, d, ca[0]);
+                            cal[1] = axpy(iinv * fw, a1, cal[1]); cal[0] = axpy(-iinv * fw, a0, cal[0]);
+                        } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
+                    }
                     ccl[(s * CC_REC + 7 + r) * 64] = aref;
                     ccl[(s * CC_REC + 11 + r) * 64] = rcp(diag + Rr);
                 }
@@ -705,6 +733,17 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 T.inv[r] = rcp(gg + diagc + Rr);
+                // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
+                const float fw = T.act ? W.arm[s][r] : 0.f;
+                T.f[r] = fw;
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = fmaf(g[j], fw, y[j]);
+                if (vs_cube) {
+                    f3 dl = r < 3 ? (-minv * fw) * d : mk(0.f, 0.f, 0.f);
+                    f3 da = r < 3 ? (-iinv * fw) * cross(T.rc, d) : (-iinv * fw) * d;
+                    if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
+                    else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
+                }
             }
         }
     }
@@ -715,11 +754,22 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool any_lim = false;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        flim[j] = 0.f;
         lim_act[j] = (S.q[j] < JLO[j]) || (S.q[j] > JHI[j]);
+        flim[j] = lim_act[j] ? W.lim[j] : 0.f;
         any_lim = any_lim || lim_act[j];
     }
     const bool wave_lim = __any(any_lim) != 0;
+    if (wave_lim) {  // apply the warm-start limit forces
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            float g[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) g[k] = k == j ? (S.q[j] < JLO[j] ? 1.f : -1.f) : 0.f;
+            fsub(CL, g);
+#pragma unroll
+            for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], flim[j], y[k]);
+        }
+    }
     const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3];
 
     // ---- projected Gauss-Seidel on the dual, matrix-free, cold start, fixed sweeps -----------------
@@ -921,6 +971,22 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
     }
 
+    // ---- keep the forces for the next substep's warm start (inactive slots hold zero) ----------------
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) W.floor[c][s][k] = FS[c][s].f[k];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) W.arm[s][k] = AS[s].f[k];
+        W.cc_prev[s] = cc_act[s];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) W.lim[j] = flim[j];
+
     // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y -------------------
     float rhs[6];
 #pragma unroll
@@ -1117,7 +1183,22 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     f3 lag_cube[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) lag_cube[c] = S.cp[c];
-    for (int s = 0; s < P.n_substeps; s++) substep<NC>(P, S, ctrl, lds, lane, lag_ee, lag_cube);
+    Warm<NC> W;
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) W.floor[c][s][k] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) W.arm[s][k] = 0.f;
+        W.cc_prev[s] = false;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) W.lim[j] = 0.f;
+    for (int s = 0; s < P.n_substeps; s++) substep<NC>(P, S, ctrl, lds, lane, lag_ee, lag_cube, W);
 
     // ---- reward / success / termination (reach:313-348 and per-task deltas), lagged kinematics (P8) ----
     f3 a3, b3;
@@ -1276,6 +1357,13 @@ __global__ __launch_bounds__(256) void lcr_image_stub_kernel(LcrDev P, int ncube
     }
 }
 
+// measurement support: one dword per lane copy (the step kernel's access pattern) with a known byte count,
+// used to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section)
+__global__ __launch_bounds__(64) void lcr_calib_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i < n) dst[i] = src[i] + 1.0f;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1315,5 +1403,10 @@ int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, 
 int lcr_launch_image_stub(const LcrDev &P, void *stream) {
     if (!P.img_front || !P.img_top) return 0;
     hipLaunchKernelGGL(lcr_image_stub_kernel, dim3(P.n, 8), dim3(256), 0, (hipStream_t)stream, P, P.task == 4 ? 2 : 1);
+    return check_launch();
+}
+
+int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream) {
+    hipLaunchKernelGGL(lcr_calib_copy_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, src, dst, n);
     return check_launch();
 }

@@ -64,7 +64,7 @@ class VecSim:
         n_substeps=20,
         max_episode_steps=50,
         impratio=100.0,
-        pgs_iters=10,
+        pgs_iters=4,
         compat=0,
         auto_reset=True,
         base_seed=0,
@@ -179,6 +179,15 @@ class VecSim:
 
     def fill_random_actions(self, arr, seed, step):
         check(self.L.lcr_fill_random_actions(self.handle, ctypes.c_void_p(arr.ptr), int(seed), int(step)))
+
+    def calibrate_copy(self, n_floats):
+        """launch the known-byte-count copy kernel once (profiling calibration); returns bytes read == bytes written"""
+        if getattr(self, "_calib_dst", None) is None or self._calib_n < n_floats:
+            p = ctypes.c_void_p()
+            check(self.L.lcr_malloc(self.handle, 4 * n_floats, ctypes.byref(p)))
+            self._calib_dst, self._calib_n = p, n_floats
+        check(self.L.lcr_calibrate_copy(self.handle, self._calib_dst, n_floats))
+        return 4 * n_floats
 
     def timer_begin(self):
         check(self.L.lcr_timer_begin(self.handle))

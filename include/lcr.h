@@ -77,7 +77,7 @@ typedef struct lcr_config {
     double impratio;           /* 100, follower.xml:3 */
     int32_t n_substeps;        /* 20 */
     int32_t max_episode_steps; /* 50, gymnasium TimeLimit configured at __init__.py:12-42; <=0 disables */
-    int32_t pgs_iters;         /* contact solver sweeps per substep, 10 */
+    int32_t pgs_iters;         /* warm-started PGS sweeps per substep, 4 */
     uint32_t compat;
     int32_t auto_reset;        /* 1: SB3 VecEnv semantics fused in the step kernel */
     int32_t _pad;
@@ -167,6 +167,11 @@ int lcr_timer_end(lcr_sim *sim, float *ms_out);
 /* Fill action_dev [k][N] with U(-1,1) from a counter-based generator keyed (seed, global env id, step):
  * the synthetic policy of the benchmark; shard-invariant by construction. */
 int lcr_fill_random_actions(lcr_sim *sim, float *action_dev, uint64_t seed, uint64_t step);
+
+/* Measurement support: copy n_floats floats from the start of the state arena to dst_dev with one dword load and
+ * one dword store per lane (the step kernel's access pattern): a launch with a KNOWN byte count (4*n read, 4*n
+ * written) against which rocprofv3 FETCH_SIZE / WRITE_SIZE are calibrated (MI355X_MICROARCH.md, HBM section). */
+int lcr_calibrate_copy(lcr_sim *sim, float *dst_dev, size_t n_floats);
 
 #ifdef __cplusplus
 }

@@ -376,6 +376,7 @@ typedef struct {
     real pos[3], frame[9], dist;
     const double *mu; /* [3] tan, tan, torsional */
     const double *solimp;
+    int slot; /* warm-start slot id: 0-3 floor-cube0, 4-7 floor-cube1, 8-11 cube-cube, 12-13 sphere-cube, 14-15 sphere-floor */
 } contact_t;
 
 #define MAX_CONTACTS (8 + 8 + ORC_MAX_ARM_CONTACTS)
@@ -393,6 +394,7 @@ static int collide_plane_box(const kin_t *K, int c, contact_t *out) {
         real dist = w[2];
         if (!(dist < 0)) continue;
         contact_t *ct = &out[n++];
+        ct->slot = 4 * c + (n - 1);
         ct->b1 = -1; ct->b2 = 6 + c; ct->dist = dist;
         v3set(ct->pos, w[0], w[1], w[2] - dist * (real)0.5);
         real nz[3] = {0, 0, 1};
@@ -434,6 +436,7 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
     m3v(pw, K->cR[c], pl);
     v3add(ct->pos, pw, K->cp[c]);
     make_frame(ct->frame, nw);
+    ct->slot = 12 + s;
     ct->b1 = 6 + c; ct->b2 = SPH_LINK[s]; ct->dist = dist;
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER_CUBE;
     return 1;
@@ -444,6 +447,7 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     v3set(ct->pos, K->sph[s][0], K->sph[s][1], dist * (real)0.5);
     real nz[3] = {0, 0, 1};
     make_frame(ct->frame, nz);
+    ct->slot = 14 + s;
     ct->b1 = -1; ct->b2 = SPH_LINK[s]; ct->dist = dist;
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
     return 1;
@@ -493,6 +497,7 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
             real dist = (ref == 0) ? (nd - refext) : (-nd - refext);
             if (!(dist < 0)) continue;
             contact_t *ct = &out[cnt++];
+            ct->slot = 8 + (cnt - 1);
             ct->b1 = 6; ct->b2 = 7; ct->dist = dist;
             real sh = (ref == 0) ? -dist * (real)0.5 : dist * (real)0.5;
             v3set(ct->pos, w[0] + n[0] * sh, w[1] + n[1] * sh, w[2] + n[2] * sh);
@@ -556,9 +561,12 @@ static double g_diag_res;
 /* one physics substep == mujoco.mj_step (reach_cube_env.py:276-277) -- MJ-DOC restatement          */
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct { real ee[3]; real cube[2][3]; } lag_t;
+/* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
+ * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
+typedef struct { real lim[12]; real slot[16][4]; } warm_t;
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
-                    int diag) {
+                    warm_t *warm, int diag) {
     const int nc = T->ncube, nv = 6 + 6 * nc;
     const real h = (real)H_STEP;
     kin_t K;
@@ -634,6 +642,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     static const int ROWDIM = 4;
     real J[MAX_ROWS * ORC_NV_MAX], aref[MAX_ROWS], Rr[MAX_ROWS];
     int kind[MAX_ROWS]; /* 0 limit, 1 contact-normal (block start), 2 friction */
+    real *wptr[MAX_ROWS]; /* where this row's force is kept between substeps */
     const double *rowmu[MAX_ROWS];
     int nr = 0;
     memset(J, 0, sizeof J);
@@ -650,6 +659,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             double r = (1 - imp) / imp * g_inv_dof[j];
             Rr[nr] = (real)(r > MJ_MINVAL ? r : MJ_MINVAL);
             kind[nr] = 0; rowmu[nr] = 0;
+            wptr[nr] = &warm->lim[2 * j + side];
             nr++;
         }
     for (int ci = 0; ci < ncon; ci++) {
@@ -682,6 +692,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             Rr[nr + r] = (real)Rrow;
             kind[nr + r] = r == 0 ? 1 : 2;
             rowmu[nr + r] = ct->mu;
+            wptr[nr + r] = &warm->slot[ct->slot][r];
         }
         nr += ROWDIM;
     }
@@ -707,7 +718,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             real s = 0;
             for (int d = 0; d < nv; d++) s += J[(size_t)i * nv + d] * a0[d];
             bvec[i] = s - aref[i];
-            f[i] = 0;
+            f[i] = P->warm_start ? *wptr[i] : 0; /* cold start when warm_start == 0 */
         }
         double lastchange = 0;
         for (int it = 0; it < P->pgs_iters; it++) {
@@ -739,6 +750,9 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         free(MiJt); free(A);
         if (diag) { g_diag_res = lastchange; }
     }
+    /* slots that are not active in this substep restart from zero */
+    memset(warm, 0, sizeof *warm);
+    for (int i = 0; i < nr; i++) *wptr[i] = f[i];
     if (diag) { g_diag_rows = nr; g_diag_contacts = ncon; if (nr == 0) g_diag_res = 0; }
 
     /* -- implicitfast: (M - h*D) qacc = qfrc_smooth + qfrc_constraint, D = d(passive+actuator)/dqvel
@@ -786,9 +800,10 @@ void orc_default_params(orc_params *p, int task) {
     p->n_substeps = 20;                  /* reach:85 */
     p->max_episode_steps = 50;           /* gym_lowcostrobot/__init__.py:12-42 */
     p->impratio = 100.0;                 /* follower.xml:3 (after the scene's own <option>; later wins, MJ-DOC unverified) */
-    p->pgs_iters = 10;
+    p->pgs_iters = 4;
     p->compat = 0;
     p->auto_reset = 1;
+    p->warm_start = 1;
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
 int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }
@@ -977,8 +992,10 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     (void)k;
     /* ---- 20 x mj_step reach:276-279 */
     lag_t lag;
+    warm_t warm;
     memset(&lag, 0, sizeof lag);
-    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, e == 0 && s == P->n_substeps - 1);
+    memset(&warm, 0, sizeof warm);
+    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, &warm, e == 0 && s == P->n_substeps - 1);
     for (int i = 0; i < nq; i++) qpos64[i] = (double)qpos[i];
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];

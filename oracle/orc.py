@@ -31,7 +31,7 @@ class OrcParams(ctypes.Structure):
         ("pgs_iters", ctypes.c_int32),
         ("compat", ctypes.c_uint32),
         ("auto_reset", ctypes.c_int32),
-        ("_pad", ctypes.c_int32),
+        ("warm_start", ctypes.c_int32),
     ]
 
 
