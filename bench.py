@@ -79,7 +79,7 @@ def main():
 
     import torch
 
-    from gym_lowcostrobot_amd import VecSim, build
+    from gym_lowcostrobot_amd import VecSim, build, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,7 +101,7 @@ def main():
 
     task, action_mode, alg_bytes = WORKLOADS[args.workload]
     n = args.envs_per_gpu
-    sim = VecSim(task, n, device=local_rank, env_id_offset=rank * n, observation_mode="state", action_mode=action_mode,
+    sim = VecSim(task, n, device=local_rank, env_id_offset=sharding.shard_offset(n, rank), observation_mode="state", action_mode=action_mode,
                  pgs_iters=args.pgs_iters, base_seed=0)
     stream = torch.cuda.current_stream()
     sim.set_stream(stream.cuda_stream)
@@ -113,25 +113,19 @@ def main():
         sim.fill_random_actions(b, seed=0, step=i)
     sim.sync()
 
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         sim.step_device(bufs[i % ring].ptr)
-    sync_all()
-    t0 = time.perf_counter()
-    sim.timer_begin()  # HIP events on the stream the kernel is launched on
-    for i in range(args.steps):
+    ev = {}
+
+    def run(i):
+        if i == 0:
+            sim.timer_begin()  # HIP events on the stream the kernel is launched on
         sim.step_device(bufs[(args.warmup + i) % ring].ptr)
-    ev_ms = sim.timer_end()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        if i == args.steps - 1:
+            ev["ms"] = sim.timer_end()
+
+    dt, _ = sharding.timed_region(run, args.steps, dist=dist, device_sync=torch.cuda.synchronize, tensor_device="cuda")
+    ev_ms = ev["ms"]
 
     calib_bytes = 0
     for _ in range(args.calibrate):
@@ -146,7 +140,6 @@ def main():
     finite = bool(np.isfinite(st["qpos"]).all() and np.isfinite(st["qvel"]).all())
 
     if rank == 0:
-        total_steps = n * world * args.steps
         kern_ms = ev_ms / args.steps
         achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
         traffic = None
@@ -159,7 +152,7 @@ def main():
                 traffic = None
         out = {
             "metric": "env-steps/sec",
-            "value": total_steps / dt,
+            "value": sharding.aggregate_throughput(n, world, args.steps, dt),
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,

@@ -1,0 +1,49 @@
+"""Multi-GPU = independent env shards, one process per GPU, no data-path collective.
+
+GPU/rank g of G owns the contiguous global env ids [g*n, (g+1)*n) (weak scaling: n per GPU is fixed).  RNG
+streams and the synthetic policy are keyed on the GLOBAL env id, so any sharding yields the same trajectories.
+The only communication is the timing protocol of the benchmark: a barrier on both sides of the timed region
+and a MAX-reduction of the elapsed time (works on the "nccl"(=RCCL) backend with GPU tensors and on "gloo"
+with CPU tensors, which is how the CPU tests cover it).
+"""
+import time
+
+
+def shard_offset(envs_per_rank, rank):
+    """global id of this rank's env 0"""
+    return int(rank) * int(envs_per_rank)
+
+
+def shard_range(envs_per_rank, rank):
+    o = shard_offset(envs_per_rank, rank)
+    return o, o + int(envs_per_rank)
+
+
+def timed_region(run_steps, steps, *, dist=None, device_sync=None, tensor_device="cpu"):
+    """Time exactly `steps` calls of run_steps(i) bracketed by barrier + device sync on both sides.
+    Returns (max elapsed seconds over ranks, this rank's elapsed seconds)."""
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        if device_sync is not None:
+            device_sync()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run_steps(i)
+    sync_all()
+    local = time.perf_counter() - t0
+    worst = local
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([local], dtype=torch.float64, device=tensor_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        worst = float(t.item())
+    return worst, local
+
+
+def aggregate_throughput(envs_per_rank, world, steps, worst_seconds):
+    """whole-job env-steps/s: units all ranks processed / max-over-ranks time"""
+    return int(envs_per_rank) * int(world) * int(steps) / worst_seconds
