@@ -86,8 +86,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if rank == 0:
-        build.build()  # no-op when the in-tree .so is current
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -98,6 +96,12 @@ def main():
         dist.barrier()
     else:
         torch.cuda.set_device(local_rank)
+    # the in-tree .so normally travels with the snapshot; only a missing library is built here (by rank 0 alone)
+    if not os.path.exists(build.LIB):
+        if rank == 0:
+            build.build()
+    if dist is not None:
+        dist.barrier()
 
     task, action_mode, alg_bytes = WORKLOADS[args.workload]
     n = args.envs_per_gpu

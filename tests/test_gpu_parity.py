@@ -176,3 +176,69 @@ def test_image_stub_written(hip_lib):
     assert (f[..., 0] == 200).any() and (t[..., 2] == 200).any()   # red and blue cube splats
     assert f.std() > 0 and t.std() > 0
     sim.close()
+
+
+def test_ragged_batch_and_masked_reset(hip_lib):
+    """N not a multiple of the 64-lane wave: tail lanes must not corrupt anything; masked reset touches only its envs"""
+    rng = np.random.default_rng(21)
+    n = 64 * 3 + 17
+    sim, o = util.make_pair("pick_place", n, auto_reset=False, max_episode_steps=0)
+    seeds = np.arange(n, dtype=np.uint64) + 9
+    o.reset(seeds=seeds); sim.reset(seeds=seeds)
+    _cmp_step(sim, o, rng, 3)
+    mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    util.sync_oracle_to_f32(o); util.push_state(sim, o)
+    before = util.pull_state(sim)
+    o.reset(mask=mask); sim.reset(mask=mask)
+    st = util.pull_state(sim)
+    keep = mask == 0
+    for k in ("qpos", "qvel", "rng", "target", "elapsed"):
+        np.testing.assert_array_equal(st[k][keep], before[k][keep], err_msg=k)          # untouched envs: bit-identical
+    np.testing.assert_array_equal(st["qpos"][~keep, :13].astype(np.float32), o.qpos[~keep, :13].astype(np.float32))
+    np.testing.assert_array_equal(st["target"][~keep], o.target[~keep])
+    np.testing.assert_array_equal(st["rng"], o.rng)
+    assert (st["elapsed"][~keep] == 0).all()
+    sim.close()
+
+
+def test_joint_limit_rows(hip_lib):
+    """drive joints into their range limits (q beyond range -> unilateral limit rows active)"""
+    rng = np.random.default_rng(22)
+    n = 256
+    sim, o = util.make_pair("lift", n, auto_reset=False, max_episode_steps=0)
+    o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+    o.qpos[:, 6:9] = [0.5, 0.5, 0.0149]
+    o.qpos[:, 0] = np.where(rng.uniform(size=n) < 0.5, 3.14 + rng.uniform(0, 0.01, n), -3.14 - rng.uniform(0, 0.01, n))
+    o.qpos[:, 5] = 0.032 + rng.uniform(0, 0.01, n)     # gripper beyond its upper limit
+    o.qpos[:, 1] = -0.8; o.qpos[:, 2] = 0.3            # keep the fingers off the floor
+    o.qvel[:, :6] = rng.normal(0, 0.5, (n, 6))
+    _cmp_step(sim, o, rng, 3, act_scale=0.1)
+    rows, cons, _ = o.diag()
+    sim.close()
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE.json sizes: 65 536 envs -- finite state, episodes cycle through TimeLimit, success flags consistent"""
+    from gym_lowcostrobot_amd import VecSim
+    n = 65536
+    sim = VecSim("reach", n, observation_mode="state", base_seed=3)
+    act = sim.alloc_actions()
+    resets = np.zeros(n, np.int64)
+    for t in range(60):
+        sim.fill_random_actions(act, 1, t)
+        sim.step_device(act.ptr)
+        out = sim.outputs()
+        resets += out["did_reset"]
+        assert np.array_equal(out["did_reset"], out["terminated"] | out["truncated"])
+        assert np.array_equal(out["terminated"], out["is_success"])
+        r = out["reward"]
+        assert np.all((r == 0) | (r == -1)) and np.all(np.signbit(r))          # -0.0 / -1.0 exactly (REF-QUIRK-7)
+        assert np.array_equal(r == 0, out["is_success"])
+    st = sim.get_state()
+    assert np.isfinite(st["qpos"]).all() and np.isfinite(st["qvel"]).all()
+    assert resets.min() >= 1 and (st["elapsed"] < 50).all()                      # every env hit the 50-step TimeLimit once
+    assert np.abs(st["qpos"][:6]).max() <= 3.2                                   # joint limits hold under a random policy
+    qn = np.linalg.norm(st["qpos"][9:13], axis=0)
+    np.testing.assert_allclose(qn, 1.0, atol=1e-5)                               # cube quaternions stay normalised
+    assert (st["qpos"][8] > -0.02).all()                                         # no cube fell through the floor
+    sim.close()
