@@ -534,7 +534,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         const f3 dc = S.cp[1] - S.cp[0];
         const f3 ax0[3] = {CR[0].X, CR[0].Y, CR[0].Z}, ax1[3] = {CR[1].X, CR[1].Y, CR[1].Z};
         float best = -1e30f, bsgn = 1.f;
-        f3 bn = mk(0.f, 0.f, 1.f);
+        int bax = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++) {
             const f3 n = a < 3 ? ax0[a] : ax1[a - 3];
@@ -543,47 +543,100 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int j = 0; j < 3; j++) ext += fabsf(dot(n, a < 3 ? ax1[j] : ax0[j])) * CH;
             float dd = dot(n, dc);
             float sep = fabsf(dd) - CH - ext;
-            if (sep > best) { best = sep; bn = n; bsgn = dd < 0.f ? -1.f : 1.f; }
+            if (sep > best) { best = sep; bax = a; bsgn = dd < 0.f ? -1.f : 1.f; }
         }
         const bool touching = best < 0.f;
-        ccn = bsgn * bn;  // points cube0 -> cube1
-        float refext[2];
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            float e = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; j++) e += fabsf(dot(ccn, b == 0 ? ax0[j] : ax1[j])) * CH;
-            refext[b] = e;
-        }
+        int cnt = 0;
         f3 cpos[4];
         float cdist[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; s++) cpos[s] = mk(0.f, 0.f, 0.f);
-        int cnt = 0;
-        const float tol = 1e-4f;
+        if (__any(touching)) {  // wave-uniform: the manifold construction is skipped unless some env has overlapping cubes
+            // reference box A (owner of the best axis), incident box B; per-lane selection by compare/select
+            const bool Ais0 = bax < 3;
+            const int k = Ais0 ? bax : bax - 3;
+            auto sel3 = [](int i, f3 a, f3 b, f3 c) { return i == 0 ? a : (i == 1 ? b : c); };
+            const f3 AX = Ais0 ? CR[0].X : CR[1].X, AY = Ais0 ? CR[0].Y : CR[1].Y, AZ = Ais0 ? CR[0].Z : CR[1].Z;
+            const f3 BX = Ais0 ? CR[1].X : CR[0].X, BY = Ais0 ? CR[1].Y : CR[0].Y, BZ = Ais0 ? CR[1].Z : CR[0].Z;
+            const f3 cA = Ais0 ? S.cp[0] : S.cp[1], cB = Ais0 ? S.cp[1] : S.cp[0];
+            ccn = bsgn * sel3(k, AX, AY, AZ);                 // cube0 -> cube1
+            const f3 m = Ais0 ? ccn : neg(ccn);               // A -> B
+            const f3 u = sel3(k, AY, AZ, AX), v = sel3(k, AZ, AX, AY);   // columns (k+1)%3, (k+2)%3
+            const float md0 = dot(m, BX), md1 = dot(m, BY), md2 = dot(m, BZ);
+            int kb = 0; float bd = fabsf(md0);
+            if (fabsf(md1) > bd) { bd = fabsf(md1); kb = 1; }
+            if (fabsf(md2) > bd) { bd = fabsf(md2); kb = 2; }
+            const float mdk = kb == 0 ? md0 : (kb == 1 ? md1 : md2);
+            const float sB = mdk > 0.f ? -1.f : 1.f;
+            const f3 nb = sB * sel3(kb, BX, BY, BZ);
+            const f3 pa = sel3(kb, BY, BZ, BX), qa = sel3(kb, BZ, BX, BY);
+            const f3 fB = axpy(CH, nb, cB);
+            const float mnb = dot(m, nb);
+            const float tol = 1e-4f;
+            const float SP[4] = {1.f, -1.f, -1.f, 1.f}, SQ[4] = {1.f, 1.f, -1.f, -1.f};
+            f3 V[4];
+            float Vu[4], Vv[4], Vd[4];
 #pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-            const int inc = pass == 0 ? 1 : 0, ref = 1 - inc;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
-                f3 w = axpy(sx, CR[inc].X, axpy(sy, CR[inc].Y, axpy(sz, CR[inc].Z, S.cp[inc])));
-                f3 d = w - S.cp[ref];
-                f3 l = mk(dot(CR[ref].X, d), dot(CR[ref].Y, d), dot(CR[ref].Z, d));
-                bool inside = !(fabsf(l.x) > CH + tol || fabsf(l.y) > CH + tol || fabsf(l.z) > CH + tol);
-                float nd = dot(ccn, d);
-                float dist = ref == 0 ? nd - refext[0] : -nd - refext[1];
-                bool take = touching && inside && dist < 0.f && cnt < 4;
-                float sh = ref == 0 ? -0.5f * dist : 0.5f * dist;
-                f3 pc = axpy(sh, ccn, w);
+            for (int i = 0; i < 4; i++) {
+                V[i] = axpy(CH * SP[i], pa, axpy(CH * SQ[i], qa, fB));
+                f3 d = V[i] - cA;
+                Vu[i] = dot(d, u); Vv[i] = dot(d, v); Vd[i] = dot(d, m) - CH;
+            }
+            float skey[4] = {0.f, 0.f, 0.f, 0.f};
+            int sidx[4] = {-1, -1, -1, -1};
+            auto consider = [&](bool ok, int cand, f3 P, float dist, float cu, float cv) {
+                const float key[4] = {cu + cv, -cu + cv, -cu - cv, cu - cv};
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    bool t = take && cnt == s;
-                    cpos[s].x = t ? pc.x : cpos[s].x; cpos[s].y = t ? pc.y : cpos[s].y; cpos[s].z = t ? pc.z : cpos[s].z;
+                    bool t = ok && (sidx[s] < 0 || key[s] > skey[s]);
+                    skey[s] = t ? key[s] : skey[s];
+                    sidx[s] = t ? cand : sidx[s];
                     cdist[s] = t ? dist : cdist[s];
-                    cc_act[s] = cc_act[s] || t;
+                    cpos[s].x = t ? P.x : cpos[s].x; cpos[s].y = t ? P.y : cpos[s].y; cpos[s].z = t ? P.z : cpos[s].z;
                 }
-                cnt += take ? 1 : 0;
+            };
+            // (a) vertices of B's incident face inside A's footprint, below A's face
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bool ok = touching && !(fabsf(Vu[i]) > CH + tol || fabsf(Vv[i]) > CH + tol) && Vd[i] < 0.f;
+                consider(ok, i, axpy(-0.5f * Vd[i], m, V[i]), Vd[i], Vu[i], Vv[i]);
+            }
+            // (b) vertices of A's face inside B's incident face (near-parallel faces only)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f3 a = axpy(CH, m, axpy(CH * SP[j], u, axpy(CH * SQ[j], v, cA)));
+                f3 d = a - fB;
+                float t = -dot(d, nb) * rcp(mnb);
+                bool ok = touching && mnb < -0.5f && !(fabsf(dot(d, pa)) > CH + tol || fabsf(dot(d, qa)) > CH + tol) && t < 0.f;
+                consider(ok, 4 + j, axpy(0.5f * t, m, a), t, SP[j] * CH, SQ[j] * CH);
+            }
+            // (c) crossings of B's face edges with A's face boundary lines
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int e2 = (e + 1) & 3;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    const bool on_u = l < 2;
+                    const float sg = (l & 1) ? -1.f : 1.f;
+                    const float cP = on_u ? Vu[e] : Vv[e], cQ = on_u ? Vu[e2] : Vv[e2];
+                    const float oP = on_u ? Vv[e] : Vu[e], oQ = on_u ? Vv[e2] : Vu[e2];
+                    const float fP = cP - sg * CH, fQ = cQ - sg * CH;
+                    const bool cross_ = (fP < 0.f && fQ > 0.f) || (fP > 0.f && fQ < 0.f);
+                    const float t = fP * rcp(cross_ ? fP - fQ : 1.f);
+                    const float ot = fmaf(t, oQ - oP, oP);
+                    const float d = fmaf(t, Vd[e2] - Vd[e], Vd[e]);
+                    bool ok = touching && cross_ && !(fabsf(ot) > CH + tol) && d < 0.f;
+                    f3 X = axpy(t, V[e2] - V[e], V[e]);
+                    consider(ok, 8 + 4 * e + l, axpy(-0.5f * d, m, X), d, on_u ? sg * CH : ot, on_u ? ot : sg * CH);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                bool dup = false;
+#pragma unroll
+                for (int s2 = 0; s2 < s; s2++) dup = dup || (sidx[s2] == sidx[s]);
+                cc_act[s] = sidx[s] >= 0 && !dup;
+                cnt += cc_act[s] ? 1 : 0;
             }
         }
         cc_any = __any(cnt > 0) != 0;

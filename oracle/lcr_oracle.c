@@ -452,14 +452,22 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
     return 1;
 }
-/* (D5) box0 (geom1) vs box1 (geom2): face axis of minimum overlap among the 6 face normals, then the
- * vertices of each box that lie below the other's reference face inside its footprint; the first 4 found
- * (box1's vertices against box0 first, then box0's against box1) are kept */
+/* (D5) box0 (geom1) vs box1 (geom2).  Restated manifold (own construction, MuJoCo's mjc_BoxBox is not available):
+ *  1. separating-axis test over the 6 face normals; the axis of least overlap gives the contact normal n (0 -> 1),
+ *     the reference box A (owner of that axis) and the incident box B;
+ *  2. B's incident face = the face of B most anti-parallel to m (m = normal pointing A -> B);
+ *  3. candidate points of the overlap polygon of B's incident face with A's reference face:
+ *       (a) the 4 vertices of B's incident face that lie inside A's face footprint and below A's face,
+ *       (b) the 4 vertices of A's face that lie inside B's incident face (only for near-parallel faces),
+ *       (c) the <= 16 crossings of B's face edges with A's face boundary lines, below A's face;
+ *  4. at most 4 are kept: the extreme candidates along the 4 diagonals (+-u +-v) of A's face frame, first-wins on
+ *     ties, duplicates dropped.  Each contact: position midway between the two surfaces, dist < 0 along n. */
 static int collide_box_box(const kin_t *K, contact_t *out) {
     const real h = (real)CUBE_HALF;
+    const real tol = (real)1e-4;
     real dc[3];
     v3sub(dc, K->cp[1], K->cp[0]);
-    real best = (real)-1e30; int bax = -1; real bsgn = 1; /* axis id 0..2 on box0, 3..5 on box1 */
+    real best = (real)-1e30; int bax = -1; real bsgn = 1;
     for (int ax = 0; ax < 6; ax++) {
         int bx = ax / 3, k = ax % 3;
         real n[3] = {K->cR[bx][k], K->cR[bx][3 + k], K->cR[bx][6 + k]};
@@ -470,40 +478,103 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
             ext += (real)fabs((double)v3dot(n, col)) * h;
         }
         real dd = v3dot(n, dc);
-        real sep = (real)fabs((double)dd) - h - ext; /* >0 separated */
+        real sep = (real)fabs((double)dd) - h - ext;
         if (sep > best) { best = sep; bax = ax; bsgn = dd < 0 ? (real)-1 : (real)1; }
     }
     if (!(best < 0)) return 0;
-    int k = bax % 3, bx = bax / 3;
-    real n[3] = {K->cR[bx][k] * bsgn, K->cR[bx][3 + k] * bsgn, K->cR[bx][6 + k] * bsgn}; /* points box0 -> box1 */
-    int cnt = 0;
-    const real tol = (real)1e-4; /* footprint tolerance so that exactly aligned faces keep their corners */
-    for (int pass = 0; pass < 2; pass++) {
-        int inc = pass == 0 ? 1 : 0, ref = 1 - inc; /* vertices of `inc` against `ref` */
-        for (int i = 0; i < 8 && cnt < 4; i++) {
-            real v[3] = {(i & 1) ? h : -h, (i & 2) ? h : -h, (i & 4) ? h : -h}, w[3], d[3], l[3];
-            m3v(w, K->cR[inc], v);
-            v3add(w, w, K->cp[inc]);
-            v3sub(d, w, K->cp[ref]);
-            m3tv(l, K->cR[ref], d);
-            if ((real)fabs((double)l[0]) > h + tol || (real)fabs((double)l[1]) > h + tol || (real)fabs((double)l[2]) > h + tol) continue;
-            /* depth along n measured from ref's face */
-            real nd = v3dot(n, d);
-            real refext = 0;
-            for (int j = 0; j < 3; j++) {
-                real col[3] = {K->cR[ref][j], K->cR[ref][3 + j], K->cR[ref][6 + j]};
-                refext += (real)fabs((double)v3dot(n, col)) * h;
-            }
-            real dist = (ref == 0) ? (nd - refext) : (-nd - refext);
-            if (!(dist < 0)) continue;
-            contact_t *ct = &out[cnt++];
-            ct->slot = 8 + (cnt - 1);
-            ct->b1 = 6; ct->b2 = 7; ct->dist = dist;
-            real sh = (ref == 0) ? -dist * (real)0.5 : dist * (real)0.5;
-            v3set(ct->pos, w[0] + n[0] * sh, w[1] + n[1] * sh, w[2] + n[2] * sh);
-            make_frame(ct->frame, n);
-            ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT;
+    const int A = bax / 3, B = 1 - A, k = bax % 3;
+    real n[3] = {K->cR[A][k] * bsgn, K->cR[A][3 + k] * bsgn, K->cR[A][6 + k] * bsgn}; /* box0 -> box1 */
+    real m[3] = {A == 0 ? n[0] : -n[0], A == 0 ? n[1] : -n[1], A == 0 ? n[2] : -n[2]}; /* A -> B */
+    const int ku = (k + 1) % 3, kv = (k + 2) % 3;
+    real u[3] = {K->cR[A][ku], K->cR[A][3 + ku], K->cR[A][6 + ku]}, v[3] = {K->cR[A][kv], K->cR[A][3 + kv], K->cR[A][6 + kv]};
+    /* incident face of B */
+    int kb = 0; real bestdot = -1;
+    real mdot[3];
+    for (int j = 0; j < 3; j++) {
+        real col[3] = {K->cR[B][j], K->cR[B][3 + j], K->cR[B][6 + j]};
+        mdot[j] = v3dot(m, col);
+        if ((real)fabs((double)mdot[j]) > bestdot) { bestdot = (real)fabs((double)mdot[j]); kb = j; }
+    }
+    const real sB = mdot[kb] > 0 ? (real)-1 : (real)1;
+    real nb[3] = {sB * K->cR[B][kb], sB * K->cR[B][3 + kb], sB * K->cR[B][6 + kb]};
+    const int kp = (kb + 1) % 3, kq = (kb + 2) % 3;
+    real pa[3] = {K->cR[B][kp], K->cR[B][3 + kp], K->cR[B][6 + kp]}, qa[3] = {K->cR[B][kq], K->cR[B][3 + kq], K->cR[B][6 + kq]};
+    real fB[3] = {K->cp[B][0] + h * nb[0], K->cp[B][1] + h * nb[1], K->cp[B][2] + h * nb[2]};
+    const real mnb = v3dot(m, nb); /* ~ -1 for parallel faces */
+    static const real SP[4] = {1, -1, -1, 1}, SQ[4] = {1, 1, -1, -1};
+    real V[4][3], Vu[4], Vv[4], Vd[4];
+    for (int i = 0; i < 4; i++) {
+        for (int c = 0; c < 3; c++) V[i][c] = fB[c] + h * (SP[i] * pa[c] + SQ[i] * qa[c]);
+        real d[3];
+        v3sub(d, V[i], K->cp[A]);
+        Vu[i] = v3dot(d, u); Vv[i] = v3dot(d, v); Vd[i] = v3dot(d, m) - h;
+    }
+    /* selection state: 4 diagonal-extreme slots */
+    real spos[4][3], sdist[4], skey[4];
+    int sidx[4] = {-1, -1, -1, -1};
+    int cand = 0;
+#define CONSIDER(PX, PY, PZ, DIST, CU, CV)                                                        \
+    do {                                                                                          \
+        real key_[4] = {(CU) + (CV), -(CU) + (CV), -(CU) - (CV), (CU) - (CV)};                     \
+        for (int s_ = 0; s_ < 4; s_++)                                                            \
+            if (sidx[s_] < 0 || key_[s_] > skey[s_]) {                                            \
+                skey[s_] = key_[s_]; sidx[s_] = cand; sdist[s_] = (DIST);                          \
+                spos[s_][0] = (PX); spos[s_][1] = (PY); spos[s_][2] = (PZ);                        \
+            }                                                                                     \
+    } while (0)
+    /* (a) vertices of B's incident face */
+    for (int i = 0; i < 4; i++, cand++) {
+        if ((real)fabs((double)Vu[i]) > h + tol || (real)fabs((double)Vv[i]) > h + tol || !(Vd[i] < 0)) continue;
+        real hd = (real)0.5 * Vd[i];
+        CONSIDER(V[i][0] - m[0] * hd, V[i][1] - m[1] * hd, V[i][2] - m[2] * hd, Vd[i], Vu[i], Vv[i]);
+    }
+    /* (b) vertices of A's reference face, near-parallel faces only */
+    for (int j = 0; j < 4; j++, cand++) {
+        if (!(mnb < (real)-0.5)) continue;
+        real a[3], d[3];
+        for (int c = 0; c < 3; c++) a[c] = K->cp[A][c] + h * m[c] + h * (SP[j] * u[c] + SQ[j] * v[c]);
+        v3sub(d, a, fB);
+        if ((real)fabs((double)v3dot(d, pa)) > h + tol || (real)fabs((double)v3dot(d, qa)) > h + tol) continue;
+        real t = -v3dot(d, nb) / mnb;
+        if (!(t < 0)) continue;
+        real ht = (real)0.5 * t;
+        CONSIDER(a[0] + m[0] * ht, a[1] + m[1] * ht, a[2] + m[2] * ht, t, SP[j] * h, SQ[j] * h);
+    }
+    /* (c) crossings of B's face edges with A's face boundary lines */
+    for (int e = 0; e < 4; e++) {
+        const int e2 = (e + 1) & 3;
+        for (int l = 0; l < 4; l++, cand++) {
+            const int on_u = l < 2; /* lines u = +-h then v = +-h */
+            const real sg = (l & 1) ? (real)-1 : (real)1;
+            const real cP = on_u ? Vu[e] : Vv[e], cQ = on_u ? Vu[e2] : Vv[e2];
+            const real oP = on_u ? Vv[e] : Vu[e], oQ = on_u ? Vv[e2] : Vu[e2];
+            const real fP = cP - sg * h, fQ = cQ - sg * h;
+            if (!((fP < 0 && fQ > 0) || (fP > 0 && fQ < 0))) continue;
+            const real t = fP / (fP - fQ);
+            const real ot = oP + t * (oQ - oP);
+            if ((real)fabs((double)ot) > h + tol) continue;
+            const real d = Vd[e] + t * (Vd[e2] - Vd[e]);
+            if (!(d < 0)) continue;
+            real X[3];
+            for (int c = 0; c < 3; c++) X[c] = V[e][c] + t * (V[e2][c] - V[e][c]);
+            real hd = (real)0.5 * d;
+            CONSIDER(X[0] - m[0] * hd, X[1] - m[1] * hd, X[2] - m[2] * hd, d, on_u ? sg * h : ot, on_u ? ot : sg * h);
         }
+    }
+#undef CONSIDER
+    int cnt = 0;
+    for (int s = 0; s < 4; s++) {
+        if (sidx[s] < 0) continue;
+        int dup = 0;
+        for (int s2 = 0; s2 < s; s2++) if (sidx[s2] == sidx[s]) dup = 1;
+        if (dup) continue;
+        contact_t *ct = &out[cnt];
+        ct->slot = 8 + s;
+        ct->b1 = 6; ct->b2 = 7; ct->dist = sdist[s];
+        v3copy(ct->pos, spos[s]);
+        make_frame(ct->frame, n);
+        ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT;
+        cnt++;
     }
     return cnt;
 }

@@ -159,9 +159,13 @@ def test_stack_cube_on_cube_contacts(hip_lib):
     o.qpos[:, 16] = np.cos(yaw / 2); o.qpos[:, 17:19] = 0; o.qpos[:, 19] = np.sin(yaw / 2)
     o.qvel[:] = 0
     o.qvel[:, 12:15] = rng.normal(0, 0.05, (n, 3))
-    _cmp_step(sim, o, rng, 6, act_scale=0.2)
+    _cmp_step(sim, o, rng, 8, act_scale=0.2)
     rows, cons, _ = o.diag()
     assert cons >= 5  # 4 floor + at least one cube-cube contact on env 0
+    # physical sanity (oracle side == HIP side within tolerance): blue cubes still rest on their red cubes (a few that
+    # were dropped with a 12 mm offset plus lateral velocity may legitimately tip over)
+    on_top = (o.qpos[:, 15] > 0.043) & (o.qpos[:, 15] < 0.047)
+    assert on_top.mean() > 0.95, on_top.mean()
     sim.close()
 
 

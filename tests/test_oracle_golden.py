@@ -267,3 +267,24 @@ def test_auto_reset_timelimit_semantics():
     assert not np.allclose(o.qpos[:, 6:8], first)      # a NEW cube position from the continued stream
     np.testing.assert_array_equal(o.obs[:, 12:15], o.qpos[:, 6:9].astype(np.float32))
     assert np.all(o.term_obs[:, 14] > 0.1)             # terminal observation is the pre-reset one
+
+
+def test_stack_manifold_keeps_offset_rotated_stacks():
+    """cube<->cube manifold (D5): blue cubes placed on red cubes with offsets up to 12 mm and yaw up to 0.6 rad stay put"""
+    rng = np.random.default_rng(11)
+    n = 64
+    o = orc.Oracle("stack", n, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=np.arange(n))
+    o.qpos[:, 6:9] = [0.25, 0.25, 0.0149]; o.qpos[:, 9:13] = [1, 0, 0, 0]
+    off = rng.uniform(-0.012, 0.012, (n, 2))
+    o.qpos[:, 13] = 0.25 + off[:, 0]; o.qpos[:, 14] = 0.25 + off[:, 1]; o.qpos[:, 15] = 0.0447
+    yaw = rng.uniform(-0.6, 0.6, n)
+    o.qpos[:, 16] = np.cos(yaw / 2); o.qpos[:, 17:19] = 0; o.qpos[:, 19] = np.sin(yaw / 2)
+    o.qvel[:] = 0
+    for _ in range(25):
+        o.step(np.zeros((n, 6), np.float32), threads=0)
+    assert np.all(o.qpos[:, 15] > 0.044) and np.all(o.qpos[:, 15] < 0.0452)
+    assert np.abs(o.qpos[:, 13:15] - 0.25 - off).max() < 5e-3
+    assert np.abs(o.qpos[:, 17:19]).max() < 0.02
+    # success criterion of the task: blue within 0.05 of red + (0,0,0.03)  (stack_two_cubes_env.py:341-347)
+    assert o.is_success.all() and o.terminated.all()
