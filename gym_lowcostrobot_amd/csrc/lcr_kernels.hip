@@ -1362,51 +1362,67 @@ __global__ __launch_bounds__(256) void lcr_fill_actions_kernel(float *action, in
 // map; exists so that the HBM-write-bound shape of the image configs can be measured.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lcr_image_stub_kernel(LcrDev P, int ncube) {
+    // One work item = one 16-B vector; consecutive lanes write consecutive vectors, so every store instruction of a
+    // wave covers one contiguous 1 KiB span (full cache lines).  A frame is 14 400 vectors (60 per 320-pixel row); both
+    // frames of an env = 28 800.  Stores are non-temporal: write-once data that should not occupy L2.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int env = blockIdx.x;
     const int N = P.n;
     const size_t img_bytes = (size_t)240 * 320 * 3;
-    // cube centres -> pixel centres (front: x,z ; top: x,y), 800 px per metre
-    float cx[2], cy[2], cz[2];
+    // cube centres -> pixel boxes (front: x,z ; top: x,y), 800 px per metre, 24 px squares
+    int bx0[2], bx1[2], fz0[2], fz1[2], ty0[2], ty1[2];
+#pragma unroll
     for (int c = 0; c < 2; c++) {
-        int cc = c < ncube ? c : 0;
-        cx[c] = P.qpos[(size_t)(6 + 7 * cc) * N + env];
-        cy[c] = P.qpos[(size_t)(7 + 7 * cc) * N + env];
-        cz[c] = P.qpos[(size_t)(8 + 7 * cc) * N + env];
+        const int cc = c < ncube ? c : 0;
+        const float cx = P.qpos[(size_t)(6 + 7 * cc) * N + env];
+        const float cy = P.qpos[(size_t)(7 + 7 * cc) * N + env];
+        const float cz = P.qpos[(size_t)(8 + 7 * cc) * N + env];
+        const int px = (int)(160.f + 800.f * cx), pz = (int)(200.f - 800.f * cz), py = (int)(200.f - 800.f * cy);
+        bx0[c] = px - 12; bx1[c] = px + 12; fz0[c] = pz - 12; fz1[c] = pz + 12; ty0[c] = py - 12; ty1[c] = py + 12;
+        if (c >= ncube) { bx0[c] = 1 << 20; bx1[c] = -(1 << 20); }
     }
-    // each thread writes 16 bytes (uint4) at a time: 230400 B / 16 = 14400 vectors per image
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 *front = reinterpret_cast<u32x4 *>(P.img_front + (size_t)env * img_bytes);
     u32x4 *top = reinterpret_cast<u32x4 *>(P.img_top + (size_t)env * img_bytes);
-    for (int v = blockIdx.y * blockDim.x + threadIdx.x; v < 14400; v += gridDim.y * blockDim.x) {
-        unsigned char fb[16], tb[16];
+    for (int g = blockIdx.y * blockDim.x + threadIdx.x; g < 28800; g += gridDim.y * blockDim.x) {
+        const bool is_top = g >= 14400;
+        const int v = is_top ? g - 14400 : g;
+        const int row = v / 60, xb = (v - row * 60) * 16;  // first byte of this vector within its row
+        const int ph = v % 3;                               // (16 v) mod 3 = v mod 3: channel phase of byte 0
+        unsigned c[3];
+        if (is_top) { c[0] = 50; c[1] = 62; c[2] = 74; }
+        else if (row < 160) { c[0] = 60; c[1] = 90; c[2] = 120; }
+        else { c[0] = 40; c[1] = 50; c[2] = 60; }
+        // background: byte i has channel (ph + i) mod 3
+        const unsigned a0 = ph == 0 ? c[0] : (ph == 1 ? c[1] : c[2]);
+        const unsigned a1 = ph == 0 ? c[1] : (ph == 1 ? c[2] : c[0]);
+        const unsigned a2 = ph == 0 ? c[2] : (ph == 1 ? c[0] : c[1]);
+        const unsigned w0 = a0 | (a1 << 8) | (a2 << 16) | (a0 << 24);
+        const unsigned w1 = a1 | (a2 << 8) | (a0 << 16) | (a1 << 24);
+        const unsigned w2 = a2 | (a0 << 8) | (a1 << 16) | (a2 << 24);
+        u32x4 out = {w0, w1, w2, w0};
+        const int px_lo = xb / 3, px_hi = (xb + 15) / 3;
+        bool hit = false;
 #pragma unroll
-        for (int b = 0; b < 16; b++) {
-            int byte = v * 16 + b, pix = byte / 3, ch = byte - pix * 3;
-            int py = pix / 320, px = pix - py * 320;
-            unsigned char bgf = py < 160 ? (unsigned char)(60 + ch * 30) : (unsigned char)(40 + ch * 10);
-            unsigned char bgt = (unsigned char)(50 + ch * 12);
-            unsigned char vf = bgf, vt = bgt;
-            for (int c = 0; c < 2; c++) {
-                if (c >= ncube) break;
-                float fx = 160.f + 800.f * cx[c], fz = 200.f - 800.f * cz[c];
-                float tx = 160.f + 800.f * cx[c], ty = 200.f - 800.f * cy[c];
-                unsigned char col = (c == 0) ? (ch == 0 ? 200 : 20) : (ch == 2 ? 200 : 20);
-                if (fabsf(px - fx) < 12.f && fabsf(py - fz) < 12.f) vf = col;
-                if (fabsf(px - tx) < 12.f && fabsf(py - ty) < 12.f) vt = col;
-            }
-            fb[b] = vf; tb[b] = vt;
+        for (int k = 0; k < 2; k++) {
+            const int r0 = is_top ? ty0[k] : fz0[k], r1 = is_top ? ty1[k] : fz1[k];
+            hit = hit || (row > r0 && row < r1 && px_hi > bx0[k] && px_lo < bx1[k]);
         }
-        u32x4 f4, t4;
-        f4.x = fb[0] | (fb[1] << 8) | (fb[2] << 16) | ((unsigned)fb[3] << 24);
-        f4.y = fb[4] | (fb[5] << 8) | (fb[6] << 16) | ((unsigned)fb[7] << 24);
-        f4.z = fb[8] | (fb[9] << 8) | (fb[10] << 16) | ((unsigned)fb[11] << 24);
-        f4.w = fb[12] | (fb[13] << 8) | (fb[14] << 16) | ((unsigned)fb[15] << 24);
-        t4.x = tb[0] | (tb[1] << 8) | (tb[2] << 16) | ((unsigned)tb[3] << 24);
-        t4.y = tb[4] | (tb[5] << 8) | (tb[6] << 16) | ((unsigned)tb[7] << 24);
-        t4.z = tb[8] | (tb[9] << 8) | (tb[10] << 16) | ((unsigned)tb[11] << 24);
-        t4.w = tb[12] | (tb[13] << 8) | (tb[14] << 16) | ((unsigned)tb[15] << 24);
-        __builtin_nontemporal_store(f4, front + v);
-        __builtin_nontemporal_store(t4, top + v);
+        if (hit) {  // rare: this vector overlaps a cube square, build it byte by byte
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int byte = xb + i, px = byte / 3, ch = byte - px * 3;
+                unsigned val = c[ch];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int r0 = is_top ? ty0[k] : fz0[k], r1 = is_top ? ty1[k] : fz1[k];
+                    if (row > r0 && row < r1 && px > bx0[k] && px < bx1[k]) val = (k == 0) ? (ch == 0 ? 200u : 20u) : (ch == 2 ? 200u : 20u);
+                }
+                w[i >> 2] |= val << (8 * (i & 3));
+            }
+            out = u32x4{w[0], w[1], w[2], w[3]};
+        }
+        __builtin_nontemporal_store(out, (is_top ? top : front) + v);
     }
 }
 
