@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblcr_hip.so")
+LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
 ABI_VERSION = 1
 TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4}

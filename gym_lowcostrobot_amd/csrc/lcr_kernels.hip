@@ -221,7 +221,7 @@ DEV double pcg_double(Pcg &g) {
     unsigned long long hi = (unsigned long long)(g.st >> 64), lo = (unsigned long long)g.st, x = hi ^ lo;
     unsigned rot = (unsigned)(hi >> 58);
     unsigned long long o = (x >> rot) | (x << ((64 - rot) & 63));
-    return (double)(o >> 11) * (1.0 / 9007199254740992.0);
+    return __dmul_rn((double)(o >> 11), 1.0 / 9007199254740992.0);
 }
 DEV uint32_t ss_hashmix(uint32_t v, uint32_t &hc) { v ^= hc; hc *= 0x931e8875u; v *= hc; v ^= v >> 16; return v; }
 DEV uint32_t ss_mix(uint32_t x, uint32_t y) { uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; r ^= r >> 16; return r; }
@@ -1093,16 +1093,17 @@ template <int NC>
 DEV void reset_env(const LcrDev &P, EnvState<NC> &S, Pcg &g, f3 &target, f3 &ee_lag) {
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        double x = P.cube_lo[0] + P.cube_rng[0] * pcg_double(g);
-        double yv = P.cube_lo[1] + P.cube_rng[1] * pcg_double(g);
-        double zv = P.cube_lo[2] + P.cube_rng[2] * pcg_double(g);
+        // low + range*u with separately rounded product and sum (numpy's random_uniform); never contracted into an fma
+        double x = __dadd_rn(P.cube_lo[0], __dmul_rn(P.cube_rng[0], pcg_double(g)));
+        double yv = __dadd_rn(P.cube_lo[1], __dmul_rn(P.cube_rng[1], pcg_double(g)));
+        double zv = __dadd_rn(P.cube_lo[2], __dmul_rn(P.cube_rng[2], pcg_double(g)));
         S.cp[c] = mk((float)x, (float)yv, (float)zv);
         S.cq[c][0] = 1.f; S.cq[c][1] = 0.f; S.cq[c][2] = 0.f; S.cq[c][3] = 0.f;
     }
     if (P.has_target) {
-        double x = P.tgt_lo[0] + P.tgt_rng[0] * pcg_double(g);
-        double yv = P.tgt_lo[1] + P.tgt_rng[1] * pcg_double(g);
-        double zv = P.tgt_lo[2] + P.tgt_rng[2] * pcg_double(g);
+        double x = __dadd_rn(P.tgt_lo[0], __dmul_rn(P.tgt_rng[0], pcg_double(g)));
+        double yv = __dadd_rn(P.tgt_lo[1], __dmul_rn(P.tgt_rng[1], pcg_double(g)));
+        double zv = __dadd_rn(P.tgt_lo[2], __dmul_rn(P.tgt_rng[2], pcg_double(g)));
         target = mk((float)x, (float)yv, (float)zv);
     }
 #pragma unroll

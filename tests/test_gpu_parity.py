@@ -246,3 +246,25 @@ def test_full_size_properties(hip_lib):
     np.testing.assert_allclose(qn, 1.0, atol=1e-5)                               # cube quaternions stay normalised
     assert (st["qpos"][8] > -0.02).all()                                         # no cube fell through the floor
     sim.close()
+
+
+@pytest.mark.parametrize("task", ["lift", "pick_place"])
+def test_pinch_grasp_finger_cube_contacts(hip_lib, task):
+    """both finger<->cube slots active in every env (gripper-cube contact of BASELINE config 4)"""
+    rng = np.random.default_rng(31)
+    n = 256
+    sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0)
+    o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+    util.pinch_setup(o)
+    o.qpos[:, 6:9] += rng.normal(0, 3e-4, (n, 3))
+    o.qpos[:, 5] += rng.uniform(-0.02, 0.02, n)
+    o.qvel[:, :6] = rng.normal(0, 0.1, (n, 6))
+    for t in range(6):
+        util.sync_oracle_to_f32(o); util.push_state(sim, o)
+        a = rng.uniform(-0.1, 0.1, (n, sim.action_dim)).astype(np.float32); a[:, 5] = 0.2
+        o.step(a, threads=0); sim.step(a)
+        st = util.pull_state(sim)
+        dq = np.abs(st["qpos"] - o.qpos[:, : sim.nq]).max(axis=1)
+        dv = np.abs(st["qvel"] - o.qvel[:, : sim.nv]).max(axis=1)
+        assert ((dq <= 2e-5) & (dv <= 4e-3)).mean() >= 0.97, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
+    sim.close()

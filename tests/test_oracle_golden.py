@@ -288,3 +288,27 @@ def test_stack_manifold_keeps_offset_rotated_stacks():
     assert np.abs(o.qpos[:, 17:19]).max() < 0.02
     # success criterion of the task: blue within 0.05 of red + (0,0,0.03)  (stack_two_cubes_env.py:341-347)
     assert o.is_success.all() and o.terminated.all()
+
+
+def test_pinch_grasp_holds_the_cube():
+    """finger<->cube contacts (two sphere proxies, mu=1.5, torsional friction): a 0.1 kg cube pinched in mid-air stays
+    between the fingers against gravity (Lift); the 10 kg PickPlace cube (REF-QUIRK-4) drags the arm down instead"""
+    from tests import util
+    o = orc.Oracle("lift", 1, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[0])
+    util.pinch_setup(o)
+    for _ in range(25):
+        a = np.zeros((1, 6), np.float32); a[0, 5] = 0.2  # keep squeezing
+        o.step(a)
+    _, _, sph = orc.fk(o.qpos[0, :6])
+    assert np.abs(o.qpos[0, 6:9] - 0.5 * (sph[0] + sph[1])).max() < 1e-3   # still centred between the fingers
+    assert o.qpos[0, 8] > 0.15 and abs(o.qvel[0, 8]) < 1e-2                # and still up in the air
+    rows, cons, _ = o.diag()
+    assert cons == 2 and rows == 8
+    h = orc.Oracle("pick_place", 1, auto_reset=0, max_episode_steps=0)
+    h.reset(seeds=[0])
+    util.pinch_setup(h)
+    for _ in range(25):
+        a = np.zeros((1, 6), np.float32); a[0, 5] = 0.2
+        h.step(a)
+    assert h.qpos[0, 8] < 0.05                                              # 98 N of weight vs 10 N m actuators

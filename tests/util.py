@@ -58,3 +58,28 @@ def random_arm_state(rng, n, scale_q=1.0, scale_v=2.0):
     q = lo + (hi - lo) * rng.uniform(0.5 - 0.5 * scale_q, 0.5 + 0.5 * scale_q, (n, 6))
     qd = rng.normal(0, scale_v, (n, 6))
     return q, qd
+
+
+def pinch_setup(o, gap=0.0285):
+    """place every env's cube between the two finger spheres with the gripper closed to `gap` (surface to surface):
+    both finger<->cube contact slots are active.  Returns the gripper angle used."""
+    def g(q6):
+        q = np.zeros(6); q[5] = q6
+        _, _, sph = orc.fk(q)
+        return np.linalg.norm(sph[0] - sph[1]) - 0.013, sph
+    lo, hi = -1.5, 0.0
+    for _ in range(50):
+        mid = 0.5 * (lo + hi)
+        if g(mid)[0] > gap:
+            lo = mid
+        else:
+            hi = mid
+    _, sph = g(mid)
+    d = sph[0] - sph[1]
+    yaw = np.arctan2(d[1], d[0])
+    o.qpos[:, :6] = 0
+    o.qpos[:, 5] = mid
+    o.qpos[:, 6:9] = 0.5 * (sph[0] + sph[1])
+    o.qpos[:, 9:13] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+    o.qvel[:] = 0
+    return mid
