@@ -64,6 +64,8 @@ DEV f3 axpy(float s, f3 a, f3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y
 DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// NaN / inf / |x| >= 2^34 (~1.7e10, MuJoCo's mjMAXVAL is 1e10) by exponent bits: immune to -ffast-math
+DEV bool bad_value(float x) { return ((__float_as_uint(x) >> 23) & 0xffu) >= 127u + 34u; }
 
 // MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi())
 DEV float impedance(float dist, float d0, float dw, float inv_width) {
@@ -1276,9 +1278,23 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
             reward = P.reward_type == 0 ? __uint_as_float(0x80000000u | (d > P.dist_thr ? 0x3f800000u : 0u)) : -d;
         }
     }
+    // failure containment (MuJoCo's mj_checkPos/mj_checkVel reset an unstable simulation; the analogue here): a state
+    // with NaN/inf/huge entries ends the episode as truncated and the env is re-initialised with zero velocity
+    bool diverged = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++) diverged = diverged || bad_value(S.q[j]) || bad_value(S.qd[j]);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        diverged = diverged || bad_value(S.cp[c].x) || bad_value(S.cp[c].y) || bad_value(S.cp[c].z);
+        diverged = diverged || bad_value(S.cv[c].x) || bad_value(S.cv[c].y) || bad_value(S.cv[c].z);
+        diverged = diverged || bad_value(S.cw[c].x) || bad_value(S.cw[c].y) || bad_value(S.cw[c].z);
+#pragma unroll
+        for (int k = 0; k < 4; k++) diverged = diverged || bad_value(S.cq[c][k]);
+    }
+    if (diverged) { reward = -1.0f; success = false; terminated = false; }
     elapsed += 1;
-    const bool truncated = P.max_steps > 0 && elapsed >= P.max_steps;  // gymnasium TimeLimit
-    const bool do_reset = P.auto_reset && (terminated || truncated);
+    const bool truncated = diverged || (P.max_steps > 0 && elapsed >= P.max_steps);  // gymnasium TimeLimit
+    const bool do_reset = diverged || (P.auto_reset && (terminated || truncated));
     if (valid) {
         P.reward[e] = reward;
         P.terminated[e] = terminated;
@@ -1290,6 +1306,12 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         if (valid) write_obs18<NC>(P, P.term_obs, e, S, target);
         Pcg g = load_rng(P, e);
         reset_env<NC>(P, S, g, target, lag_ee);
+        if (diverged) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) S.qd[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) { S.cv[c] = mk(0.f, 0.f, 0.f); S.cw[c] = mk(0.f, 0.f, 0.f); }
+        }
         if (valid) {
             store_rng(P, e, g);
             if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }

@@ -1093,13 +1093,19 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
         b3[2] += 0.03;
         orc_reward(P, a3, b3, &r32, &r64, &succ); term = succ; break;
     }
+    /* failure containment (MJ-DOC: mj_checkPos / mj_checkVel reset an unstable simulation): NaN / inf / |x| >= 2^34 */
+    int diverged = 0;
+    for (int i = 0; i < nq; i++) if (!(fabs(qpos64[i]) < 17179869184.0)) diverged = 1;
+    for (int i = 0; i < nv; i++) if (!(fabs(qvel64[i]) < 17179869184.0)) diverged = 1;
+    if (diverged) { r32 = -1.0f; r64 = -1.0; succ = 0; term = 0; }
     io->elapsed[e] += 1;
-    uint8_t trunc = P->max_episode_steps > 0 && io->elapsed[e] >= P->max_episode_steps; /* gymnasium TimeLimit; <=0 disables */
+    uint8_t trunc = diverged || (P->max_episode_steps > 0 && io->elapsed[e] >= P->max_episode_steps); /* gymnasium TimeLimit; <=0 disables */
     io->reward[e] = r32; io->reward64[e] = r64; io->terminated[e] = term; io->truncated[e] = trunc; io->is_success[e] = succ;
     memcpy(io->term_obs + 18 * e, obs, sizeof(float) * 18);
     io->did_reset[e] = 0;
-    if (P->auto_reset && (term || trunc)) { /* SB3 DummyVecEnv.step_wait semantics (examples/gym_manipulation_sb3.py:34-39) */
+    if (diverged || (P->auto_reset && (term || trunc))) { /* SB3 DummyVecEnv.step_wait semantics (examples/gym_manipulation_sb3.py:34-39) */
         reset_one(P, T, qpos64, qvel64, ee_lag, target, io->elapsed + e, io->rng + 4 * e);
+        if (diverged) for (int d = 0; d < ORC_NV_MAX; d++) qvel64[d] = 0;
         write_obs(P, T, qpos64, qvel64, target, obs);
         io->did_reset[e] = 1;
     }

@@ -268,3 +268,24 @@ def test_pinch_grasp_finger_cube_contacts(hip_lib, task):
         dv = np.abs(st["qvel"] - o.qvel[:, : sim.nv]).max(axis=1)
         assert ((dq <= 2e-5) & (dv <= 4e-3)).mean() >= 0.97, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
     sim.close()
+
+
+def test_divergence_guard(hip_lib):
+    """a poisoned state (NaN / inf / huge) ends the episode as truncated and the env restarts clean, others untouched"""
+    n = 128
+    sim, o = util.make_pair("reach", n, auto_reset=False, max_episode_steps=0)
+    o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+    bad = np.zeros(n, bool); bad[[3, 64, 127]] = True
+    o.qvel[3, 2] = np.nan; o.qvel[64, 7] = np.inf; o.qpos[127, 1] = 1e30
+    util.push_state(sim, o)
+    a = np.zeros((n, 5), np.float32)
+    o.step(a, threads=0); sim.step(a)
+    out, st = sim.outputs(), util.pull_state(sim)
+    np.testing.assert_array_equal(out["truncated"], bad)
+    np.testing.assert_array_equal(out["did_reset"], bad)
+    np.testing.assert_array_equal(out["truncated"], o.truncated.astype(bool))
+    assert np.isfinite(st["qpos"]).all() and np.isfinite(st["qvel"]).all()
+    assert np.all(st["qvel"][bad] == 0) and np.all(st["qpos"][bad, :6] == 0)
+    assert np.all(out["reward"][bad] == -1.0) and not out["terminated"][bad].any()
+    np.testing.assert_array_equal(st["qpos"][bad, 6:9].astype(np.float32), o.qpos[bad, 6:9].astype(np.float32))
+    sim.close()
