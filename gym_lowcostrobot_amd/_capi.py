@@ -4,7 +4,9 @@ There is deliberately NO fallback: if the HIP library is missing or no MI355X is
 library / creating a simulator raises -- the product path never routes through a CPU implementation.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
@@ -102,6 +104,14 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m gym_lowcostrobot_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two runtimes in one process do not coexist when the system
+    # one (ours) initialises first (torch then reports "No HIP GPUs are available"), so if torch is installed it is
+    # imported BEFORE liblcr_hip.so is loaded; set LCR_NO_TORCH_PRELOAD=1 to skip (processes that never use torch).
+    if "torch" not in sys.modules and os.environ.get("LCR_NO_TORCH_PRELOAD") != "1" and importlib.util.find_spec("torch"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64
     L.lcr_abi_version.restype = ctypes.c_int

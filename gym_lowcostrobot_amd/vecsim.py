@@ -28,7 +28,7 @@ class DeviceArray:
         self.__cuda_array_interface__ = {
             "shape": self.shape,
             "typestr": self.dtype.str,
-            "data": (self.ptr, bool(readonly)),
+            "data": (self.ptr, False),  # torch rejects read-only exports; observation views are read-only by convention
             "version": 3,
             "strides": None,
         }

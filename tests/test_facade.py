@@ -118,3 +118,25 @@ def test_vecenv_autoreset_infos(hip_lib):
         np.testing.assert_array_equal(obs["arm_qpos"][i], np.zeros(6, np.float32))  # reset observation returned
         assert np.abs(infos[i]["terminal_observation"]["arm_qpos"]).max() > 0
     v.close()
+
+
+@pytest.mark.gpu
+def test_zero_copy_torch_views_and_device_actions(hip_lib):
+    """rank-1 'next' row of SURVEY.md 8(f): observations as torch-ROCm tensors without a copy, actions from a device tensor"""
+    torch = pytest.importorskip("torch")
+    from gym_lowcostrobot_amd import VecSim
+
+    n = 1024
+    sim = VecSim("push", n, observation_mode="state")
+    sim.set_stream(torch.cuda.current_stream().cuda_stream)
+    q = sim.arm_qpos.torch()
+    assert q.data_ptr() == sim.arm_qpos.ptr and q.shape == (6, n) and q.dtype == torch.float32 and q.is_cuda
+    act = torch.rand((sim.action_dim, n), device="cuda") * 2 - 1
+    before = q.clone()
+    sim.step_device(act.data_ptr())
+    torch.cuda.synchronize()
+    assert not torch.equal(q, before)                       # the view sees the kernel's writes, no copy involved
+    np.testing.assert_array_equal(q.cpu().numpy(), sim.arm_qpos.numpy())
+    r = sim.reward.torch()
+    assert r.shape == (n,) and torch.all((r == 0) | (r == -1))
+    sim.close()
