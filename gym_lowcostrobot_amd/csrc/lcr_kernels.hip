@@ -862,43 +862,35 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const f3 r = T.r;
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
-                // normal row: J = [z ; r x z]
-                float res = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - T.aref[0] + T.Rn * T.f[0];
-                float nf = fmaxf(T.f[0] - res * T.inv[0], 0.f);
-                float d = T.act ? nf - T.f[0] : 0.f;
-                T.f[0] += d;
-                ca[c].z = fmaf(minv, d, ca[c].z);
-                cal[c].x = fmaf(iinv * r.y, d, cal[c].x);
-                cal[c].y = fmaf(-iinv * r.x, d, cal[c].y);
-                // t1 = +y : J = [y ; r x y] = [y ; (-r.z, 0, r.x)]
-                res = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * T.f[1];
-                d = T.act ? -res * T.inv[1] : 0.f;
-                T.f[1] += d;
-                ca[c].y = fmaf(minv, d, ca[c].y);
-                cal[c].x = fmaf(-iinv * r.z, d, cal[c].x);
-                cal[c].z = fmaf(iinv * r.x, d, cal[c].z);
-                // t2 = -x : J = [-x ; r x (-x)] = [-x ; (0, -r.z, r.y)]
-                res = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * T.f[2];
-                d = T.act ? -res * T.inv[2] : 0.f;
-                T.f[2] += d;
-                ca[c].x = fmaf(-minv, d, ca[c].x);
-                cal[c].y = fmaf(-iinv * r.z, d, cal[c].y);
-                cal[c].z = fmaf(iinv * r.y, d, cal[c].z);
-                // torsion about n = z
-                res = cal[c].z - T.aref[3] + Rt * T.f[3];
-                d = T.act ? -res * T.inv[3] : 0.f;
-                T.f[3] += d;
-                cal[c].z = fmaf(iinv, d, cal[c].z);
+                // Block form of the four Gauss-Seidel row updates of this contact (same arithmetic as row-by-row GS):
+                // rows J_r = [d_r ; c_r], d = (z, y, -x, 0), c = (r x d) resp. z for the torsion row.  The row residuals
+                // against the CURRENT acceleration (u_r) are independent of each other; the coupling inside the contact is
+                // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
+                const float u0 = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - T.aref[0] + T.Rn * T.f[0];
+                const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * T.f[1];
+                const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * T.f[2];
+                const float u3 = cal[c].z - T.aref[3] + Rt * T.f[3];
+                const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
+                const float Bd1 = minv + iinv * (r.z * r.z + r.x * r.x) + Rf, Bd2 = minv + iinv * (r.z * r.z + r.y * r.y) + Rf, Bd3 = iinv + Rt;
+                float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
+                const float d0 = T.act ? nf - T.f[0] : 0.f;
+                const float d1a = T.act ? -(u1 + B01 * d0) * T.inv[1] : 0.f;
+                const float d2a = T.act ? -(u2 + B02 * d0 + B12 * d1a) * T.inv[2] : 0.f;
+                const float d3a = T.act ? -(u3 + B13 * d1a + B23 * d2a) * T.inv[3] : 0.f;
+                (void)Bd1; (void)Bd2; (void)Bd3;
                 // elliptic cone: radial projection of the friction part
-                float fn = T.f[0];
-                float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * (1.f / (MU_CUBE * MU_CUBE)) + T.f[3] * T.f[3] * (1.f / (MU_TORS * MU_TORS));
-                float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
-                float d1 = T.f[1] * sc - T.f[1], d2 = T.f[2] * sc - T.f[2], d3 = T.f[3] * sc - T.f[3];
-                T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                const float fn = T.f[0] + d0;
+                const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                const float s2 = (g1 * g1 + g2 * g2) * (1.f / (MU_CUBE * MU_CUBE)) + g3 * g3 * (1.f / (MU_TORS * MU_TORS));
+                const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
+                T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                // a += M^-1 J^T delta
+                ca[c].z = fmaf(minv, d0, ca[c].z);
                 ca[c].y = fmaf(minv, d1, ca[c].y);
                 ca[c].x = fmaf(-minv, d2, ca[c].x);
-                cal[c].x = fmaf(-iinv * r.z, d1, cal[c].x);
-                cal[c].y = fmaf(-iinv * r.z, d2, cal[c].y);
+                cal[c].x = fmaf(iinv, r.y * d0 - r.z * d1, cal[c].x);
+                cal[c].y = fmaf(iinv, -r.x * d0 - r.z * d2, cal[c].y);
                 cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
             }
         }
