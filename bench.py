@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--pgs-iters", type=int, default=4)
     ap.add_argument("--obs", default="state", choices=["state", "both"], help="both: also write the 2x240x320x3 image stub per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for a single rank (tests the N>1 code path on one GPU)")
     ap.add_argument("--calibrate", type=int, default=0, help="after timing, launch the known-byte-count copy kernel this many times (PMC calibration)")
     args = ap.parse_args()
 
@@ -88,7 +89,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -67,6 +67,22 @@ DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); 
 // NaN / inf / |x| >= 2^34 (~1.7e10, MuJoCo's mjMAXVAL is 1e10) by exponent bits: immune to -ffast-math
 DEV bool bad_value(float x) { return ((__float_as_uint(x) >> 23) & 0xffu) >= 127u + 34u; }
 
+// sin/cos for |x| <~ 4 (joint angles are range-limited, follower.xml:58-95): quadrant reduction with a two-term pi/2 and
+// the classic single-precision minimax polynomials on [-pi/4, pi/4]; max abs error 8.5e-8 on [-3.3, 3.3], ~30
+// instructions instead of libm sincosf's ~150 (which carries a large-argument path this kernel can never take).
+DEV void sincos_small(float x, float *sp_out, float *cp_out) {
+    const float k = rintf(x * 0.636619772f);
+    float r = fmaf(k, -1.57079637f, x);
+    r = fmaf(k, 4.37113883e-8f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515296e-4f, r2, 8.3321609e-3f), r2, -1.6666655e-1f), r2 * r, r);
+    const float cp = fmaf(fmaf(fmaf(2.4433157e-5f, r2, -1.3887316e-3f), r2, 4.1666646e-2f), r2 * r2, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    *sp_out = (q & 2) ? -ss : ss;
+    *cp_out = ((q + 1) & 2) ? -cc : cc;
+}
+
 // MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi())
 DEV float impedance(float dist, float d0, float dw, float inv_width) {
     float x = fminf(fabsf(dist) * inv_width, 1.0f);
@@ -98,37 +114,37 @@ DEV void arm_frames(const float (&q)[6], ArmFrames &F) {
     const f3 X0 = mk(0.f, -1.f, 0.f), Y0 = mk(1.f, 0.f, 0.f), Z0 = mk(0.f, 0.f, 1.f);
     // link_1: pos (P1x,0,P1z), axis -z
     F.p[0] = axpy(P1x, X0, P1z * Z0);
-    sincosf(q[0], &s, &c);
+    sincos_small(q[0], &s, &c);
     F.X[0] = axpy(c, X0, (-s) * Y0);
     F.Y[0] = axpy(s, X0, c * Y0);
     F.Z[0] = Z0;
     // link_2: pos (0,P2y,P2z), axis +y
     F.p[1] = axpy(P2y, F.Y[0], axpy(P2z, F.Z[0], F.p[0]));
-    sincosf(q[1], &s, &c);
+    sincos_small(q[1], &s, &c);
     F.X[1] = axpy(c, F.X[0], (-s) * F.Z[0]);
     F.Z[1] = axpy(s, F.X[0], c * F.Z[0]);
     F.Y[1] = F.Y[0];
     // link_3: axis -y
     F.p[2] = axpy(P3x, F.X[1], axpy(P3y, F.Y[1], axpy(P3z, F.Z[1], F.p[1])));
-    sincosf(q[2], &s, &c);
+    sincos_small(q[2], &s, &c);
     F.X[2] = axpy(c, F.X[1], s * F.Z[1]);
     F.Z[2] = axpy(-s, F.X[1], c * F.Z[1]);
     F.Y[2] = F.Y[1];
     // link_4: axis +y
     F.p[3] = axpy(P4x, F.X[2], axpy(P4y, F.Y[2], axpy(P4z, F.Z[2], F.p[2])));
-    sincosf(q[3], &s, &c);
+    sincos_small(q[3], &s, &c);
     F.X[3] = axpy(c, F.X[2], (-s) * F.Z[2]);
     F.Z[3] = axpy(s, F.X[2], c * F.Z[2]);
     F.Y[3] = F.Y[2];
     // link_5: pos (P5x,P5y,0), axis +x
     F.p[4] = axpy(P5x, F.X[3], axpy(P5y, F.Y[3], F.p[3]));
-    sincosf(q[4], &s, &c);
+    sincos_small(q[4], &s, &c);
     F.Y[4] = axpy(c, F.Y[3], s * F.Z[3]);
     F.Z[4] = axpy(-s, F.Y[3], c * F.Z[3]);
     F.X[4] = F.X[3];
     // link_6: axis -z
     F.p[5] = axpy(P6x, F.X[4], axpy(P6y, F.Y[4], axpy(P6z, F.Z[4], F.p[4])));
-    sincosf(q[5], &s, &c);
+    sincos_small(q[5], &s, &c);
     F.X[5] = axpy(c, F.X[4], (-s) * F.Y[4]);
     F.Y[5] = axpy(s, F.X[4], c * F.Y[4]);
     F.Z[5] = F.Z[4];
@@ -1066,7 +1082,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         if (wn2 > 0.f) {
             float iw = rsq(wn2), wn = wn2 * iw;
             float sh, chf;
-            sincosf(0.5f * H * wn, &sh, &chf);
+            sincos_small(0.5f * H * wn, &sh, &chf);
             float s = sh * iw;
             float dq0 = chf, dq1 = w.x * s, dq2 = w.y * s, dq3 = w.z * s;
             float q0 = S.cq[c][0], q1 = S.cq[c][1], q2 = S.cq[c][2], q3 = S.cq[c][3];
