@@ -3,8 +3,9 @@ from gym_lowcostrobot_amd.envs import (  # noqa: F401
     LiftCubeEnv,
     PickPlaceCubeEnv,
     PushCubeEnv,
+    PushCubeLoopEnv,
     ReachCubeEnv,
     StackTwoCubesEnv,
 )
 
-__all__ = ["LiftCubeEnv", "PickPlaceCubeEnv", "PushCubeEnv", "ReachCubeEnv", "StackTwoCubesEnv"]
+__all__ = ["LiftCubeEnv", "PickPlaceCubeEnv", "PushCubeEnv", "ReachCubeEnv", "StackTwoCubesEnv", "PushCubeLoopEnv"]

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
 ABI_VERSION = 1
-TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4}
+TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
 REWARD_TYPES = {"sparse": 0, "dense": 1}
@@ -81,6 +81,8 @@ class LcrOutView(ctypes.Structure):
         ("is_success", ctypes.c_void_p),
         ("did_reset", ctypes.c_void_p),
         ("terminal_obs", ctypes.c_void_p),
+        ("timestamp", ctypes.c_void_p),
+        ("current_goal", ctypes.c_void_p),
     ]
 
 
@@ -130,8 +132,8 @@ def load():
     L.lcr_step_host.argtypes = [vp, vp]
     L.lcr_get_obs.argtypes = [vp, ctypes.POINTER(LcrObsView)]
     L.lcr_get_outputs.argtypes = [vp, ctypes.POINTER(LcrOutView)]
-    L.lcr_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
-    L.lcr_set_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.lcr_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lcr_set_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lcr_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.lcr_free.argtypes = [vp, vp]
     L.lcr_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]

@@ -54,7 +54,7 @@ int lcr_nv(int task) { return task == LCR_TASK_STACK ? 18 : 12; }
 
 int lcr_config_default(lcr_config *cfg, int task) {
     if (!cfg) return fail(LCR_ERR_INVALID, "cfg is NULL");
-    if (task < LCR_TASK_REACH || task > LCR_TASK_STACK) return fail(LCR_ERR_INVALID, "unknown task %d", task);
+    if (task < LCR_TASK_REACH || task > LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_INVALID, "unknown task %d", task);
     memset(cfg, 0, sizeof *cfg);
     cfg->struct_size = sizeof(lcr_config);
     cfg->task = task;
@@ -82,7 +82,7 @@ int lcr_config_default(lcr_config *cfg, int task) {
 
 static int resolved_block_gripper(const lcr_config *cfg) {
     if (cfg->block_gripper >= 0) return cfg->block_gripper ? 1 : 0;
-    return (cfg->task == LCR_TASK_REACH || cfg->task == LCR_TASK_PUSH) ? 1 : 0;  // reach:82 push:84 / lift:82
+    return (cfg->task == LCR_TASK_REACH || cfg->task == LCR_TASK_PUSH || cfg->task == LCR_TASK_PUSH_LOOP) ? 1 : 0;  // reach:82 push:84 loop:80 / lift:82
 }
 
 int lcr_action_dim(const lcr_config *cfg) {
@@ -97,7 +97,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     *out = nullptr;
     if (cfg->struct_size != sizeof(lcr_config))
         return fail(LCR_ERR_INVALID, "lcr_config size mismatch (got %u, want %zu): ABI version skew", cfg->struct_size, sizeof(lcr_config));
-    if (cfg->task < LCR_TASK_REACH || cfg->task > LCR_TASK_STACK) return fail(LCR_ERR_INVALID, "unknown task %d", cfg->task);
+    if (cfg->task < LCR_TASK_REACH || cfg->task > LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_INVALID, "unknown task %d", cfg->task);
     if (cfg->n_envs <= 0) return fail(LCR_ERR_INVALID, "n_envs must be positive");
     if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
     if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters must be >= 0");
@@ -105,7 +105,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
     int k = lcr_action_dim(cfg);
     if (k < 0) return k;
-    const bool gripper_task = !(cfg->task == LCR_TASK_REACH || cfg->task == LCR_TASK_PUSH);
+    const bool gripper_task = !(cfg->task == LCR_TASK_REACH || cfg->task == LCR_TASK_PUSH || cfg->task == LCR_TASK_PUSH_LOOP);
     if (cfg->action_mode == LCR_ACTION_EE && gripper_task && resolved_block_gripper(cfg))
         return fail(LCR_ERR_INVALID, "ee mode with block_gripper on a gripper task indexes action[3] out of range in the reference (lift_cube_env.py:242)");
 
@@ -142,6 +142,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_tgt = off; off += al(sizeof(float) * 3 * N);
     size_t o_el = off; off += al(sizeof(int) * N);
     size_t o_rng = off; off += al(sizeof(unsigned long long) * 4 * N);
+    size_t o_goal = off; off += al(sizeof(int) * N);
+    size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_rew = off; off += al(sizeof(float) * N);
     size_t o_term = off; off += al(N);
     size_t o_trunc = off; off += al(N);
@@ -179,8 +181,20 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.inv_impratio = (float)(1.0 / (cfg->impratio > 1e-15 ? cfg->impratio : 1e-15));
     // scene constants: reach/lift/push cube 0.1 kg, I=1.6667e-4 (reach_cube.xml:25); pick_place 10 kg (pick_place_cube.xml:27);
     // stack 0.1 kg, I=1.125e-5 (stack_two_cubes.xml:27,33)
-    double cm = cfg->task == LCR_TASK_PICK_PLACE ? 10.0 : 0.1;
-    double ci = cfg->task == LCR_TASK_STACK ? 0.00001125 : 0.00016667;
+    // push_cube_loop.xml:29-31: 0.05 kg, I=1.125e-5, friction 1.5 / 1.5 (torsional)
+    const bool loop = cfg->task == LCR_TASK_PUSH_LOOP;
+    double cm = cfg->task == LCR_TASK_PICK_PLACE ? 10.0 : (loop ? 0.05 : 0.1);
+    double ci = (cfg->task == LCR_TASK_STACK || loop) ? 0.00001125 : 0.00016667;
+    {
+        const double mu = loop ? 1.5 : 0.5, mut = loop ? 1.5 : 0.005;   // cube geom friction (tangential, torsional)
+        const double muf = 1.5, muft = loop ? 1.5 : 0.005;               // finger<->cube pair: max of both geoms
+        D.rt_cube = (float)(mu * mu / (mut * mut));
+        D.inv_mu_c2 = (float)(1.0 / (mu * mu));
+        D.inv_mu_ct2 = (float)(1.0 / (mut * mut));
+        D.rt_fc = (float)(muf * muf / (muft * muft));
+        D.inv_mu_fct2 = (float)(1.0 / (muft * muft));
+        D.walls = loop ? 1 : 0;
+    }
     D.cube_mass = (float)cm;
     D.cube_minv = (float)(1.0 / cm);
     D.cube_iinv = (float)(1.0 / ci);
@@ -190,6 +204,11 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         double tl[3] = {-cfg->target_xy_range / 2, -cfg->target_xy_range / 2, 0};
         double th[3] = {cfg->target_xy_range / 2, cfg->target_xy_range / 2, cfg->task == LCR_TASK_PICK_PLACE ? cfg->goal_z_range : 0.0};
         tl[1] += 0.165; th[1] += 0.10;
+        if (loop) {  // push_cube_loop_env.py:130-135 with push_cube_loop.xml:38: goal_region_high = size/2, [:2] -= 0.008, low = high*(-1,-1,1)
+            double gh[3] = {0.035 / 2, 0.045 / 2, 0.007 / 2};
+            gh[0] -= 0.008; gh[1] -= 0.008;
+            for (int i = 0; i < 3; i++) { hi[i] = gh[i]; lo[i] = gh[i] * (i < 2 ? -1.0 : 1.0); }
+        }
         for (int i = 0; i < 3; i++) { D.cube_lo[i] = lo[i]; D.cube_rng[i] = hi[i] - lo[i]; D.tgt_lo[i] = tl[i]; D.tgt_rng[i] = th[i] - tl[i]; }
     }
     D.qpos = (float *)(base + o_qpos);
@@ -198,6 +217,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.target = (float *)(base + o_tgt);
     D.elapsed = (int *)(base + o_el);
     D.rng = (unsigned long long *)(base + o_rng);
+    D.goal = (int *)(base + o_goal);
+    D.sim_time = (double *)(base + o_time);
     D.reward = (float *)(base + o_rew);
     D.terminated = (unsigned char *)(base + o_term);
     D.truncated = (unsigned char *)(base + o_trunc);
@@ -307,10 +328,13 @@ int lcr_get_outputs(lcr_sim *s, lcr_out_view *out) {
     out->is_success = s->dev.is_success;
     out->did_reset = s->dev.did_reset;
     out->terminal_obs = s->dev.term_obs;
+    out->timestamp = s->dev.sim_time;
+    out->current_goal = s->dev.goal;
     return LCR_OK;
 }
 
-int lcr_get_state(lcr_sim *s, double *qpos, double *qvel, double *ee_lag, float *target, int32_t *elapsed, uint64_t *rng) {
+int lcr_get_state(lcr_sim *s, double *qpos, double *qvel, double *ee_lag, float *target, int32_t *elapsed, uint64_t *rng,
+                  int32_t *current_goal, double *sim_time) {
     SIMCHK(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     const size_t N = (size_t)s->dev.n;
@@ -327,11 +351,13 @@ int lcr_get_state(lcr_sim *s, double *qpos, double *qvel, double *ee_lag, float 
     if (target) HIPCHK(hipMemcpy(target, s->dev.target, 3 * N * sizeof(float), hipMemcpyDeviceToHost));
     if (elapsed) HIPCHK(hipMemcpy(elapsed, s->dev.elapsed, N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (rng) HIPCHK(hipMemcpy(rng, s->dev.rng, 4 * N * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (current_goal) HIPCHK(hipMemcpy(current_goal, s->dev.goal, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (sim_time) HIPCHK(hipMemcpy(sim_time, s->dev.sim_time, N * sizeof(double), hipMemcpyDeviceToHost));
     return LCR_OK;
 }
 
 int lcr_set_state(lcr_sim *s, const double *qpos, const double *qvel, const double *ee_lag, const float *target,
-                  const int32_t *elapsed, const uint64_t *rng) {
+                  const int32_t *elapsed, const uint64_t *rng, const int32_t *current_goal, const double *sim_time) {
     SIMCHK(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     const size_t N = (size_t)s->dev.n;
@@ -347,6 +373,8 @@ int lcr_set_state(lcr_sim *s, const double *qpos, const double *qvel, const doub
     if (target) HIPCHK(hipMemcpy(s->dev.target, target, 3 * N * sizeof(float), hipMemcpyHostToDevice));
     if (elapsed) HIPCHK(hipMemcpy(s->dev.elapsed, elapsed, N * sizeof(int32_t), hipMemcpyHostToDevice));
     if (rng) HIPCHK(hipMemcpy(s->dev.rng, rng, 4 * N * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (current_goal) HIPCHK(hipMemcpy(s->dev.goal, current_goal, N * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (sim_time) HIPCHK(hipMemcpy(s->dev.sim_time, sim_time, N * sizeof(double), hipMemcpyHostToDevice));
     return LCR_OK;
 }
 

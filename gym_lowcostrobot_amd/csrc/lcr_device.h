@@ -20,6 +20,14 @@ struct LcrDev {
     long long env_off;
     float dist_thr, height_thr, inv_impratio;
     float cube_mass, cube_minv, cube_iinv;
+    // friction of the cube geom (reach_cube.xml:26: 0.5 / torsional 0.005; push_cube_loop.xml:31: 1.5 / 1.5) and of the
+    // finger<->cube pair (max rule): ratios used by the elliptic-cone regularisation and projection
+    float rt_cube;       // mu_tan^2 / mu_tors^2 of cube contacts
+    float inv_mu_c2;     // 1 / mu_tan^2
+    float inv_mu_ct2;    // 1 / mu_tors^2
+    float rt_fc;         // finger<->cube: mu_tan^2 / mu_tors^2
+    float inv_mu_fct2;   // finger<->cube: 1 / mu_tors^2
+    int walls;           // PushCubeLoop rails
     // reset sampling boxes, fp64 exactly as the reference builds them (reach_cube_env.py:132-139, push:141-148)
     double cube_lo[3], cube_rng[3], tgt_lo[3], tgt_rng[3];
     // state, SoA [component][n]
@@ -29,6 +37,8 @@ struct LcrDev {
     float *target;    // [3][n]
     int *elapsed;     // [n]
     unsigned long long *rng;  // [4][n]  PCG64 state_hi, state_lo, inc_hi, inc_lo
+    int *goal;        // [n]  PushCubeLoop current_goal (persists across resets)
+    double *sim_time; // [n]  accumulated simulation time (data.time is never reset by the reference)
     // step outputs
     float *reward;
     unsigned char *terminated, *truncated, *is_success, *did_reset;

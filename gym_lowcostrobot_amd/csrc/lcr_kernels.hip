@@ -49,7 +49,10 @@ constexpr float K_FC = 1.0f / (0.975f * 0.975f * 0.02f * 0.02f), B_FC = 2.0f / (
 constexpr float D0_FC = 0.4575f, DW_FC = 0.975f, W_FC = 0.0185f;
 constexpr float K_FF = 1.0f / (0.9999f * 0.9999f * 0.02f * 0.02f), B_FF = 2.0f / (0.9999f * 0.02f);  // finger-floor
 constexpr float D0_FF = 0.015f, DW_FF = 0.9999f, W_FF = 0.036f;
-constexpr float MU_CUBE = 0.5f, MU_FINGER = 1.5f, MU_TORS = 0.005f;
+constexpr float MU_FINGER = 1.5f, MU_TORS = 0.005f;  // finger geom (follower.xml:15); the cube geom's friction is per task (LcrDev)
+constexpr float RT_FF = (MU_FINGER * MU_FINGER) / (MU_TORS * MU_TORS);
+// PushCubeLoop rails (push_cube_loop.xml:44-47): inner faces of the four wall boxes and their top
+constexpr float WALL_X = 0.115f, WALL_Y0 = 0.10f, WALL_Y1 = 0.17f, WALL_TOP = 0.012f;
 constexpr float INVW_DOF[6] = {lcrm::INVW_DOF1, lcrm::INVW_DOF2, lcrm::INVW_DOF3, lcrm::INVW_DOF4, lcrm::INVW_DOF5, lcrm::INVW_DOF6};
 
 struct f3 { float x, y, z; };
@@ -359,6 +362,7 @@ struct Warm {
     float floor[NC][4][4];
     float arm[4][4];
     float lim[6];
+    float wall[4][4];
     bool cc_prev[4];
 };
 
@@ -373,7 +377,7 @@ template <int NC> struct LdsSize { static constexpr int value = LDS_G_FLOATS + (
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC>
+template <int NC, bool WALLS>
 DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC> &W) {
     using namespace lcrm;
     // ---- position stage -------------------------------------------------------------------------
@@ -517,7 +521,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             float imp = impedance(sdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
             float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);  // diagApprox = cube body_invweight0 (translational)
             float Rf = Rn * P.inv_impratio;                          // elliptic cone: friction rows R/impratio
-            float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+            float Rt = Rf * P.rt_cube;
             T.Rn = Rn;
             f3 vp = S.cv[c] + cross(cww[c], T.r);  // velocity of the contact point
             T.aref[0] = -B_DEF * vp.z - K_DEF * imp * sdist[s];
@@ -666,7 +670,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 float imp = impedance(cdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
                 float Rn = fmaxf((1.f - imp) * rcp(imp) * (2.f * minv), 1e-15f);
                 float Rf = Rn * P.inv_impratio;
-                float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+                float Rt = Rf * P.rt_cube;
                 f3 vrel = (S.cv[1] + cross(cww[1], r1)) - (S.cv[0] + cross(cww[0], r0));
                 f3 wrel = cww[1] - cww[0];
                 ccl[(s * CC_REC + 0) * 64] = cpos[s].x; ccl[(s * CC_REC + 1) * 64] = cpos[s].y; ccl[(s * CC_REC + 2) * 64] = cpos[s].z;
@@ -692,6 +696,81 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     ccl[(s * CC_REC + 11 + r) * 64] = rcp(diag + Rr);
                 }
                 ccl[(s * CC_REC + 15) * 64] = Rn;
+            }
+        }
+    }
+
+    // ---- collision: PushCubeLoop rails.  The four wall boxes act as their inner faces (vertical half-spaces below the wall
+    //      top); cube vertices beyond a face, in wall order (left, right, top, bottom) x vertex order, first 4 kept. ----
+    FloorSlot WS[4];   // same record as a floor slot; the frame depends on the wall
+    int wall_id[4] = {0, 0, 0, 0};
+    bool wall_any = false;
+    if constexpr (WALLS) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { WS[s].act = false; WS[s].r = mk(0.f, 0.f, 0.f); WS[s].Rn = 1.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { WS[s].f[k] = 0.f; WS[s].aref[k] = 0.f; WS[s].inv[k] = 0.f; } }
+        f3 vw[8];
+        float worst = 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
+            vw[i] = axpy(sx, CR[0].X, axpy(sy, CR[0].Y, sz * CR[0].Z));   // relative to the cube centre
+            const f3 p = vw[i] + S.cp[0];
+            const float dmin = fminf(fminf(p.x + WALL_X, WALL_X - p.x), fminf(p.y - WALL_Y0, WALL_Y1 - p.y));
+            worst = fminf(worst, p.z < WALL_TOP ? dmin : 1.f);
+        }
+        wall_any = __any(worst < 0.f) != 0;
+        if (wall_any) {
+            int cnt = 0;
+            float wdist[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const f3 p = vw[i] + S.cp[0];
+                    const float dist = w == 0 ? p.x + WALL_X : (w == 1 ? WALL_X - p.x : (w == 2 ? p.y - WALL_Y0 : WALL_Y1 - p.y));
+                    const bool pen = dist < 0.f && p.z < WALL_TOP && cnt < 4;
+                    const float nx = w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), ny = w == 2 ? 1.f : (w == 3 ? -1.f : 0.f);
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const bool take = pen && cnt == s;
+                        WS[s].r.x = take ? vw[i].x - 0.5f * dist * nx : WS[s].r.x;
+                        WS[s].r.y = take ? vw[i].y - 0.5f * dist * ny : WS[s].r.y;
+                        WS[s].r.z = take ? vw[i].z : WS[s].r.z;
+                        wdist[s] = take ? dist : wdist[s];
+                        wall_id[s] = take ? w : wall_id[s];
+                        WS[s].act = WS[s].act || take;
+                    }
+                    cnt += pen ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                FloorSlot &T = WS[s];
+                const int w = wall_id[s];
+                const f3 n = mk(w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), w == 2 ? 1.f : (w == 3 ? -1.f : 0.f), 0.f);
+                const f3 t1 = w < 2 ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f);   // mju_makeFrame of an axis-aligned normal
+                const f3 t2 = cross(n, t1);
+                float imp = impedance(wdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
+                float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
+                float Rf = Rn * P.inv_impratio;
+                float Rt = Rf * P.rt_cube;
+                T.Rn = Rn;
+                const f3 vp = S.cv[0] + cross(cww[0], T.r);
+                const f3 c0 = cross(T.r, n), c1 = cross(T.r, t1), c2 = cross(T.r, t2);
+                T.aref[0] = -B_DEF * dot(n, vp) - K_DEF * imp * wdist[s];
+                T.aref[1] = -B_DEF * dot(t1, vp);
+                T.aref[2] = -B_DEF * dot(t2, vp);
+                T.aref[3] = -B_DEF * dot(n, cww[0]);
+                T.inv[0] = rcp(minv + iinv * dot(c0, c0) + Rn);
+                T.inv[1] = rcp(minv + iinv * dot(c1, c1) + Rf);
+                T.inv[2] = rcp(minv + iinv * dot(c2, c2) + Rf);
+                T.inv[3] = rcp(iinv + Rt);
+#pragma unroll
+                for (int k = 0; k < 4; k++) T.f[k] = T.act ? W.wall[s][k] : 0.f;   // warm start
+                ca[0] = axpy(minv * T.f[0], n, axpy(minv * T.f[1], t1, axpy(minv * T.f[2], t2, ca[0])));
+                cal[0] = axpy(iinv * T.f[0], c0, axpy(iinv * T.f[1], c1, axpy(iinv * T.f[2], c2, axpy(iinv * T.f[3], n, cal[0]))));
             }
         }
     }
@@ -765,12 +844,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 else { cube_p = S.cp[0]; cube_v = S.cv[0]; cube_w = cww[0]; }
                 T.rc = pos - cube_p;
             }
-            float imp, Kc, Bc, mu0 = MU_FINGER;
+            float imp, Kc, Bc;
             if (vs_cube) { imp = impedance(dist, D0_FC, DW_FC, 1.0f / W_FC); Kc = K_FC; Bc = B_FC; }
             else { imp = impedance(dist, D0_FF, DW_FF, 1.0f / W_FF); Kc = K_FF; Bc = B_FF; }
             float Rn = fmaxf((1.f - imp) * rcp(imp) * (invw_link + (vs_cube ? minv : 0.f)), 1e-15f);
             float Rf = Rn * P.inv_impratio;
-            float Rt = Rf * (mu0 * mu0) / (MU_TORS * MU_TORS);
+            float Rt = Rf * (vs_cube ? P.rt_fc : RT_FF);
             T.Rn = Rn;
             // point Jacobian columns of the link at the contact point
             f3 jc[6];
@@ -877,7 +956,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 FloorSlot &T = FS[c][s];
                 const f3 r = T.r;
                 const float Rf = T.Rn * P.inv_impratio;
-                const float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+                const float Rt = Rf * P.rt_cube;
                 // Block form of the four Gauss-Seidel row updates of this contact (same arithmetic as row-by-row GS):
                 // rows J_r = [d_r ; c_r], d = (z, y, -x, 0), c = (r x d) resp. z for the torsion row.  The row residuals
                 // against the CURRENT acceleration (u_r) are independent of each other; the coupling inside the contact is
@@ -897,7 +976,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // elliptic cone: radial projection of the friction part
                 const float fn = T.f[0] + d0;
                 const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
-                const float s2 = (g1 * g1 + g2 * g2) * (1.f / (MU_CUBE * MU_CUBE)) + g3 * g3 * (1.f / (MU_TORS * MU_TORS));
+                const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
                 const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
                 const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                 T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
@@ -919,7 +998,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const f3 r0 = pos - S.cp[0], r1 = pos - S.cp[1];
                     const float Rn = ccl[(s * CC_REC + 15) * 64];
                     const float Rf = Rn * P.inv_impratio;
-                    const float Rt = Rf * (MU_CUBE * MU_CUBE) / (MU_TORS * MU_TORS);
+                    const float Rt = Rf * P.rt_cube;
                     float f[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) f[r] = ccl[(s * CC_REC + 3 + r) * 64];
@@ -943,7 +1022,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         } else { cal[1] = axpy(iinv * dlt, d, cal[1]); cal[0] = axpy(-iinv * dlt, d, cal[0]); }
                     }
                     float fn = f[0];
-                    float s2 = (f[1] * f[1] + f[2] * f[2]) * (1.f / (MU_CUBE * MU_CUBE)) + f[3] * f[3] * (1.f / (MU_TORS * MU_TORS));
+                    float s2 = (f[1] * f[1] + f[2] * f[2]) * P.inv_mu_c2 + f[3] * f[3] * P.inv_mu_ct2;
                     float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
 #pragma unroll
                     for (int r = 1; r < 4; r++) {
@@ -961,6 +1040,44 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
         }
+        // rails (PushCubeLoop)
+        if constexpr (WALLS) {
+            if (wall_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    FloorSlot &T = WS[s];
+                    const int w = wall_id[s];
+                    const f3 n = mk(w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), w == 2 ? 1.f : (w == 3 ? -1.f : 0.f), 0.f);
+                    const f3 t1 = w < 2 ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f);
+                    const f3 t2 = cross(n, t1);
+                    const float Rf = T.Rn * P.inv_impratio, Rt = Rf * P.rt_cube;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const f3 d = r == 0 ? n : (r == 1 ? t1 : (r == 2 ? t2 : n));
+                        const f3 c = cross(T.r, d);
+                        const float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                        float res = (r < 3 ? dot(d, ca[0]) + dot(c, cal[0]) : dot(d, cal[0])) - T.aref[r] + Rr * T.f[r];
+                        float nf = T.f[r] - res * T.inv[r];
+                        if (r == 0) nf = fmaxf(nf, 0.f);
+                        const float dlt = T.act ? nf - T.f[r] : 0.f;
+                        T.f[r] += dlt;
+                        if (r < 3) { ca[0] = axpy(minv * dlt, d, ca[0]); cal[0] = axpy(iinv * dlt, c, cal[0]); }
+                        else cal[0] = axpy(iinv * dlt, d, cal[0]);
+                    }
+                    const float fn = T.f[0];
+                    const float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * P.inv_mu_c2 + T.f[3] * T.f[3] * P.inv_mu_ct2;
+                    const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+#pragma unroll
+                    for (int r = 1; r < 4; r++) {
+                        const f3 d = r == 1 ? t1 : (r == 2 ? t2 : n);
+                        const float dlt = T.f[r] * sc - T.f[r];
+                        T.f[r] += dlt;
+                        if (r < 3) { ca[0] = axpy(minv * dlt, d, ca[0]); cal[0] = axpy(iinv * dlt, cross(T.r, d), cal[0]); }
+                        else cal[0] = axpy(iinv * dlt, d, cal[0]);
+                    }
+                }
+            }
+        }
         // finger spheres
         if (wave_arm) {
 #pragma unroll
@@ -970,7 +1087,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const bool vs_cube = s < 2;
                 const int sp = s & 1;
                 const float Rf = T.Rn * P.inv_impratio;
-                const float Rt = Rf * (MU_FINGER * MU_FINGER) / (MU_TORS * MU_TORS);
+                const float Rt = Rf * (vs_cube ? P.rt_fc : RT_FF);
                 float g[4][6];
 #pragma unroll
                 for (int r = 0; r < 4; r++)
@@ -1009,7 +1126,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // cone projection
                 {
                     float fn = T.f[0];
-                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * (1.f / (MU_FINGER * MU_FINGER)) + T.f[3] * T.f[3] * (1.f / (MU_TORS * MU_TORS));
+                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * (1.f / (MU_FINGER * MU_FINGER)) + T.f[3] * T.f[3] * (vs_cube ? P.inv_mu_fct2 : 1.f / (MU_TORS * MU_TORS));
                     float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
 #pragma unroll
                     for (int r = 1; r < 4; r++) {
@@ -1049,6 +1166,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = flim[j];
+    if constexpr (WALLS) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) W.wall[s][k] = WS[s].f[k];
+    }
 
     // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y -------------------
     float rhs[6];
@@ -1100,13 +1223,17 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // reset of one env (reach_cube_env.py:297-311 etc.); sampling in fp64 exactly as numpy does
 // ------------------------------------------------------------------------------------------------
 template <int NC>
-DEV void reset_env(const LcrDev &P, EnvState<NC> &S, Pcg &g, f3 &target, f3 &ee_lag) {
+DEV void reset_env(const LcrDev &P, EnvState<NC> &S, Pcg &g, f3 &target, f3 &ee_lag, int goal) {
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         // low + range*u with separately rounded product and sum (numpy's random_uniform); never contracted into an fma
         double x = __dadd_rn(P.cube_lo[0], __dmul_rn(P.cube_rng[0], pcg_double(g)));
         double yv = __dadd_rn(P.cube_lo[1], __dmul_rn(P.cube_rng[1], pcg_double(g)));
         double zv = __dadd_rn(P.cube_lo[2], __dmul_rn(P.cube_rng[2], pcg_double(g)));
+        if (P.walls) {  // push_cube_loop_env.py:304-308: the sample is centred on the current goal region
+            x = __dadd_rn(x, goal ? -0.06 : 0.06);
+            yv = __dadd_rn(yv, 0.135);
+        }
         S.cp[c] = mk((float)x, (float)yv, (float)zv);
         S.cq[c][0] = 1.f; S.cq[c][1] = 0.f; S.cq[c][2] = 0.f; S.cq[c][3] = 0.f;
     }
@@ -1160,7 +1287,7 @@ DEV void write_obs18(const LcrDev &P, float *dst, int e, const EnvState<NC> &S, 
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE>
+template <int NC, bool EE, bool WALLS>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
     __shared__ float lds[LdsSize<NC>::value];
     const int lane = threadIdx.x;
@@ -1174,6 +1301,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     f3 target = mk(0.f, 0.f, 0.f);
     if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
     int elapsed = P.elapsed[e];
+    int goal = WALLS ? P.goal[e] : 0;
 
     // ---- apply_action (reach_cube_env.py:223-273) ------------------------------------------------
     float act[6];
@@ -1262,7 +1390,11 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = 0.f;
-    for (int s = 0; s < P.n_substeps; s++) substep<NC>(P, S, ctrl, lds, lane, lag_ee, lag_cube, W);
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) W.wall[s][k] = 0.f;
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS>(P, S, ctrl, lds, lane, lag_ee, lag_cube, W);
 
     // ---- reward / success / termination (reach:313-348 and per-task deltas), lagged kinematics (P8) ----
     f3 a3, b3;
@@ -1276,7 +1408,19 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         else { a3 = lag_cube[0]; b3 = target; }
         f3 df = a3 - b3;
         float d = sqrtf(dot(df, df));
-        if (task == 1) {  // lift:341-345: (cube_z - height_threshold) + distance, never terminates, info = {}
+        if (task == 5) {  // PushCubeLoop get_reward / get_cube_overlap (push_cube_loop_env.py:334-383), FRESH cube position
+            const float xc = S.cp[0].x, yc = S.cp[0].y, wc = 0.0075f;            // cube_size = 0.015 / 2 (:124)
+            const float gx = goal ? -0.06f : 0.06f, gy = 0.135f;                 // push_cube_loop.xml:38,41
+            const float gh0 = 0.0095f, gh1 = 0.0145f;                            // goal_region_high[:2] (:133-134)
+            const float xo = fmaxf(0.f, fminf(xc + wc, gx + gh0) - fmaxf(xc - wc, gx - gh0));
+            const float yo = fmaxf(0.f, fminf(yc + wc, gy + gh1) - fmaxf(yc - wc, gy - gh1));
+            const float overlap = xo * yo * (1.f / (4.f * 0.0075f * 0.0075f));
+            success = overlap > 0.95f;
+            terminated = false;
+            const float edge = -gh1 + gy;
+            reward = success ? 5.f : (overlap > 0.f ? overlap - 1.f : clampf(-fabsf(yc - edge) * (1.f / 0.16f) - 1.f, -2.f, -1.f));
+            if (success) goal = 1 - goal;                                         // the goal side switches and PERSISTS (:341)
+        } else if (task == 1) {  // lift:341-345: (cube_z - height_threshold) + distance, never terminates, info = {}
             reward = (lag_cube[0].z - P.height_thr) + d;
             success = false; terminated = false;
         } else {
@@ -1313,7 +1457,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     if (do_reset) {  // SB3 VecEnv semantics: keep the terminal observation, then reset in place
         if (valid) write_obs18<NC>(P, P.term_obs, e, S, target);
         Pcg g = load_rng(P, e);
-        reset_env<NC>(P, S, g, target, lag_ee);
+        reset_env<NC>(P, S, g, target, lag_ee, goal);
         if (diverged) {
 #pragma unroll
             for (int j = 0; j < 6; j++) S.qd[j] = 0.f;
@@ -1330,6 +1474,8 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         store_state<NC>(P, e, S);
         P.elapsed[e] = elapsed;
         P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
+        if (WALLS) P.goal[e] = goal;
+        if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);  // data.time advances in mj_step only
     }
 }
 
@@ -1351,7 +1497,7 @@ __global__ __launch_bounds__(256) void lcr_reset_kernel(LcrDev P, const unsigned
     else g = load_rng(P, e);
     f3 target = mk(0.f, 0.f, 0.f), ee;
     if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
-    reset_env<NC>(P, S, g, target, ee);
+    reset_env<NC>(P, S, g, target, ee, P.walls ? P.goal[e] : 0);
     store_rng(P, e, g);
     store_state<NC>(P, e, S);
     if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }
@@ -1478,10 +1624,12 @@ int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void 
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (P.n + 63) / 64;
     const bool stack = P.task == 4;
-    if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<2, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
     return check_launch();
 }
 

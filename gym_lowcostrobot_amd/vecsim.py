@@ -127,6 +127,8 @@ class VecSim:
         self.is_success = DeviceArray(self, out.is_success, (N,), np.uint8)
         self.did_reset = DeviceArray(self, out.did_reset, (N,), np.uint8)
         self.terminal_obs = DeviceArray(self, out.terminal_obs, (18, N), np.float32)
+        self.timestamp = DeviceArray(self, out.timestamp, (N,), np.float64)
+        self.current_goal = DeviceArray(self, out.current_goal, (N,), np.int32)
 
     # ---- lifecycle ----
     def close(self):
@@ -226,12 +228,13 @@ class VecSim:
         st = {
             "qpos": np.zeros((self.nq, N)), "qvel": np.zeros((self.nv, N)), "ee_lag": np.zeros((3, N)),
             "target": np.zeros((3, N), np.float32), "elapsed": np.zeros(N, np.int32), "rng": np.zeros((4, N), np.uint64),
+            "current_goal": np.zeros(N, np.int32), "sim_time": np.zeros(N),
         }
         check(self.L.lcr_get_state(self.handle, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["ee_lag"]), _vp(st["target"]),
-                                   _vp(st["elapsed"]), _vp(st["rng"])))
+                                   _vp(st["elapsed"]), _vp(st["rng"]), _vp(st["current_goal"]), _vp(st["sim_time"])))
         return st
 
-    def set_state(self, qpos=None, qvel=None, ee_lag=None, target=None, elapsed=None, rng=None):
+    def set_state(self, qpos=None, qvel=None, ee_lag=None, target=None, elapsed=None, rng=None, current_goal=None, sim_time=None):
         N = self.n
 
         def prep(a, shape, dt):
@@ -245,4 +248,6 @@ class VecSim:
         qpos, qvel = prep(qpos, (self.nq, N), np.float64), prep(qvel, (self.nv, N), np.float64)
         ee_lag, target = prep(ee_lag, (3, N), np.float64), prep(target, (3, N), np.float32)
         elapsed, rng = prep(elapsed, (N,), np.int32), prep(rng, (4, N), np.uint64)
-        check(self.L.lcr_set_state(self.handle, _vp(qpos), _vp(qvel), _vp(ee_lag), _vp(target), _vp(elapsed), _vp(rng)))
+        current_goal, sim_time = prep(current_goal, (N,), np.int32), prep(sim_time, (N,), np.float64)
+        check(self.L.lcr_set_state(self.handle, _vp(qpos), _vp(qvel), _vp(ee_lag), _vp(target), _vp(elapsed), _vp(rng),
+                                   _vp(current_goal), _vp(sim_time)))

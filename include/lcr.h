@@ -41,7 +41,8 @@ typedef enum lcr_task {
     LCR_TASK_LIFT = 1,        /* LiftCube-v0        envs/lift_cube_env.py */
     LCR_TASK_PUSH = 2,        /* PushCube-v0        envs/push_cube_env.py */
     LCR_TASK_PICK_PLACE = 3,  /* PickPlaceCube-v0   envs/pick_place_cube_env.py */
-    LCR_TASK_STACK = 4        /* StackTwoCubes-v0   envs/stack_two_cubes_env.py */
+    LCR_TASK_STACK = 4,       /* StackTwoCubes-v0   envs/stack_two_cubes_env.py */
+    LCR_TASK_PUSH_LOOP = 5    /* PushCubeLoop-v0    envs/push_cube_loop_env.py */
 } lcr_task;
 
 enum { LCR_ACTION_JOINT = 0, LCR_ACTION_EE = 1 };            /* action_mode   reach_cube_env.py:80 */
@@ -110,6 +111,8 @@ typedef struct lcr_out_view {
     const uint8_t *is_success;  /* [N]  info["is_success"] (lift: always 0, reference returns info={}) */
     const uint8_t *did_reset;   /* [N]  1 where the env was auto-reset at the end of this step */
     const float *terminal_obs;  /* [18][N] arm_qpos6, arm_qvel6, cube_pos3, aux3 -- valid where did_reset */
+    const double *timestamp;    /* [N]  accumulated simulation time = info["timestamp"] of PushCubeLoop-v0 (push_cube_loop_env.py:328) */
+    const int32_t *current_goal;/* [N]  PushCubeLoop-v0 goal side (0|1), persists across resets (push_cube_loop_env.py:136,341) */
 } lcr_out_view;
 
 int lcr_abi_version(void);
@@ -150,9 +153,10 @@ int lcr_get_outputs(lcr_sim *sim, lcr_out_view *out);
  * also checkpoint/resume and the "(qpos, qvel, action) triple" parity tests).  Host pointers, any may be
  * NULL, SoA [component][N]; synchronous. */
 int lcr_get_state(lcr_sim *sim, double *qpos /*[nq][N]*/, double *qvel /*[nv][N]*/, double *ee_lag /*[3][N]*/,
-                  float *target /*[3][N]*/, int32_t *elapsed /*[N]*/, uint64_t *rng /*[4][N]*/);
+                  float *target /*[3][N]*/, int32_t *elapsed /*[N]*/, uint64_t *rng /*[4][N]*/,
+                  int32_t *current_goal /*[N]*/, double *sim_time /*[N]*/);
 int lcr_set_state(lcr_sim *sim, const double *qpos, const double *qvel, const double *ee_lag, const float *target,
-                  const int32_t *elapsed, const uint64_t *rng);
+                  const int32_t *elapsed, const uint64_t *rng, const int32_t *current_goal, const double *sim_time);
 
 /* small device-memory helpers so a ctypes/numpy caller needs no other GPU library */
 int lcr_malloc(lcr_sim *sim, size_t bytes, void **dev_out);

@@ -92,11 +92,22 @@ static const double SOLIMP_FINGER[5] = {0.015, 1.0, 0.036, 0.5, 2.0};
 static const double SOLIMP_FINGER_CUBE[5] = {0.4575, 0.975, 0.0185, 0.5, 2.0};
 static const double MU_CUBE[3] = {0.5, 0.5, 0.005};   /* reach_cube.xml:26 friction="0.5" (+default torsional) */
 static const double MU_FINGER[3] = {1.5, 1.5, 0.005}; /* follower.xml:15 friction="1.5" */
+/* push_cube_loop.xml:31 cube friction="1.5 1.5 1.5" (tangential, torsional, rolling), priority 1: used against the floor
+ * and the walls (priority 0) and, by the max rule, against the fingers (priority 1) */
+static const double MU_LOOP[3] = {1.5, 1.5, 1.5};
+/* push_cube_loop.xml:44-47 rails: inner faces of the four wall boxes, top of the walls */
+#define WALL_X 0.115
+#define WALL_Y0 0.10
+#define WALL_Y1 0.17
+#define WALL_TOP 0.012
 
 typedef struct {
     int ncube;
     double cube_mass, cube_inertia;
     int has_target;
+    int walls;            /* PushCubeLoop rails */
+    const double *mu_cube; /* cube geom friction */
+    const double *mu_finger_cube;
 } task_model;
 
 static task_model get_task_model(int task) {
@@ -108,6 +119,10 @@ static task_model get_task_model(int task) {
     if (task == ORC_TASK_PICK_PLACE) { t.cube_mass = 10.0; t.has_target = 1; } /* pick_place_cube.xml:27 REF-QUIRK-4 */
     if (task == ORC_TASK_PUSH) t.has_target = 1;
     if (task == ORC_TASK_STACK) { t.ncube = 2; t.cube_inertia = 0.00001125; }   /* stack_two_cubes.xml:27,33 */
+    t.walls = 0; t.mu_cube = MU_CUBE; t.mu_finger_cube = MU_FINGER;
+    if (task == ORC_TASK_PUSH_LOOP) { /* push_cube_loop.xml:29-31 */
+        t.cube_mass = 0.05; t.cube_inertia = 0.00001125; t.walls = 1; t.mu_cube = MU_LOOP; t.mu_finger_cube = MU_LOOP;
+    }
     return t;
 }
 
@@ -198,6 +213,7 @@ typedef struct {
     real sph[NSPH][3];
     int ncube;
     real cR[2][9], cp[2][3];
+    const double *mu_cube, *mu_finger_cube;
 } kin_t;
 
 static void arm_kinematics(const real *q, kin_t *K) {
@@ -399,7 +415,7 @@ static int collide_plane_box(const kin_t *K, int c, contact_t *out) {
         v3set(ct->pos, w[0], w[1], w[2] - dist * (real)0.5);
         real nz[3] = {0, 0, 1};
         make_frame(ct->frame, nz);
-        ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT; /* P9: cube priority 1 beats floor priority 0 */
+        ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT; /* P9: cube priority 1 beats floor priority 0 */
     }
     return n;
 }
@@ -438,7 +454,7 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
     make_frame(ct->frame, nw);
     ct->slot = 12 + s;
     ct->b1 = 6 + c; ct->b2 = SPH_LINK[s]; ct->dist = dist;
-    ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER_CUBE;
+    ct->mu = K->mu_finger_cube; ct->solimp = SOLIMP_FINGER_CUBE;
     return 1;
 }
 static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
@@ -452,6 +468,33 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
     return 1;
 }
+/* (D7) PushCubeLoop rails (push_cube_loop.xml:44-47): the four wall boxes are restated as their inner faces -- vertical
+ * half-spaces that only act below the wall top (z < 0.012).  Cube vertices beyond a face (in wall order left, right,
+ * top, bottom; vertex order 0..7) give contacts, at most 4 in total; frame normal points from the wall into the pen. */
+static int collide_walls(const kin_t *K, contact_t *out) {
+    int n = 0;
+    for (int w = 0; w < 4 && n < 4; w++) {
+        real nw[3] = {0, 0, 0};
+        if (w == 0) nw[0] = 1; else if (w == 1) nw[0] = -1; else if (w == 2) nw[1] = 1; else nw[1] = -1;
+        for (int i = 0; i < 8 && n < 4; i++) {
+            real v[3] = {(i & 1) ? (real)CUBE_HALF : (real)-CUBE_HALF, (i & 2) ? (real)CUBE_HALF : (real)-CUBE_HALF,
+                         (i & 4) ? (real)CUBE_HALF : (real)-CUBE_HALF}, p[3];
+            m3v(p, K->cR[0], v);
+            v3add(p, p, K->cp[0]);
+            real dist = w == 0 ? p[0] + (real)WALL_X : (w == 1 ? (real)WALL_X - p[0] : (w == 2 ? p[1] - (real)WALL_Y0 : (real)WALL_Y1 - p[1]));
+            if (!(dist < 0) || !(p[2] < (real)WALL_TOP)) continue;
+            contact_t *ct = &out[n];
+            ct->slot = 8 + n;
+            n++;
+            ct->b1 = -1; ct->b2 = 6; ct->dist = dist;
+            v3set(ct->pos, p[0] - nw[0] * dist * (real)0.5, p[1] - nw[1] * dist * (real)0.5, p[2]);
+            make_frame(ct->frame, nw);
+            ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT;
+        }
+    }
+    return n;
+}
+
 /* (D5) box0 (geom1) vs box1 (geom2).  Restated manifold (own construction, MuJoCo's mjc_BoxBox is not available):
  *  1. separating-axis test over the 6 face normals; the axis of least overlap gives the contact normal n (0 -> 1),
  *     the reference box A (owner of that axis) and the incident box B;
@@ -643,6 +686,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     kin_t K;
     /* -- position stage: normalise quaternions, kinematics */
     K.ncube = nc;
+    K.mu_cube = T->mu_cube; K.mu_finger_cube = T->mu_finger_cube;
     for (int c = 0; c < nc; c++) {
         real *qq = qpos + 6 + 7 * c + 3, n2 = 0;
         for (int k = 0; k < 4; k++) n2 += qq[k] * qq[k];
@@ -696,6 +740,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     int ncon = 0;
     for (int c = 0; c < nc; c++) ncon += collide_plane_box(&K, c, con + ncon);
     if (nc == 2) ncon += collide_box_box(&K, con + ncon);
+    if (T->walls) ncon += collide_walls(&K, con + ncon);
     /* one contact per finger sphere against the cube it penetrates deepest (tie: cube 0), then the floor */
     for (int s = 0; s < NSPH; s++) {
         contact_t cand[2];
@@ -862,7 +907,7 @@ void orc_default_params(orc_params *p, int task) {
     p->task = task;
     p->action_mode = ORC_ACTION_JOINT;   /* reach:80 */
     p->reward_type = ORC_REWARD_SPARSE;  /* reach:81 */
-    p->block_gripper = (task == ORC_TASK_REACH || task == ORC_TASK_PUSH) ? 1 : 0; /* reach:82 push:84 lift:82 */
+    p->block_gripper = (task == ORC_TASK_REACH || task == ORC_TASK_PUSH || task == ORC_TASK_PUSH_LOOP) ? 1 : 0; /* reach:82 push:84 lift:82 loop:80 */
     p->distance_threshold = 0.05;        /* reach:83 */
     p->cube_xy_range = 0.3;              /* reach:84 */
     p->target_xy_range = 0.3;            /* push:87 */
@@ -881,7 +926,7 @@ int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }
 int orc_action_dim(const orc_params *p) { /* reach:95-96 */
     return (p->action_mode == ORC_ACTION_EE ? 3 : 5) + (p->block_gripper ? 0 : 1);
 }
-static int gripper_active(const orc_params *p) { return !(p->task == ORC_TASK_REACH || p->task == ORC_TASK_PUSH); }
+static int gripper_active(const orc_params *p) { return !(p->task == ORC_TASK_REACH || p->task == ORC_TASK_PUSH || p->task == ORC_TASK_PUSH_LOOP); }
 
 static float clip1(float a) { return a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a); } /* reach:234 */
 
@@ -948,6 +993,53 @@ void orc_reward(const orc_params *p, const double *a3, const double *b3, float *
     }
 }
 
+/* ---- PushCubeLoop reward (push_cube_loop_env.py:334-383), with numpy's scalar promotion rules (NEP 50) emulated:
+ * np.float32 (op) python-float -> float32 ; np.float32 (op) np.float64 -> float64 ; python min/max return one of their
+ * arguments unchanged (the first one on ties). */
+typedef struct { double v; int f32; } npnum;
+static npnum np32(float x) { npnum r = {(double)x, 1}; return r; }
+static npnum np64(double x) { npnum r = {x, 0}; return r; }
+static npnum np_bin(npnum a, npnum b, char op) {
+    npnum r;
+    r.f32 = a.f32 && b.f32;
+    if (r.f32) {
+        float x = (float)a.v, y = (float)b.v, z = op == '+' ? x + y : (op == '-' ? x - y : (op == '*' ? x * y : x / y));
+        r.v = (double)z;
+    } else r.v = op == '+' ? a.v + b.v : (op == '-' ? a.v - b.v : (op == '*' ? a.v * b.v : a.v / b.v));
+    return r;
+}
+static npnum np_min(npnum a, npnum b) { return b.v < a.v ? b : a; }
+static npnum np_max(npnum a, npnum b) { return b.v > a.v ? b : a; }
+void orc_loop_reward(const float *cube, int32_t *goal, double *overlap_out, double *reward, uint8_t *success) {
+    const double gh0 = 0.035 / 2 - 0.008, gh1 = 0.045 / 2 - 0.008; /* goal_region_high[:2] (:133-134) */
+    const double gl1 = gh1 * -1.0;
+    const double cx = *goal == 0 ? 0.06 : -0.06, cy = 0.135;
+    const float wc = (float)(0.015 / 2); /* cube_size as a weak python float next to a float32 scalar */
+    npnum xc = np32(cube[0]), yc = np32(cube[1]), w32 = np32(wc);
+    npnum zero = {0.0, 1}; /* python int 0: weakest type, keep f32-ness of the other operand */
+    npnum xo = np_max(zero, np_bin(np_min(np_bin(xc, w32, '+'), np64(cx + gh0)), np_max(np_bin(xc, w32, '-'), np64(cx - gh0)), '-'));
+    npnum yo = np_max(zero, np_bin(np_min(np_bin(yc, w32, '+'), np64(cy + gh1)), np_max(np_bin(yc, w32, '-'), np64(cy - gh1)), '-'));
+    /* python `max(0, v)` returns the int 0 when v <= 0: an exact zero of the weakest type */
+    if (!(xo.v > 0)) { xo.v = 0; xo.f32 = 1; }
+    if (!(yo.v > 0)) { yo.v = 0; yo.f32 = 1; }
+    npnum area = np_bin(xo, yo, '*');
+    const double cube_area = (0.015 / 2) * (0.015 / 2) * 4; /* python floats */
+    double overlap = area.f32 ? (double)((float)area.v / (float)cube_area) : area.v / cube_area;
+    if (xo.v == 0 || yo.v == 0) overlap = 0;
+    *overlap_out = overlap;
+    *success = 0;
+    if (overlap > 0.95) { *success = 1; *reward = 5; *goal = 1 - *goal; }
+    else if (overlap > 0.0) *reward = area.f32 ? (double)((float)overlap - 1.0f) : overlap - 1;
+    else {
+        double edge = gl1 + (*goal == 0 ? 0.135 : 0.135); /* goal_region_low[1] + centre y of the current goal (:352-356) */
+        double d = sqrt(((double)cube[1] - edge) * ((double)cube[1] - edge));
+        double r = (-d / 0.16) - 1;
+        if (r < -2) r = -2;
+        if (r > -1) r = -1;
+        *reward = r;
+    }
+}
+
 /* ---- numpy-compatible RNG ---- */
 typedef unsigned __int128 u128;
 #define PCG_MULT (((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL)
@@ -992,9 +1084,19 @@ double orc_rng_double(uint64_t rng[4]) {
 
 /* reset(): reach:297-311, push:308-328, pick_place:316-336, stack:307-324 */
 static void reset_one(const orc_params *P, const task_model *T, double *qpos, double *qvel, double *ee_lag, float *target,
-                      int32_t *elapsed, uint64_t *rng) {
+                      int32_t *elapsed, uint64_t *rng, int goal) {
     double lo[3] = {-P->cube_xy_range / 2, -P->cube_xy_range / 2, 0}, hi[3] = {P->cube_xy_range / 2, P->cube_xy_range / 2, 0};
     lo[1] += 0.165; hi[1] += 0.10; /* reach:138-139 */
+    if (P->task == ORC_TASK_PUSH_LOOP) { /* push_cube_loop_env.py:304-308, constants :130-135 from push_cube_loop.xml:38,41 */
+        double gh[3] = {0.035 / 2, 0.045 / 2, 0.007 / 2};
+        gh[0] -= 0.008; gh[1] -= 0.008;
+        double gl[3] = {gh[0] * -1.0, gh[1] * -1.0, gh[2] * 1.0};
+        double c1[2] = {0.06, 0.135}, c2[2] = {-0.06, 0.135};
+        for (int k = 0; k < 3; k++) lo[k] = gl[k], hi[k] = gh[k];
+        for (int k = 0; k < 3; k++) qpos[6 + k] = lo[k] + (hi[k] - lo[k]) * orc_rng_double(rng);
+        for (int k = 0; k < 2; k++) qpos[6 + k] += (1 - goal) * c1[k] + goal * c2[k];
+        qpos[9] = 1; qpos[10] = 0; qpos[11] = 0; qpos[12] = 0;
+    } else
     for (int c = 0; c < T->ncube; c++) {
         for (int k = 0; k < 3; k++) qpos[6 + 7 * c + k] = lo[k] + (hi[k] - lo[k]) * orc_rng_double(rng); /* np_random.uniform */
         qpos[6 + 7 * c + 3] = 1; qpos[6 + 7 * c + 4] = 0; qpos[6 + 7 * c + 5] = 0; qpos[6 + 7 * c + 6] = 0;
@@ -1029,7 +1131,7 @@ void orc_reset(const orc_params *p, orc_io *io, int n, const uint8_t *mask, cons
         if (mask && !mask[e]) continue;
         if (seeds) orc_rng_seed(seeds[e], io->rng + 4 * (size_t)e);
         reset_one(p, &T, io->qpos + (size_t)e * ORC_NQ_MAX, io->qvel + (size_t)e * ORC_NV_MAX, io->ee_lag + 3 * (size_t)e,
-                  io->target + 3 * (size_t)e, io->elapsed + e, io->rng + 4 * (size_t)e);
+                  io->target + 3 * (size_t)e, io->elapsed + e, io->rng + 4 * (size_t)e, io->goal ? io->goal[e] : 0);
         if (io->obs) write_obs(p, &T, io->qpos + (size_t)e * ORC_NQ_MAX, io->qvel + (size_t)e * ORC_NV_MAX, io->target + 3 * (size_t)e,
                                io->obs + 18 * (size_t)e);
     }
@@ -1070,6 +1172,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     for (int i = 0; i < nq; i++) qpos64[i] = (double)qpos[i];
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];
+    if (io->sim_time) io->sim_time[e] += P->n_substeps * H_STEP; /* data.time advances in mj_step only */
 
     /* ---- observation, reward, termination: reach:313-333 (+ lift:322-346 push:330-346 stack:326-348) */
     float *obs = io->obs + 18 * e;
@@ -1088,6 +1191,11 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     case ORC_TASK_PUSH: case ORC_TASK_PICK_PLACE:
         for (int i = 0; i < 3; i++) { a3[i] = cube[i]; b3[i] = (double)target[i]; }
         orc_reward(P, a3, b3, &r32, &r64, &succ); term = succ; break;
+    case ORC_TASK_PUSH_LOOP: { /* push_cube_loop_env.py:324-331: reward from the FRESH qpos cast to float32, never terminates */
+        float cpos[3] = {(float)qpos64[6], (float)qpos64[7], (float)qpos64[8]};
+        double ov;
+        orc_loop_reward(cpos, io->goal + e, &ov, &r64, &succ);
+        r32 = (float)r64; term = 0; break; }
     case ORC_TASK_STACK: /* stack:334-347 */
         for (int i = 0; i < 3; i++) { a3[i] = (double)lag.cube[1][i]; b3[i] = (double)lag.cube[0][i]; }
         b3[2] += 0.03;
@@ -1104,7 +1212,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     memcpy(io->term_obs + 18 * e, obs, sizeof(float) * 18);
     io->did_reset[e] = 0;
     if (diverged || (P->auto_reset && (term || trunc))) { /* SB3 DummyVecEnv.step_wait semantics (examples/gym_manipulation_sb3.py:34-39) */
-        reset_one(P, T, qpos64, qvel64, ee_lag, target, io->elapsed + e, io->rng + 4 * e);
+        reset_one(P, T, qpos64, qvel64, ee_lag, target, io->elapsed + e, io->rng + 4 * e, io->goal ? io->goal[e] : 0);
         if (diverged) for (int d = 0; d < ORC_NV_MAX; d++) qvel64[d] = 0;
         write_obs(P, T, qpos64, qvel64, target, obs);
         io->did_reset[e] = 1;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4}
+TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 NQ_MAX, NV_MAX = 20, 18
 
 
@@ -51,6 +51,8 @@ class OrcIO(ctypes.Structure):
         ("truncated", ctypes.c_void_p),
         ("is_success", ctypes.c_void_p),
         ("did_reset", ctypes.c_void_p),
+        ("goal", ctypes.c_void_p),
+        ("sim_time", ctypes.c_void_p),
     ]
 
 
@@ -118,10 +120,12 @@ class Oracle:
         self.truncated = np.zeros(n, np.uint8)
         self.is_success = np.zeros(n, np.uint8)
         self.did_reset = np.zeros(n, np.uint8)
+        self.goal = np.zeros(n, np.int32)
+        self.sim_time = np.zeros(n)
         self.io = OrcIO(
             _p(self.qpos), _p(self.qvel), _p(self.ee_lag), _p(self.target), _p(self.elapsed), _p(self.rng),
             _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.reward64), _p(self.terminated),
-            _p(self.truncated), _p(self.is_success), _p(self.did_reset),
+            _p(self.truncated), _p(self.is_success), _p(self.did_reset), _p(self.goal), _p(self.sim_time),
         )
 
     def reset(self, seeds=None, mask=None):
@@ -193,3 +197,11 @@ def rng_seed(seed):
 
 def rng_double(r):
     return lib().orc_rng_double(_p(r))
+
+
+def loop_reward(cube_xyz_f32, goal):
+    c = np.ascontiguousarray(cube_xyz_f32, np.float32)
+    g = ctypes.c_int32(int(goal))
+    ov, r, s = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint8()
+    lib().orc_loop_reward(_p(c), ctypes.byref(g), ctypes.byref(ov), ctypes.byref(r), ctypes.byref(s))
+    return ov.value, r.value, int(s.value), g.value

@@ -203,6 +203,59 @@ def main():
                 }
             )
 
+    # ---- PushCubeLoop-v0: overlap / reward / goal switching / reset sampling (push_cube_loop_env.py:299-383) -----
+    from gym_lowcostrobot.envs.push_cube_loop_env import PushCubeLoopEnv
+
+    def mk_loop():
+        env = PushCubeLoopEnv.__new__(PushCubeLoopEnv)
+        env.model = _FakeModel()
+        env.data = _FakeData(13)
+        env.num_dof = 6
+        env.observation_mode = "state"
+        # constants exactly as __init__ derives them (push_cube_loop_env.py:124-135) from push_cube_loop.xml:38,41
+        env.cube_size = 0.015 / 2
+        env.cube_position = np.array([0.0, 0.0, 0.0])
+        env.goal_region_1_center = np.array([0.06, 0.135, 0.01])
+        env.goal_region_2_center = np.array([-0.06, 0.135, 0.01])
+        env.goal_region_high = np.array([0.035, 0.045, 0.007]) / 2
+        env.goal_region_high[:2] -= 0.008
+        env.goal_region_low = env.goal_region_high * np.array([-1.0, -1.0, 1.0])
+        env.current_goal = 0
+        env._step = 0
+        return env
+
+    out["loop_consts"] = {}
+    env = mk_loop()
+    out["loop_consts"] = {"goal_region_high": env.goal_region_high.tolist(), "goal_region_low": env.goal_region_low.tolist(),
+                          "cube_size": env.cube_size}
+    out["loop_rewards"] = []
+    pts = [(0.06, 0.135), (-0.06, 0.135), (0.0605, 0.1353), (0.066, 0.14), (0.07, 0.135), (0.0, 0.135), (0.05, 0.12),
+           (0.0772, 0.135), (0.06, 0.1571), (0.06, 0.1121), (-0.0612, 0.1344), (0.1, 0.165)]
+    for _ in range(20):
+        pts.append((float(rng.uniform(-0.11, 0.11)), float(rng.uniform(0.10, 0.17))))
+    for goal in (0, 1):
+        for (x, y) in pts:
+            env = mk_loop()
+            env.current_goal = goal
+            env.data.qpos[6:9] = [x, y, 0.015]
+            env.cube_position = env.data.qpos[6:9].astype(np.float32).copy()  # what get_reward() does first (:336)
+            overlap = float(env.get_cube_overlap())
+            reward, success = env.get_reward()
+            out["loop_rewards"].append({"goal": goal, "cube": [x, y, 0.015], "reward": float(reward), "success": int(success),
+                                        "goal_after": int(env.current_goal), "overlap": overlap})
+    out["loop_resets"] = []
+    for seed in (0, 1, 42):
+        for goal in (0, 1):
+            env = mk_loop()
+            env.current_goal = goal
+            seq = []
+            obs, info = env.reset(seed=seed)
+            seq.append({"qpos": env.data.qpos.tolist(), "info": info})
+            for _ in range(2):
+                obs, info = env.reset()
+                seq.append({"qpos": env.data.qpos.tolist(), "info": info})
+            out["loop_resets"].append({"seed": seed, "goal": goal, "sequence": seq})
+
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "glue_golden.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)

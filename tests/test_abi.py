@@ -37,9 +37,9 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.max_episode_steps == 50                        # gym_lowcostrobot/__init__.py:12
         assert cfg.impratio == 100.0
         k = hip_lib.lcr_action_dim(ctypes.byref(cfg))
-        assert k == (5 if task in ("reach", "push") else 6)       # block_gripper defaults reach:82 / lift:82
+        assert k == (5 if task in ("reach", "push", "push_loop") else 6)  # block_gripper defaults reach:82 / lift:82
         cfg.action_mode = _capi.ACTION_MODES["ee"]
-        assert hip_lib.lcr_action_dim(ctypes.byref(cfg)) == (3 if task in ("reach", "push") else 4)
+        assert hip_lib.lcr_action_dim(ctypes.byref(cfg)) == (3 if task in ("reach", "push", "push_loop") else 4)
         assert hip_lib.lcr_nq(tid) == (20 if task == "stack" else 13)
         assert hip_lib.lcr_nv(tid) == (18 if task == "stack" else 12)
 

@@ -8,11 +8,11 @@ import gym_lowcostrobot
 import gym_lowcostrobot.envs as ref_path
 from gym_lowcostrobot_amd import envs, spaces
 
-ENV_IDS = ["LiftCube-v0", "PickPlaceCube-v0", "PushCube-v0", "ReachCube-v0", "StackTwoCubes-v0"]
+ENV_IDS = ["LiftCube-v0", "PickPlaceCube-v0", "PushCube-v0", "ReachCube-v0", "StackTwoCubes-v0", "PushCubeLoop-v0"]
 
 
 def test_registry_table_matches_reference_ids():
-    assert sorted(envs.REGISTRY) == sorted(ENV_IDS)          # gym_lowcostrobot/__init__.py:9-43 minus PushCubeLoop
+    assert sorted(envs.REGISTRY) == sorted(ENV_IDS)          # all six ids of gym_lowcostrobot/__init__.py:9-43
     assert envs.MAX_EPISODE_STEPS == 50
     for cls in envs.REGISTRY.values():
         assert getattr(ref_path, cls) is getattr(envs, cls)   # `gym_lowcostrobot.envs:<Class>` entry points resolve
@@ -46,7 +46,7 @@ def test_env_checker_contract(hip_lib, env_id, observation_mode):
     env = cls(observation_mode=observation_mode)
     try:
         obs, info = env.reset(seed=123)
-        assert info == {}
+        assert info == ({"timestamp": 0.0} if env_id == "PushCubeLoop-v0" else {})
         assert set(obs) == set(env.observation_space.keys())
         for k, v in obs.items():
             assert env.observation_space[k].contains(v), (k, v.dtype, v.shape)
@@ -65,7 +65,10 @@ def test_env_checker_contract(hip_lib, env_id, observation_mode):
             for k, v in o.items():
                 assert env.observation_space[k].contains(v), (k, v)
             assert trunc is False
-            if env_id == "LiftCube-v0":
+            if env_id == "PushCubeLoop-v0":
+                assert isinstance(r, float) and term is False and set(info) == {"timestamp", "success"}
+                assert -2.0 <= r <= 5.0 and info["timestamp"] > 0
+            elif env_id == "LiftCube-v0":
                 assert isinstance(r, np.float64) and term is False and info == {}
             else:
                 assert isinstance(r, np.float32) and isinstance(term, (bool, np.bool_)) and "is_success" in info
@@ -78,7 +81,8 @@ def test_env_checker_contract(hip_lib, env_id, observation_mode):
 
 @pytest.mark.gpu
 def test_action_dims_follow_reference_rule(hip_lib):
-    for cls, joint_k in [(envs.ReachCubeEnv, 5), (envs.PushCubeEnv, 5), (envs.LiftCubeEnv, 6), (envs.PickPlaceCubeEnv, 6), (envs.StackTwoCubesEnv, 6)]:
+    for cls, joint_k in [(envs.ReachCubeEnv, 5), (envs.PushCubeEnv, 5), (envs.PushCubeLoopEnv, 5), (envs.LiftCubeEnv, 6), (envs.PickPlaceCubeEnv, 6),
+                         (envs.StackTwoCubesEnv, 6)]:
         e = cls(observation_mode="state")
         assert e.action_space.shape == (joint_k,)
         e.close()

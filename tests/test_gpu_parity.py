@@ -289,3 +289,42 @@ def test_divergence_guard(hip_lib):
     assert np.all(out["reward"][bad] == -1.0) and not out["terminated"][bad].any()
     np.testing.assert_array_equal(st["qpos"][bad, 6:9].astype(np.float32), o.qpos[bad, 6:9].astype(np.float32))
     sim.close()
+
+
+def test_push_loop_parity(hip_lib):
+    """PushCubeLoop-v0: rails (wall contacts), overlap reward, goal switching, accumulated timestamp"""
+    rng = np.random.default_rng(41)
+    n = 512
+    sim, o = util.make_pair("push_loop", n, auto_reset=False, max_episode_steps=0)
+    seeds = np.arange(n, dtype=np.uint64) + 5
+    o.goal[:] = rng.integers(0, 2, n)
+    util.push_state(sim, o)
+    o.reset(seeds=seeds); sim.reset(seeds=seeds)
+    st = util.pull_state(sim)
+    np.testing.assert_array_equal(st["qpos"][:, :13].astype(np.float32), o.qpos[:, :13].astype(np.float32))  # goal-centred sampling
+    # cubes thrown at the rails and corners, some parked in their goal region
+    o.qpos[:, 6] = rng.uniform(-0.1, 0.1, n); o.qpos[:, 7] = rng.uniform(0.115, 0.155, n); o.qpos[:, 8] = 0.0149
+    o.qvel[:, 6:8] = rng.normal(0, 1.2, (n, 2))
+    park = rng.uniform(size=n) < 0.2
+    o.qpos[park, 6] = np.where(o.goal[park] == 0, 0.06, -0.06) + rng.uniform(-0.003, 0.003, park.sum())
+    o.qpos[park, 7] = 0.135 + rng.uniform(-0.004, 0.004, park.sum())
+    o.qvel[park, 6:8] = 0
+    total_success = 0
+    for t in range(6):
+        util.sync_oracle_to_f32(o); util.push_state(sim, o)
+        a = (0.3 * rng.uniform(-1, 1, (n, 5))).astype(np.float32)
+        o.step(a, threads=0); sim.step(a)
+        st = util.pull_state(sim); out = sim.outputs()
+        dq = np.abs(st["qpos"] - o.qpos[:, :13]).max(axis=1); dv = np.abs(st["qvel"] - o.qvel[:, :12]).max(axis=1)
+        assert ((dq <= 2e-5) & (dv <= 4e-3)).mean() >= 0.98, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
+        same = out["is_success"] == o.is_success.astype(bool)
+        assert same.mean() > 0.995
+        np.testing.assert_array_equal(st["current_goal"][same], o.goal[same])
+        assert np.abs(out["reward"] - o.reward)[same].max() < 2e-4       # fp32 overlap arithmetic vs numpy's mixed precision
+        assert not out["terminated"].any()
+        np.testing.assert_allclose(sim.timestamp.numpy(), o.sim_time, atol=1e-12)
+        total_success += int(o.is_success.sum())
+        o.goal[:] = st["current_goal"]
+    assert total_success > 20
+    rows, cons, _ = o.diag()
+    sim.close()

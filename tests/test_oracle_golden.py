@@ -312,3 +312,41 @@ def test_pinch_grasp_holds_the_cube():
         a = np.zeros((1, 6), np.float32); a[0, 5] = 0.2
         h.step(a)
     assert h.qpos[0, 8] < 0.05                                              # 98 N of weight vs 10 N m actuators
+
+
+# ---------------------------------------------------------------- PushCubeLoop-v0 glue (push_cube_loop_env.py:299-383)
+@pytest.mark.parametrize("rec", GOLD["loop_rewards"], ids=lambda r: f"goal{r['goal']}")
+def test_loop_reward_golden(rec):
+    ov, rew, succ, goal_after = orc.loop_reward(np.array(rec["cube"], np.float32), rec["goal"])
+    assert ov == pytest.approx(rec["overlap"], abs=1e-15)
+    assert rew == pytest.approx(rec["reward"], abs=1e-15)
+    assert succ == rec["success"] and goal_after == rec["goal_after"]
+
+
+@pytest.mark.parametrize("rec", GOLD["loop_resets"], ids=lambda r: f"seed{r['seed']}-goal{r['goal']}")
+def test_loop_reset_golden(rec):
+    o = orc.Oracle("push_loop", 1)
+    o.goal[0] = rec["goal"]
+    for i, st in enumerate(rec["sequence"]):
+        o.reset(seeds=[rec["seed"]]) if i == 0 else o.reset()
+        np.testing.assert_array_equal(o.qpos[0, :13], np.array(st["qpos"]))
+        assert o.goal[0] == rec["goal"]           # reset never changes the goal side
+    assert GOLD["loop_consts"]["goal_region_high"] == [0.035 / 2 - 0.008, 0.045 / 2 - 0.008, 0.007 / 2]
+
+
+def test_loop_rails_and_goal_switch():
+    o = orc.Oracle("push_loop", 2, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[0, 1])
+    o.qpos[:, 6:9] = [[0.09, 0.135, 0.0149], [0.09, 0.16, 0.0149]]
+    o.qvel[:] = 0
+    o.qvel[:, 6:8] = [[2.0, 0.0], [2.0, 2.0]]           # thrown at the right rail / the corner
+    for _ in range(15):
+        o.step(np.zeros((2, 5), np.float32))
+    assert np.all(o.qpos[:, 6] < 0.102) and np.all(o.qpos[:, 7] < 0.157)     # pushed back inside the rails (soft contact)
+    assert o.sim_time[0] == pytest.approx(15 * 20 * 0.002)
+    # a cube resting inside goal region 1 -> success, +5, goal side flips and stays flipped through a reset
+    o.qpos[0, 6:9] = [0.06, 0.135, 0.0149]; o.qvel[:] = 0
+    o.step(np.zeros((2, 5), np.float32))
+    assert o.is_success[0] == 1 and o.reward64[0] == 5 and o.goal[0] == 1 and o.terminated[0] == 0
+    o.reset()
+    assert o.goal[0] == 1 and o.qpos[0, 6] < 0

@@ -25,6 +25,8 @@ def push_state(sim, o):
         target=np.ascontiguousarray(o.target.T),
         elapsed=o.elapsed.copy(),
         rng=np.ascontiguousarray(o.rng.T),
+        current_goal=o.goal.copy(),
+        sim_time=o.sim_time.copy(),
     )
 
 
