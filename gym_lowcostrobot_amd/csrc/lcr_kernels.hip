@@ -701,7 +701,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     }
 
     // ---- collision: PushCubeLoop rails.  The four wall boxes act as their inner faces (vertical half-spaces below the wall
-    //      top); cube vertices beyond a face, in wall order (left, right, top, bottom) x vertex order, first 4 kept. ----
+    //      top); per wall (left, right, top, bottom) the two deepest cube vertices beyond its face, at most 4 in total. ----
     FloorSlot WS[4];   // same record as a floor slot; the frame depends on the wall
     int wall_id[4] = {0, 0, 0, 0};
     bool wall_any = false;
@@ -726,23 +726,42 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             float wdist[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; w++) {
+                // the two deepest vertices beyond this face (ties: lower vertex index first)
+                float d1 = 0.f, d2 = 0.f;
+                bool h1 = false, h2 = false;
+                f3 r1 = mk(0.f, 0.f, 0.f), r2 = mk(0.f, 0.f, 0.f);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const f3 p = vw[i] + S.cp[0];
                     const float dist = w == 0 ? p.x + WALL_X : (w == 1 ? WALL_X - p.x : (w == 2 ? p.y - WALL_Y0 : WALL_Y1 - p.y));
-                    const bool pen = dist < 0.f && p.z < WALL_TOP && cnt < 4;
-                    const float nx = w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), ny = w == 2 ? 1.f : (w == 3 ? -1.f : 0.f);
+                    const bool pen = dist < 0.f && p.z < WALL_TOP;
+                    const bool first = pen && (!h1 || dist < d1);
+                    const bool second = pen && !first && (!h2 || dist < d2);
+                    // demote the current best when a deeper one arrives
+                    d2 = first ? d1 : (second ? dist : d2);
+                    r2 = first ? r1 : (second ? vw[i] : r2);
+                    h2 = first ? h1 : (second ? true : h2);
+                    d1 = first ? dist : d1;
+                    r1 = first ? vw[i] : r1;
+                    h1 = h1 || first;
+                }
+                const float nx = w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), ny = w == 2 ? 1.f : (w == 3 ? -1.f : 0.f);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const bool have = (c == 0 ? h1 : h2) && cnt < 4;
+                    const float dist = c == 0 ? d1 : d2;
+                    const f3 rv = c == 0 ? r1 : r2;
 #pragma unroll
                     for (int s = 0; s < 4; s++) {
-                        const bool take = pen && cnt == s;
-                        WS[s].r.x = take ? vw[i].x - 0.5f * dist * nx : WS[s].r.x;
-                        WS[s].r.y = take ? vw[i].y - 0.5f * dist * ny : WS[s].r.y;
-                        WS[s].r.z = take ? vw[i].z : WS[s].r.z;
+                        const bool take = have && cnt == s;
+                        WS[s].r.x = take ? rv.x - 0.5f * dist * nx : WS[s].r.x;
+                        WS[s].r.y = take ? rv.y - 0.5f * dist * ny : WS[s].r.y;
+                        WS[s].r.z = take ? rv.z : WS[s].r.z;
                         wdist[s] = take ? dist : wdist[s];
                         wall_id[s] = take ? w : wall_id[s];
                         WS[s].act = WS[s].act || take;
                     }
-                    cnt += pen ? 1 : 0;
+                    cnt += have ? 1 : 0;
                 }
             }
 #pragma unroll

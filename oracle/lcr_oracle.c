@@ -470,24 +470,38 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
 }
 /* (D7) PushCubeLoop rails (push_cube_loop.xml:44-47): the four wall boxes are restated as their inner faces -- vertical
  * half-spaces that only act below the wall top (z < 0.012).  Cube vertices beyond a face (in wall order left, right,
- * top, bottom; vertex order 0..7) give contacts, at most 4 in total; frame normal points from the wall into the pen. */
+ * top, bottom) give contacts: the two deepest per wall, at most 4 in total (so that a corner keeps both walls);
+ * frame normal points from the wall into the pen. */
 static int collide_walls(const kin_t *K, contact_t *out) {
     int n = 0;
-    for (int w = 0; w < 4 && n < 4; w++) {
+    real P[8][3];
+    for (int i = 0; i < 8; i++) {
+        real v[3] = {(i & 1) ? (real)CUBE_HALF : (real)-CUBE_HALF, (i & 2) ? (real)CUBE_HALF : (real)-CUBE_HALF,
+                     (i & 4) ? (real)CUBE_HALF : (real)-CUBE_HALF};
+        m3v(P[i], K->cR[0], v);
+        v3add(P[i], P[i], K->cp[0]);
+    }
+    for (int w = 0; w < 4; w++) {
         real nw[3] = {0, 0, 0};
         if (w == 0) nw[0] = 1; else if (w == 1) nw[0] = -1; else if (w == 2) nw[1] = 1; else nw[1] = -1;
-        for (int i = 0; i < 8 && n < 4; i++) {
-            real v[3] = {(i & 1) ? (real)CUBE_HALF : (real)-CUBE_HALF, (i & 2) ? (real)CUBE_HALF : (real)-CUBE_HALF,
-                         (i & 4) ? (real)CUBE_HALF : (real)-CUBE_HALF}, p[3];
-            m3v(p, K->cR[0], v);
-            v3add(p, p, K->cp[0]);
+        /* the two deepest vertices beyond this face (ties: lower vertex index first) */
+        real d1 = 0, d2 = 0; int i1 = -1, i2 = -1;
+        for (int i = 0; i < 8; i++) {
+            const real *p = P[i];
             real dist = w == 0 ? p[0] + (real)WALL_X : (w == 1 ? (real)WALL_X - p[0] : (w == 2 ? p[1] - (real)WALL_Y0 : (real)WALL_Y1 - p[1]));
             if (!(dist < 0) || !(p[2] < (real)WALL_TOP)) continue;
+            if (i1 < 0 || dist < d1) { d2 = d1; i2 = i1; d1 = dist; i1 = i; }
+            else if (i2 < 0 || dist < d2) { d2 = dist; i2 = i; }
+        }
+        for (int c = 0; c < 2 && n < 4; c++) {
+            int i = c == 0 ? i1 : i2;
+            real dist = c == 0 ? d1 : d2;
+            if (i < 0) continue;
             contact_t *ct = &out[n];
             ct->slot = 8 + n;
             n++;
             ct->b1 = -1; ct->b2 = 6; ct->dist = dist;
-            v3set(ct->pos, p[0] - nw[0] * dist * (real)0.5, p[1] - nw[1] * dist * (real)0.5, p[2]);
+            v3set(ct->pos, P[i][0] - nw[0] * dist * (real)0.5, P[i][1] - nw[1] * dist * (real)0.5, P[i][2]);
             make_frame(ct->frame, nw);
             ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT;
         }

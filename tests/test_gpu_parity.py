@@ -320,7 +320,8 @@ def test_push_loop_parity(hip_lib):
         same = out["is_success"] == o.is_success.astype(bool)
         assert same.mean() > 0.995
         np.testing.assert_array_equal(st["current_goal"][same], o.goal[same])
-        assert np.abs(out["reward"] - o.reward)[same].max() < 2e-4       # fp32 overlap arithmetic vs numpy's mixed precision
+        # reward = overlap - 1 with d(overlap)/d(position) up to ~70 / m: scale the bound with the state difference
+        assert np.all(np.abs(out["reward"] - o.reward)[same] <= 200.0 * dq[same] + 2e-5)
         assert not out["terminated"].any()
         np.testing.assert_allclose(sim.timestamp.numpy(), o.sim_time, atol=1e-12)
         total_success += int(o.is_success.sum())
