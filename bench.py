@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="ReachCube-v0", choices=sorted(WORKLOADS))
     ap.add_argument("--pgs-iters", type=int, default=4)
-    ap.add_argument("--obs", default="state", choices=["state", "both"], help="both: also write the 2x240x320x3 image stub per env")
+    ap.add_argument("--obs", default="state", choices=["state", "both"], help="both: also ray-cast the two 240x320x3 observation frames per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for a single rank (tests the N>1 code path on one GPU)")
     ap.add_argument("--calibrate", type=int, default=0, help="after timing, launch the known-byte-count copy kernel this many times (PMC calibration)")
@@ -107,7 +107,7 @@ def main():
 
     task, action_mode, alg_bytes = WORKLOADS[args.workload]
     if args.obs == "both":
-        alg_bytes += 2 * 240 * 320 * 3  # image stub: write-once frames
+        alg_bytes += 2 * 240 * 320 * 3  # write-once frames
     n = args.envs_per_gpu
     sim = VecSim(task, n, device=local_rank, env_id_offset=sharding.shard_offset(n, rank), observation_mode=args.obs, action_mode=action_mode,
                  pgs_iters=args.pgs_iters, base_seed=0)
@@ -185,7 +185,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "lcr_step_kernel" if args.obs == "state" else "lcr_step_kernel + lcr_image_stub_kernel",
+                "kernel": "lcr_step_kernel" if args.obs == "state" else "lcr_step_kernel + lcr_render_obs_kernel",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_env_step": alg_bytes,
                 "note": "state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick",

@@ -2,6 +2,7 @@
 // No simulation arithmetic lives here (that is lcr_kernels.hip) and there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,41 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 }  // namespace
 
+namespace {
+void cam_finish(LcrCam &c, const double p[3], double X[3], double Y[3], int height) {
+    auto nrm = [](double *v) { double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= n; v[1] /= n; v[2] /= n; };
+    nrm(X);
+    double d = X[0] * Y[0] + X[1] * Y[1] + X[2] * Y[2];
+    for (int i = 0; i < 3; i++) Y[i] -= d * X[i];
+    nrm(Y);
+    double Z[3] = {X[1] * Y[2] - X[2] * Y[1], X[2] * Y[0] - X[0] * Y[2], X[0] * Y[1] - X[1] * Y[0]};
+    c.px = (float)p[0]; c.py = (float)p[1]; c.pz = (float)p[2];
+    c.xx = (float)X[0]; c.xy = (float)X[1]; c.xz = (float)X[2];
+    c.yx = (float)Y[0]; c.yy = (float)Y[1]; c.yz = (float)Y[2];
+    c.zx = (float)Z[0]; c.zy = (float)Z[1]; c.zz = (float)Z[2];
+    c.s = (float)(2.0 * std::tan(0.5 * 45.0 * M_PI / 180.0) / height);  // MuJoCo default camera fovy = 45 deg
+}
+// cameras of the scene files (reach_cube.xml:29-31 and siblings)
+void make_cameras(int task, LcrCam &front, LcrCam &top, LcrCam &vizu) {
+    {   // camera_front pos="0.049 0.5 0.225" xyaxes="-0.998 0.056 -0.000 -0.019 -0.335 0.942"
+        double p[3] = {0.049, 0.5, 0.225}, X[3] = {-0.998, 0.056, -0.000}, Y[3] = {-0.019, -0.335, 0.942};
+        cam_finish(front, p, X, Y, LCR_IMG_H);
+    }
+    {   // camera_top pos="0 0.1 0.6" euler="0 0 0"
+        double p[3] = {0, 0.1, 0.6}, X[3] = {1, 0, 0}, Y[3] = {0, 1, 0};
+        cam_finish(top, p, X, Y, LCR_IMG_H);
+    }
+    {   // camera_vizu pos="-0.2 0.6 0.3" (reach) / "-0.1 0.6 0.3" (others) quat="-0.15 -0.1 0.6 1"
+        double p[3] = {task == LCR_TASK_REACH ? -0.2 : -0.1, 0.6, 0.3};
+        double q[4] = {-0.15, -0.1, 0.6, 1.0}, n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+        double X[3] = {1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)};
+        double Y[3] = {2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)};
+        cam_finish(vizu, p, X, Y, 640);
+    }
+}
+}  // namespace
+
 struct lcr_sim {
     lcr_config cfg;
     LcrDev dev;
@@ -42,6 +78,9 @@ struct lcr_sim {
     unsigned long long *seeds_dev; // [N]
     hipEvent_t ev0, ev1;
     bool has_images;
+    LcrCam cam_front, cam_top, cam_vizu;
+    unsigned char *render_dev;  // scratch frame for lcr_render
+    size_t render_bytes;
 };
 
 extern "C" {
@@ -227,6 +266,9 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.term_obs = (float *)(base + o_tobs);
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
+    make_cameras(cfg->task, s->cam_front, s->cam_top, s->cam_vizu);
+    s->render_dev = nullptr;
+    s->render_bytes = 0;
     s->action_stage = (float *)(base + o_act);
     s->mask_dev = (unsigned char *)(base + o_mask);
     s->seeds_dev = (unsigned long long *)(base + o_seeds);
@@ -237,7 +279,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     // initial state: reset of seed (base_seed + global env id) for every env
     int rc = lcr_launch_reset(D, nullptr, nullptr, 1, cfg->base_seed, s->stream);
     if (rc) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); }
-    if (s->has_images) lcr_launch_image_stub(D, s->stream);
+    if (s->has_images) lcr_launch_render_obs(D, s->cam_front, s->cam_top, s->stream);
     e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e)); }
     *out = s;
@@ -250,6 +292,7 @@ void lcr_destroy(lcr_sim *s) {
     (void)hipStreamSynchronize(s->stream);
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
+    if (s->render_dev) (void)hipFree(s->render_dev);
     (void)hipFree(s->arena);
     delete s;
 }
@@ -277,7 +320,7 @@ int lcr_reset(lcr_sim *s, const uint8_t *mask_host, const uint64_t *seeds_host) 
     if (seeds_host) HIPCHK(hipMemcpyAsync(s->seeds_dev, seeds_host, N * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
     int rc = lcr_launch_reset(s->dev, mask_host ? s->mask_dev : nullptr, seeds_host ? s->seeds_dev : nullptr, 0, 0, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (s->has_images) lcr_launch_image_stub(s->dev, s->stream);
+    if (s->has_images) lcr_launch_render_obs(s->dev, s->cam_front, s->cam_top, s->stream);
     // the staging copies above read caller memory: do not return before they are consumed
     if (mask_host || seeds_host) HIPCHK(hipStreamSynchronize(s->stream));
     return LCR_OK;
@@ -289,8 +332,8 @@ int lcr_step(lcr_sim *s, const float *action_dev) {
     int rc = lcr_launch_step(s->dev, action_dev, s->ee_mode, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (s->has_images) {
-        rc = lcr_launch_image_stub(s->dev, s->stream);
-        if (rc) return fail(LCR_ERR_HIP, "image stub launch failed: %s", hipGetErrorString((hipError_t)rc));
+        rc = lcr_launch_render_obs(s->dev, s->cam_front, s->cam_top, s->stream);
+        if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
     return LCR_OK;
 }
@@ -422,6 +465,29 @@ int lcr_fill_random_actions(lcr_sim *s, float *action_dev, uint64_t seed, uint64
     if (!action_dev) return fail(LCR_ERR_INVALID, "action is NULL");
     int rc = lcr_launch_fill_actions(action_dev, s->dev.n, s->k, s->dev.env_off, seed, step, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "fill kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return LCR_OK;
+}
+
+int lcr_render(lcr_sim *s, int env, int camera, int width, int height, uint8_t *rgb_host) {
+    SIMCHK(s);
+    if (!rgb_host) return fail(LCR_ERR_INVALID, "rgb_host is NULL");
+    if (env < 0 || env >= s->dev.n) return fail(LCR_ERR_INVALID, "env %d out of range", env);
+    if (camera < 0 || camera > 2) return fail(LCR_ERR_INVALID, "camera must be 0 (front), 1 (top) or 2 (vizu)");
+    if (width <= 0 || height <= 0 || (size_t)width * height > ((size_t)1 << 26)) return fail(LCR_ERR_INVALID, "bad frame size");
+    LcrCam cam = camera == 0 ? s->cam_front : (camera == 1 ? s->cam_top : s->cam_vizu);
+    cam.s = (float)(2.0 * std::tan(0.5 * 45.0 * M_PI / 180.0) / height);
+    const size_t bytes = (size_t)width * height * 3;
+    if (bytes > s->render_bytes) {
+        if (s->render_dev) (void)hipFree(s->render_dev);
+        s->render_dev = nullptr; s->render_bytes = 0;
+        hipError_t e = hipMalloc((void **)&s->render_dev, bytes);
+        if (e != hipSuccess) return fail(LCR_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        s->render_bytes = bytes;
+    }
+    int rc = lcr_launch_render_single(s->dev, cam, env, width, height, s->render_dev, s->stream);
+    if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(rgb_host, s->render_dev, bytes, hipMemcpyDeviceToHost));
     return LCR_OK;
 }
 

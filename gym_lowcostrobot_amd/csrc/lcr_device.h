@@ -43,15 +43,23 @@ struct LcrDev {
     float *reward;
     unsigned char *terminated, *truncated, *is_success, *did_reset;
     float *term_obs;  // [18][n]
-    // image stub
+    // image observations
     unsigned char *img_front, *img_top;  // [n][240][320][3] or null
 };
 
-// launchers implemented in lcr_kernels.hip (plain C++ linkage, same shared object)
+// pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height
+struct LcrCam {
+    float px, py, pz;
+    float xx, xy, xz, yx, yy, yz, zx, zy, zz;
+    float s;
+};
+
+// launchers implemented in lcr_kernels.hip / lcr_render.hip (plain C++ linkage, same shared object)
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
 int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,
                      unsigned long long base_seed, void *stream);
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,
                             unsigned long long step, void *stream);
-int lcr_launch_image_stub(const LcrDev &P, void *stream);
+int lcr_launch_render_obs(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream);
+int lcr_launch_render_single(const LcrDev &P, const LcrCam &cam, int env, int W, int H, unsigned char *out_dev, void *stream);
 int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream);

@@ -21,10 +21,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lcr_arm.h"
 #include "lcr_device.h"
 #include "lcr_model_gen.h"
 
-#define DEV __device__ __forceinline__
+using namespace lcrdev;
 
 namespace {
 
@@ -55,37 +56,6 @@ constexpr float RT_FF = (MU_FINGER * MU_FINGER) / (MU_TORS * MU_TORS);
 constexpr float WALL_X = 0.115f, WALL_Y0 = 0.10f, WALL_Y1 = 0.17f, WALL_TOP = 0.012f;
 constexpr float INVW_DOF[6] = {lcrm::INVW_DOF1, lcrm::INVW_DOF2, lcrm::INVW_DOF3, lcrm::INVW_DOF4, lcrm::INVW_DOF5, lcrm::INVW_DOF6};
 
-struct f3 { float x, y, z; };
-DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
-DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
-DEV float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
-DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DEV f3 axpy(float s, f3 a, f3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }  // s*a+b
-DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-// NaN / inf / |x| >= 2^34 (~1.7e10, MuJoCo's mjMAXVAL is 1e10) by exponent bits: immune to -ffast-math
-DEV bool bad_value(float x) { return ((__float_as_uint(x) >> 23) & 0xffu) >= 127u + 34u; }
-
-// sin/cos for |x| <~ 4 (joint angles are range-limited, follower.xml:58-95): quadrant reduction with a two-term pi/2 and
-// the classic single-precision minimax polynomials on [-pi/4, pi/4]; max abs error 8.5e-8 on [-3.3, 3.3], ~30
-// instructions instead of libm sincosf's ~150 (which carries a large-argument path this kernel can never take).
-DEV void sincos_small(float x, float *sp_out, float *cp_out) {
-    const float k = rintf(x * 0.636619772f);
-    float r = fmaf(k, -1.57079637f, x);
-    r = fmaf(k, 4.37113883e-8f, r);
-    const float r2 = r * r;
-    const float sp = fmaf(fmaf(fmaf(-1.9515296e-4f, r2, 8.3321609e-3f), r2, -1.6666655e-1f), r2 * r, r);
-    const float cp = fmaf(fmaf(fmaf(2.4433157e-5f, r2, -1.3887316e-3f), r2, 4.1666646e-2f), r2 * r2, fmaf(-0.5f, r2, 1.0f));
-    const int q = (int)k;
-    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
-    *sp_out = (q & 2) ? -ss : ss;
-    *cp_out = ((q + 1) & 2) ? -cc : cc;
-}
-
 // MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi())
 DEV float impedance(float dist, float d0, float dw, float inv_width) {
     float x = fminf(fabsf(dist) * inv_width, 1.0f);
@@ -102,70 +72,6 @@ DEV void make_frame(f3 n, f3 &t1, f3 &t2) {
     t1 = il * y;
     t2 = cross(n, t1);
 }
-
-// ------------------------------------------------------------------------------------------------
-// arm kinematics: world frames of link_1..link_6 (base quat of follower.xml:51 folded in)
-// ------------------------------------------------------------------------------------------------
-struct ArmFrames {
-    f3 X[6], Y[6], Z[6], p[6];
-};
-
-DEV void arm_frames(const float (&q)[6], ArmFrames &F) {
-    using namespace lcrm;
-    float s, c;
-    // base_link: Rz(-90deg): X0=(0,-1,0) Y0=(1,0,0) Z0=(0,0,1)
-    const f3 X0 = mk(0.f, -1.f, 0.f), Y0 = mk(1.f, 0.f, 0.f), Z0 = mk(0.f, 0.f, 1.f);
-    // link_1: pos (P1x,0,P1z), axis -z
-    F.p[0] = axpy(P1x, X0, P1z * Z0);
-    sincos_small(q[0], &s, &c);
-    F.X[0] = axpy(c, X0, (-s) * Y0);
-    F.Y[0] = axpy(s, X0, c * Y0);
-    F.Z[0] = Z0;
-    // link_2: pos (0,P2y,P2z), axis +y
-    F.p[1] = axpy(P2y, F.Y[0], axpy(P2z, F.Z[0], F.p[0]));
-    sincos_small(q[1], &s, &c);
-    F.X[1] = axpy(c, F.X[0], (-s) * F.Z[0]);
-    F.Z[1] = axpy(s, F.X[0], c * F.Z[0]);
-    F.Y[1] = F.Y[0];
-    // link_3: axis -y
-    F.p[2] = axpy(P3x, F.X[1], axpy(P3y, F.Y[1], axpy(P3z, F.Z[1], F.p[1])));
-    sincos_small(q[2], &s, &c);
-    F.X[2] = axpy(c, F.X[1], s * F.Z[1]);
-    F.Z[2] = axpy(-s, F.X[1], c * F.Z[1]);
-    F.Y[2] = F.Y[1];
-    // link_4: axis +y
-    F.p[3] = axpy(P4x, F.X[2], axpy(P4y, F.Y[2], axpy(P4z, F.Z[2], F.p[2])));
-    sincos_small(q[3], &s, &c);
-    F.X[3] = axpy(c, F.X[2], (-s) * F.Z[2]);
-    F.Z[3] = axpy(s, F.X[2], c * F.Z[2]);
-    F.Y[3] = F.Y[2];
-    // link_5: pos (P5x,P5y,0), axis +x
-    F.p[4] = axpy(P5x, F.X[3], axpy(P5y, F.Y[3], F.p[3]));
-    sincos_small(q[4], &s, &c);
-    F.Y[4] = axpy(c, F.Y[3], s * F.Z[3]);
-    F.Z[4] = axpy(-s, F.Y[3], c * F.Z[3]);
-    F.X[4] = F.X[3];
-    // link_6: axis -z
-    F.p[5] = axpy(P6x, F.X[4], axpy(P6y, F.Y[4], axpy(P6z, F.Z[4], F.p[4])));
-    sincos_small(q[5], &s, &c);
-    F.X[5] = axpy(c, F.X[4], (-s) * F.Y[4]);
-    F.Y[5] = axpy(s, F.X[4], c * F.Y[4]);
-    F.Z[5] = F.Z[4];
-}
-DEV f3 joint_axis(const ArmFrames &F, int j) {  // world joint axes (follower.xml:58,65,72,79,86,95); j is a literal after unrolling
-    switch (j) {
-    case 0: return neg(F.Z[0]);
-    case 1: return F.Y[1];
-    case 2: return neg(F.Y[2]);
-    case 3: return F.Y[3];
-    case 4: return F.X[4];
-    default: return neg(F.Z[5]);
-    }
-}
-DEV f3 local_point(const ArmFrames &F, int i, float x, float y, float z) {
-    return axpy(x, F.X[i], axpy(y, F.Y[i], axpy(z, F.Z[i], F.p[i])));
-}
-DEV f3 site_pos(const ArmFrames &F) { return local_point(F, 4, lcrm::SITEx, lcrm::SITEy, lcrm::SITEz); }
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 DEV f3 symv(const Sym3 &S, f3 v) {
@@ -323,27 +229,6 @@ DEV void store_state(const LcrDev &P, int e, const EnvState<NC> &S) {
     }
 }
 
-struct CubeRot { f3 X, Y, Z; };  // columns of the cube rotation matrix
-DEV CubeRot quat_to_cols(const float (&q)[4]) {
-    float w = q[0], x = q[1], y = q[2], z = q[3];
-    CubeRot R;
-    R.X = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y));
-    R.Y = mk(2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x));
-    R.Z = mk(2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y));
-    return R;
-}
-
-// ------------------------------------------------------------------------------------------------
-// floor <-> cube contact slot (cube-only rows; frame n=+z, t1=+y, t2=-x)
-// ------------------------------------------------------------------------------------------------
-struct FloorSlot {
-    f3 r;            // contact point relative to cube centre (world)
-    float f[4];      // n, t1, t2, torsion
-    float aref[4];
-    float inv[4];    // 1 / (A_ii + R_i)
-    float Rn;
-    bool act;
-};
 
 // ------------------------------------------------------------------------------------------------
 // arm-coupled contact slot: finger sphere vs cube (HASCUBE) or vs floor
@@ -1552,76 +1437,6 @@ __global__ __launch_bounds__(256) void lcr_fill_actions_kernel(float *action, in
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// image observation STUB (observation_mode image/both): two 240x320x3 uint8 frames per env.  Not a
-// renderer -- a flat background with the cube(s) splatted as a small square under a fixed orthographic
-// map; exists so that the HBM-write-bound shape of the image configs can be measured.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lcr_image_stub_kernel(LcrDev P, int ncube) {
-    // One work item = one 16-B vector; consecutive lanes write consecutive vectors, so every store instruction of a
-    // wave covers one contiguous 1 KiB span (full cache lines).  A frame is 14 400 vectors (60 per 320-pixel row); both
-    // frames of an env = 28 800.  Stores are non-temporal: write-once data that should not occupy L2.
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const int env = blockIdx.x;
-    const int N = P.n;
-    const size_t img_bytes = (size_t)240 * 320 * 3;
-    // cube centres -> pixel boxes (front: x,z ; top: x,y), 800 px per metre, 24 px squares
-    int bx0[2], bx1[2], fz0[2], fz1[2], ty0[2], ty1[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int cc = c < ncube ? c : 0;
-        const float cx = P.qpos[(size_t)(6 + 7 * cc) * N + env];
-        const float cy = P.qpos[(size_t)(7 + 7 * cc) * N + env];
-        const float cz = P.qpos[(size_t)(8 + 7 * cc) * N + env];
-        const int px = (int)(160.f + 800.f * cx), pz = (int)(200.f - 800.f * cz), py = (int)(200.f - 800.f * cy);
-        bx0[c] = px - 12; bx1[c] = px + 12; fz0[c] = pz - 12; fz1[c] = pz + 12; ty0[c] = py - 12; ty1[c] = py + 12;
-        if (c >= ncube) { bx0[c] = 1 << 20; bx1[c] = -(1 << 20); }
-    }
-    u32x4 *front = reinterpret_cast<u32x4 *>(P.img_front + (size_t)env * img_bytes);
-    u32x4 *top = reinterpret_cast<u32x4 *>(P.img_top + (size_t)env * img_bytes);
-    for (int g = blockIdx.y * blockDim.x + threadIdx.x; g < 28800; g += gridDim.y * blockDim.x) {
-        const bool is_top = g >= 14400;
-        const int v = is_top ? g - 14400 : g;
-        const int row = v / 60, xb = (v - row * 60) * 16;  // first byte of this vector within its row
-        const int ph = v % 3;                               // (16 v) mod 3 = v mod 3: channel phase of byte 0
-        unsigned c[3];
-        if (is_top) { c[0] = 50; c[1] = 62; c[2] = 74; }
-        else if (row < 160) { c[0] = 60; c[1] = 90; c[2] = 120; }
-        else { c[0] = 40; c[1] = 50; c[2] = 60; }
-        // background: byte i has channel (ph + i) mod 3
-        const unsigned a0 = ph == 0 ? c[0] : (ph == 1 ? c[1] : c[2]);
-        const unsigned a1 = ph == 0 ? c[1] : (ph == 1 ? c[2] : c[0]);
-        const unsigned a2 = ph == 0 ? c[2] : (ph == 1 ? c[0] : c[1]);
-        const unsigned w0 = a0 | (a1 << 8) | (a2 << 16) | (a0 << 24);
-        const unsigned w1 = a1 | (a2 << 8) | (a0 << 16) | (a1 << 24);
-        const unsigned w2 = a2 | (a0 << 8) | (a1 << 16) | (a2 << 24);
-        u32x4 out = {w0, w1, w2, w0};
-        const int px_lo = xb / 3, px_hi = (xb + 15) / 3;
-        bool hit = false;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int r0 = is_top ? ty0[k] : fz0[k], r1 = is_top ? ty1[k] : fz1[k];
-            hit = hit || (row > r0 && row < r1 && px_hi > bx0[k] && px_lo < bx1[k]);
-        }
-        if (hit) {  // rare: this vector overlaps a cube square, build it byte by byte
-            unsigned w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int byte = xb + i, px = byte / 3, ch = byte - px * 3;
-                unsigned val = c[ch];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int r0 = is_top ? ty0[k] : fz0[k], r1 = is_top ? ty1[k] : fz1[k];
-                    if (row > r0 && row < r1 && px > bx0[k] && px < bx1[k]) val = (k == 0) ? (ch == 0 ? 200u : 20u) : (ch == 2 ? 200u : 20u);
-                }
-                w[i >> 2] |= val << (8 * (i & 3));
-            }
-            out = u32x4{w[0], w[1], w[2], w[3]};
-        }
-        __builtin_nontemporal_store(out, (is_top ? top : front) + v);
-    }
-}
-
 // measurement support: one dword per lane copy (the step kernel's access pattern) with a known byte count,
 // used to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section)
 __global__ __launch_bounds__(64) void lcr_calib_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
@@ -1664,12 +1479,6 @@ int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsig
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed, unsigned long long step,
                             void *stream) {
     hipLaunchKernelGGL(lcr_fill_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, action_dev, n, k, env_off, seed, step);
-    return check_launch();
-}
-
-int lcr_launch_image_stub(const LcrDev &P, void *stream) {
-    if (!P.img_front || !P.img_top) return 0;
-    hipLaunchKernelGGL(lcr_image_stub_kernel, dim3(P.n, 8), dim3(256), 0, (hipStream_t)stream, P, P.task == 4 ? 2 : 1);
     return check_launch();
 }
 

@@ -3,7 +3,7 @@
 Same class names, constructor kwargs and defaults, spaces, return types and exception types as the
 reference env classes (gym_lowcostrobot/envs/*_env.py); physics runs in the fused HIP step kernel through
 the C ABI.  Differences a caller can observe are listed in INTEGRATION.md (no `model` / `data` MuJoCo
-objects -> get_state()/set_state(); image observations and render() are a stub, not a renderer).
+objects -> get_state()/set_state(); image observations and render() come from an approximate ray-caster).
 """
 import os
 
@@ -87,12 +87,8 @@ class _LowCostRobotEnv(sp.EnvBase):
         return observation, reward, terminated, False, info
 
     def render(self):
-        if self.render_mode == "rgb_array":  # reference: 640x640 camera_vizu frame (reach_cube_env.py:350-355); STUB here
-            frame = np.full((640, 640, 3), 60, np.uint8)
-            c = self._sim.cube_pos.numpy()[:, 0]
-            px, py = int(320 + 1600 * c[0]), int(500 - 1600 * c[2])
-            frame[max(py - 24, 0): py + 24, max(px - 24, 0): px + 24] = (200, 20, 20)
-            return frame
+        if self.render_mode == "rgb_array":  # 640x640 frame of camera_vizu (reach_cube_env.py:350-355), ray-cast approximation
+            return self._sim.render(0, "camera_vizu", 640, 640)
         return None
 
     def close(self):

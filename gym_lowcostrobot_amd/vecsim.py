@@ -182,6 +182,13 @@ class VecSim:
     def fill_random_actions(self, arr, seed, step):
         check(self.L.lcr_fill_random_actions(self.handle, ctypes.c_void_p(arr.ptr), int(seed), int(step)))
 
+    def render(self, env=0, camera="camera_vizu", width=640, height=640):
+        """ray-cast one env: camera_front / camera_top / camera_vizu -> (height, width, 3) uint8"""
+        cam = {"camera_front": 0, "camera_top": 1, "camera_vizu": 2}[camera]
+        out = np.empty((height, width, 3), np.uint8)
+        check(self.L.lcr_render(self.handle, int(env), cam, int(width), int(height), _vp(out)))
+        return out
+
     def calibrate_copy(self, n_floats):
         """launch the known-byte-count copy kernel once (profiling calibration); returns bytes read == bytes written"""
         if getattr(self, "_calib_dst", None) is None or self._calib_n < n_floats:

@@ -97,7 +97,7 @@ typedef struct lcr_obs_view {
     const float *arm_qvel;      /* [6][N] */
     const float *cube_pos;      /* [3][N]  (stack: cube_red_pos) */
     const float *aux_pos;       /* [3][N]  or NULL */
-    const uint8_t *image_front; /* [N][240][320][3] or NULL (observation_mode image/both) -- render STUB */
+    const uint8_t *image_front; /* [N][240][320][3] or NULL (observation_mode image/both); approximate ray-cast, see lcr_render.hip */
     const uint8_t *image_top;   /* [N][240][320][3] or NULL */
 } lcr_obs_view;
 
@@ -171,6 +171,11 @@ int lcr_timer_end(lcr_sim *sim, float *ms_out);
 /* Fill action_dev [k][N] with U(-1,1) from a counter-based generator keyed (seed, global env id, step):
  * the synthetic policy of the benchmark; shard-invariant by construction. */
 int lcr_fill_random_actions(lcr_sim *sim, float *action_dev, uint64_t seed, uint64_t step);
+
+/* == render() with render_mode="rgb_array" (reach_cube_env.py:350-355: 640x640 frame of camera_vizu) and ad-hoc frames of
+ * the observation cameras: ray-cast env `env` from camera 0 (camera_front), 1 (camera_top) or 2 (camera_vizu) at
+ * width x height into rgb_host[height][width][3].  Synchronous. */
+int lcr_render(lcr_sim *sim, int env, int camera, int width, int height, uint8_t *rgb_host);
 
 /* Measurement support: copy n_floats floats from the start of the state arena to dst_dev with one dword load and
  * one dword store per lane (the step kernel's access pattern): a launch with a KNOWN byte count (4*n read, 4*n

@@ -81,6 +81,11 @@ def test_env_checker_contract(hip_lib, env_id, observation_mode):
 
 @pytest.mark.gpu
 def test_action_dims_follow_reference_rule(hip_lib):
+    e = envs.ReachCubeEnv(observation_mode="state", render_mode="rgb_array")
+    e.reset(seed=0)
+    frame = e.render()
+    assert frame.shape == (640, 640, 3) and frame.dtype == np.uint8 and frame.std() > 5   # reach_cube_env.py:350-355
+    e.close()
     for cls, joint_k in [(envs.ReachCubeEnv, 5), (envs.PushCubeEnv, 5), (envs.PushCubeLoopEnv, 5), (envs.LiftCubeEnv, 6), (envs.PickPlaceCubeEnv, 6),
                          (envs.StackTwoCubesEnv, 6)]:
         e = cls(observation_mode="state")

@@ -169,16 +169,67 @@ def test_stack_cube_on_cube_contacts(hip_lib):
     sim.close()
 
 
-def test_image_stub_written(hip_lib):
+def _project(cam, p, H=240, W=320):
+    """pinhole model of lcr_render.hip: returns pixel (u, v)"""
+    pos, X, Y = np.array(cam["pos"], float), np.array(cam["x"], float), np.array(cam["y"], float)
+    X /= np.linalg.norm(X); Y -= (Y @ X) * X; Y /= np.linalg.norm(Y); Z = np.cross(X, Y)
+    d = np.asarray(p, float) - pos
+    s = 2 * np.tan(np.radians(22.5)) / H
+    depth = -(d @ Z)
+    return int(round(W / 2 + (d @ X) / (depth * s) - 0.5)), int(round(H / 2 - (d @ Y) / (depth * s) - 0.5))
+
+
+CAM_FRONT = {"pos": (0.049, 0.5, 0.225), "x": (-0.998, 0.056, 0.0), "y": (-0.019, -0.335, 0.942)}   # reach_cube.xml:29
+CAM_TOP = {"pos": (0.0, 0.1, 0.6), "x": (1, 0, 0), "y": (0, 1, 0)}                                  # reach_cube.xml:30
+
+
+def test_image_observations_raycast(hip_lib):
+    """image observations: cubes, arm and checker floor appear where the pinhole cameras of the scene xml put them"""
     from gym_lowcostrobot_amd import VecSim
-    sim = VecSim("stack", 8, observation_mode="both")
-    a = np.zeros((8, 6), np.float32)
-    sim.step(a)
+    from oracle import orc
+    n = 6
+    sim = VecSim("stack", n, observation_mode="both", auto_reset=False)
+    qpos = sim.get_state()["qpos"]
+    red = np.array([[0.08, 0.2, 0.015], [-0.1, 0.12, 0.015], [0.0, 0.25, 0.015], [0.12, 0.05, 0.015], [-0.05, 0.3, 0.015], [0.05, 0.15, 0.015]])
+    blue = red + np.array([-0.07, 0.04, 0.0])
+    qpos[6:9] = red.T; qpos[13:16] = blue.T
+    qpos[9:13] = np.array([[1, 0, 0, 0]] * n).T; qpos[16:20] = np.array([[1, 0, 0, 0]] * n).T
+    q_arm = np.array([[0.3, -0.4, 0.5, 0.2, 0.1, -0.3]] * n)
+    qpos[:6] = q_arm.T
+    sim.set_state(qpos=qpos, qvel=np.zeros((18, n)))
+    sim.reset(mask=np.zeros(n, np.uint8))            # no env reset, but re-renders the frames from the new state
     obs = sim.observations()
     f, t = obs["image_front"], obs["image_top"]
-    assert f.shape == (8, 240, 320, 3) and f.dtype == np.uint8 and t.shape == f.shape
-    assert (f[..., 0] == 200).any() and (t[..., 2] == 200).any()   # red and blue cube splats
-    assert f.std() > 0 and t.std() > 0
+    assert f.shape == (n, 240, 320, 3) and f.dtype == np.uint8 and t.shape == f.shape
+    hits = tot = 0
+    for e in range(n):
+        for cam, img in ((CAM_TOP, t), (CAM_FRONT, f)):
+            for centre, chan in ((red[e], 0), (blue[e], 2)):      # cube geoms rgba (0.5 0 0) / (0 0 0.5)
+                u, v = _project(cam, centre)
+                if 2 <= u < 318 and 2 <= v < 238:
+                    px = img[e, v, u].astype(int)
+                    tot += 1
+                    others = [px[i] for i in range(3) if i != chan]
+                    hits += int(px[chan] > 60 and max(others) < 20)
+    assert tot >= 16 and hits >= 0.8 * tot, (hits, tot)           # a few centres may be hidden behind the arm
+    # the arm: the pixel of a point INSIDE the forearm capsule (midpoint of link_3 .. link_4 origins) is light grey
+    lp, site, _ = orc.fk(q_arm[0])
+    mid = 0.5 * (lp[2] + lp[3])
+    for cam, img in ((CAM_TOP, t), (CAM_FRONT, f)):
+        u, v = _project(cam, mid)
+        px = img[0, v, u].astype(int)
+        assert px.min() > 70 and px.max() - px.min() < 12, (cam["pos"], u, v, px)
+    # checker floor seen from the top camera: two floor points in adjacent 0.1 m squares have the two checker colours
+    u0, v0 = _project(CAM_TOP, (-0.15, -0.05, 0.0)); u1, v1 = _project(CAM_TOP, (-0.15, 0.02, 0.0))
+    c0, c1 = t[0, v0, u0].astype(int), t[0, v1, u1].astype(int)
+    assert abs(int(c0[2]) - int(c1[2])) > 15 and c0[2] > c0[1] > c0[0] and c1[2] > c1[1] > c1[0]    # bluish greys
+    # sky above the horizon in the front camera, and determinism
+    assert f[0, 2, 160, 2] > f[0, 2, 160, 0]
+    sim.reset(mask=np.zeros(n, np.uint8))
+    np.testing.assert_array_equal(sim.observations()["image_front"], f)
+    # render(): 640x640 frame of camera_vizu shows floor and sky
+    frame = sim.render(0, "camera_vizu", 640, 640)
+    assert frame.shape == (640, 640, 3) and frame.std() > 5
     sim.close()
 
 
