@@ -17,3 +17,7 @@ rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_FLAT SQ_WAVES SQ_ACTIVE_INS
 find $OUT -name "*.csv" | head -40
 # config-5 shape: Stack + image stub (HBM-write-bound), kernel trace only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_img -o t -- python $REPO/bench.py --workload StackTwoCubes-v0 --obs both --envs-per-gpu 32768 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace_img.log 2>&1
+# the other BASELINE.json workloads at 65 536 envs (kernel trace only)
+for WL in PushCube-v0 LiftCube-v0 PickPlaceCube-v0 StackTwoCubes-v0; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -o t -- python $REPO/bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline > $OUT/trace_$WL.log 2>&1
+done
