@@ -193,6 +193,25 @@ def main():
             "state_finite": finite,
             "calibration_bytes_per_launch": calib_bytes or None,
         }
+        # VALU-side view of the same kernel (the state-only step is VALU-issue-bound): taken from the committed
+        # rocprofv3 PMC summary of this command, not measured live
+        try:
+            import glob
+
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+            with open(pm) as f:
+                pj = json.load(f)
+            pmc = pj["step_kernel_pmc_per_launch"]
+            if pj.get("workload") == args.workload and args.obs == "state":
+                out["valu"] = {
+                    "source": os.path.basename(pm),
+                    "valu_insts_per_wave_per_launch": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
+                    "valu_busy_frac_of_wave_cycles": pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"],
+                    "wait_frac_of_wave_cycles": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
+                    "note": "one wave per SIMD at 65 536 envs; plain fp32 VALU issues ~1 instruction per 4 cycles per SIMD",
+                }
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(task, action_mode)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
