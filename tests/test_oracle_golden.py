@@ -350,3 +350,79 @@ def test_loop_rails_and_goal_switch():
     assert o.is_success[0] == 1 and o.reward64[0] == 5 and o.goal[0] == 1 and o.terminated[0] == 0
     o.reset()
     assert o.goal[0] == 1 and o.qpos[0, 6] < 0
+
+
+# ---------------------------------------------------------------- analytic known answers of the restated MuJoCo pipeline
+def test_kat_free_fall_semi_implicit_euler():
+    """no contact: v_n = -g h n and z_n = z0 - g h^2 n(n+1)/2 exactly (velocity first, then position)"""
+    o = orc.Oracle("reach", 1, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[0])
+    o.qpos[0, 6:9] = [0.3, 0.3, 1.0]; o.qvel[:] = 0
+    o.step(np.zeros((1, 5), np.float32))
+    n, h, g = 20, 0.002, 9.81
+    assert o.qvel[0, 8] == pytest.approx(-g * h * n, rel=1e-12)
+    assert o.qpos[0, 8] == pytest.approx(1.0 - g * h * h * n * (n + 1) / 2, rel=1e-12)
+
+
+def test_kat_resting_penetration_of_the_soft_contact_model():
+    """cube at rest on 4 contacts: every normal row carries m g / 4 and, with zero acceleration, f = aref / R, i.e.
+    m g / 4 = k d(r) r / R(r) with k = 1/(dmax^2 tc^2), R = (1-d)/d * (1/m): solve for the penetration r"""
+    m, g, tc, dmax, d0, width = 0.1, 9.81, 0.02, 0.95, 0.9, 0.001
+    k = 1.0 / (dmax * dmax * tc * tc)
+    r = 1e-4
+    for _ in range(100):
+        x = min(r / width, 1.0)
+        y = 2 * x * x if x <= 0.5 else 1 - 2 * (1 - x) ** 2
+        d = d0 + y * (dmax - d0)
+        R = (1 - d) / d * (1.0 / m)
+        r = (m * g / 4) * R / (k * d)
+    o = orc.Oracle("reach", 1, auto_reset=0, max_episode_steps=0, pgs_iters=30)
+    o.reset(seeds=[0])
+    o.qpos[0, 6:9] = [0.3, 0.3, 0.015]
+    for _ in range(40):
+        o.step(np.zeros((1, 5), np.float32))
+    pen = 0.015 - o.qpos[0, 8]
+    assert r == pytest.approx(1.1e-4, rel=0.05)
+    assert pen == pytest.approx(r, rel=0.02), (pen, r)
+    assert abs(o.qvel[0, 8]) < 1e-5
+
+
+def test_kat_pd_static_sag_and_saturated_terminal_velocity():
+    """position actuator kp=1000: holding a pose against gravity leaves an error tau_g / kp; a saturated actuator
+    (+-10 N m, follower.xml:7) against joint damping 1 converges to 10 rad/s on the gravity-free pan joint"""
+    o = orc.Oracle("lift", 1, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[0])
+    o.qpos[0, 6:9] = [0.5, 0.5, 0.015]
+    q = np.array([0.3, 0.2, 0.3, 0.2, 0.1, -0.2])   # fingers well above the floor
+    o.qpos[0, :6] = q
+    # absolute target = q (action = target - current each step), hold for a while
+    for _ in range(30):
+        a = np.zeros((1, 6), np.float32); a[0, :] = np.clip(q - o.qpos[0, :6], -1, 1)
+        o.step(a)
+    tau_g = -orc.bias(o.qpos[0, :6], np.zeros(6))
+    np.testing.assert_allclose(o.qpos[0, :6] - q, tau_g / 1000.0, atol=3e-5)   # error after the hold: tau_g / kp
+    # saturation: keep asking for +1 rad on joint 1 only
+    o.qvel[:] = 0
+    for _ in range(25):
+        a = np.zeros((1, 6), np.float32); a[0, 0] = 1.0
+        a[0, 1:] = np.clip(q[1:] - o.qpos[0, 1:6], -1, 1)
+        o.step(a)
+        if abs(o.qpos[0, 0]) > 2.5:
+            break
+    # first-order approach with time constant armature / damping = 0.1 s; the joint reaches its range after ~0.28 s
+    assert 9.0 < o.qvel[0, 0] < 10.0
+
+
+def test_kat_warm_start_four_sweeps_near_converged_solution():
+    """D1: 4 warm-started PGS sweeps stay within 2e-4 of the converged (300 cold sweeps) solution, like 10 cold sweeps"""
+    def run(**kw):
+        o = orc.Oracle("push", 16, auto_reset=0, max_episode_steps=0, **kw)
+        o.reset(seeds=np.arange(16))
+        rng = np.random.default_rng(0)
+        for _ in range(3):
+            o.step(rng.uniform(-1, 1, (16, 5)).astype(np.float32), threads=0)
+        return o.qpos.copy()
+    ref = run(pgs_iters=300, warm_start=0)
+    cold10 = np.abs(run(pgs_iters=10, warm_start=0) - ref).max()
+    warm4 = np.abs(run(pgs_iters=4, warm_start=1) - ref).max()
+    assert warm4 < 2e-4 and cold10 < 2e-4
