@@ -952,6 +952,15 @@ void orc_joint_ctrl(const orc_params *p, const double *q6, const float *action, 
     else ctrl6[5] = 0.0;                                                                                     /* reach:255,265 */
 }
 
+/* ee-mode glue of apply_action: target = site_xpos + float32(action[:3] * 0.05), z clamped at 0 (reach:236-242); gripper
+ * target = clip(qpos[5] + float32(action[3] * 0.2), ctrlrange) for the gripper tasks (lift:253-257), 0 otherwise (reach:247) */
+void orc_ee_glue(const orc_params *p, const double *site3, double q_gripper, const float *action, double *target3, double *grip) {
+    for (int i = 0; i < 3; i++) target3[i] = site3[i] + (double)(clip1(action[i]) * 0.05f); /* float32 product, float64 sum */
+    if (target3[2] < 0) target3[2] = 0;
+    if (gripper_active(p)) *grip = clampd(q_gripper + (double)(clip1(action[3]) * 0.2f), JNT_LO[5], JNT_HI[5]);
+    else *grip = 0.0;
+}
+
 /* inverse_kinematics (reach:148-221) incl. REF-QUIRK-3: writes the sim's qpos */
 static int ik_solve(real *q_state /*in: qpos[:6], out: teleported*/, const real *target, real *q_ctrl, real *site_last) {
     real q[6];
@@ -1162,14 +1171,13 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     /* ---- apply_action reach:223-273 */
     if (P->action_mode == ORC_ACTION_EE) {
         real tgt[3], qc[6], sl[3];
-        for (int i = 0; i < 3; i++) tgt[i] = (real)(ee_lag[i] + (double)(clip1(action[i]) * 0.05f)); /* reach:241 (float32 product) */
-        if (tgt[2] < 0) tgt[2] = 0; /* reach:242 */
+        double t64[3], g64;
+        orc_ee_glue(P, ee_lag, 0.0, action, t64, &g64); /* target only; the gripper needs the post-IK qpos[5] */
+        for (int i = 0; i < 3; i++) tgt[i] = (real)t64[i];
         ik_solve(qpos, tgt, qc, sl);
         for (int j = 0; j < 6; j++) ctrl[j] = qc[j];
-        if (gripper_active(P)) { /* lift:253-257 */
-            double g = (double)qpos[5] + (double)(clip1(action[3]) * 0.2f);
-            ctrl[5] = (real)clampd(g, JNT_LO[5], JNT_HI[5]);
-        } else ctrl[5] = 0; /* reach:247 */
+        orc_ee_glue(P, ee_lag, (double)qpos[5], action, t64, &g64);
+        ctrl[5] = (real)g64;
     } else {
         double q6[6], c6[6];
         for (int j = 0; j < 6; j++) q6[j] = (double)qpos[j];

@@ -203,6 +203,41 @@ def main():
                 }
             )
 
+    # ---- ee-mode glue of apply_action (reach:236-247, lift:241-257) with the MuJoCo-dependent IK stubbed out ----------
+    class _Site:
+        def __init__(self, xpos):
+            self.xpos = xpos
+            self.id = 0
+
+    out["ee_glue"] = []
+    for cls, name, gripper in [(ReachCubeEnv, "reach", False), (LiftCubeEnv, "lift", True), (PickPlaceCubeEnv, "pick_place", True)]:
+        for _ in range(12):
+            env = mk(cls, 13)
+            env.action_mode = "ee"
+            env.render_mode = None
+            env.control_decimation = 1
+            env.ctrl_range = env.model.actuator_ctrlrange
+            k = 4 if gripper else 3
+            env.action_space = Box(-1.0, 1.0, shape=(k,), dtype=np.float32)
+            site = rng.uniform(-0.2, 0.3, 3)
+            site[2] = rng.uniform(-0.01, 0.2)
+            env.model.site = lambda n, _s=site: _Site(_s)
+            env.data.site = lambda i, _s=site: _Site(_s.copy())
+            env.data.qpos[:6] = rng.uniform(-1.0, 1.0, 6)
+            env.data.qpos[5] = rng.uniform(-2.45, 0.032)
+            captured = {}
+
+            def fake_ik(ee_target_pos, _c=captured, _e=env):
+                _c["target"] = np.array(ee_target_pos, dtype=np.float64).copy()
+                return _e.data.qpos[:6].copy()
+
+            env.inverse_kinematics = fake_ik
+            act = rng.uniform(-1.4, 1.4, k).astype(np.float32)
+            q5 = float(env.data.qpos[5])
+            env.apply_action(act)
+            out["ee_glue"].append({"task": name, "site": site.tolist(), "q5": q5, "action": [float(x) for x in act],
+                                   "target": captured["target"].tolist(), "ctrl5": float(np.asarray(env.data.ctrl)[5])})
+
     # ---- PushCubeLoop-v0: overlap / reward / goal switching / reset sampling (push_cube_loop_env.py:299-383) -----
     from gym_lowcostrobot.envs.push_cube_loop_env import PushCubeLoopEnv
 

@@ -426,3 +426,17 @@ def test_kat_warm_start_four_sweeps_near_converged_solution():
     cold10 = np.abs(run(pgs_iters=10, warm_start=0) - ref).max()
     warm4 = np.abs(run(pgs_iters=4, warm_start=1) - ref).max()
     assert warm4 < 2e-4 and cold10 < 2e-4
+
+
+@pytest.mark.parametrize("rec", GOLD["ee_glue"], ids=lambda r: r["task"])
+def test_ee_glue_golden(rec):
+    """ee-mode target and gripper arithmetic of apply_action (reach:236-247, lift:241-257), incl. numpy's float32 products"""
+    import ctypes
+
+    p = _params(rec["task"], action_mode=1)
+    site = np.array(rec["site"], np.float64)
+    a = np.zeros(4, np.float32); a[: len(rec["action"])] = rec["action"]
+    tgt = np.zeros(3); grip = ctypes.c_double()
+    orc.lib().orc_ee_glue(ctypes.byref(p), orc._p(site), ctypes.c_double(rec["q5"]), orc._p(a), orc._p(tgt), ctypes.byref(grip))
+    np.testing.assert_array_equal(tgt, np.array(rec["target"]))
+    assert grip.value == rec["ctrl5"]
