@@ -238,6 +238,49 @@ def main():
             out["ee_glue"].append({"task": name, "site": site.tolist(), "q5": q5, "action": [float(x) for x in act],
                                    "target": captured["target"].tolist(), "ctrl5": float(np.asarray(env.data.ctrl)[5])})
 
+    # ---- inverse_kinematics loop (reach:148-221) run UNMODIFIED, with mj_forward / mj_jacSite / site xpos served by
+    #      this repo's kinematics (oracle FK and Jacobian, themselves pinned to the SURVEY.md 8(c) known answers).
+    #      Pins the reference's own loop arithmetic: DLS solve, unit-norm clamp, 0.5 step, joint limits, early break,
+    #      and the qpos overwrite (REF-QUIRK-3).
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from oracle import orc as _orc
+    import mujoco as _mj
+
+    class _IKData(_FakeData):
+        def __init__(self):
+            super().__init__(13)
+            self._site = np.zeros(3)
+
+        def site(self, i):
+            return _Site(self._site)
+
+    def _mj_forward(model, data):
+        data._site[:] = _orc.fk(np.array(data.qpos[:6], dtype=np.float64))[1]
+
+    def _mj_jacsite(model, data, jacp, jacr, sid):
+        jacp[:] = 0
+        jacp[:, :6] = _orc.site_jac(np.array(data.qpos[:6], dtype=np.float64))
+
+    _mj.mj_forward = _mj_forward
+    _mj.mj_jacSite = _mj_jacsite
+    out["ik"] = []
+    for _ in range(24):
+        env = mk(ReachCubeEnv, 13)
+        env.model.nv = 12
+        env.model.site = lambda n: _Site(np.zeros(3))
+        env.data = _IKData()
+        q0 = rng.uniform(-1.2, 1.2, 6)
+        q0[5] = rng.uniform(-2.45, 0.06)  # occasionally beyond the upper gripper limit: IK clamps it (teleport of joint 6)
+        env.data.qpos[:6] = q0
+        site0 = _orc.fk(q0)[1]
+        reach = rng.choice([0.004, 0.03, 0.08, 0.25])
+        tgt = site0 + rng.normal(0, 1, 3) * reach
+        tgt[2] = max(0.0, tgt[2])
+        qt = env.inverse_kinematics(ee_target_pos=tgt.copy())
+        out["ik"].append({"q0": q0.tolist(), "target": tgt.tolist(), "q_target": np.asarray(qt).tolist(),
+                          "qpos_after": env.data.qpos[:6].tolist(), "site_after": env.data._site.tolist()})
+    _mj.mj_forward = lambda m, d: None
+
     # ---- PushCubeLoop-v0: overlap / reward / goal switching / reset sampling (push_cube_loop_env.py:299-383) -----
     from gym_lowcostrobot.envs.push_cube_loop_env import PushCubeLoopEnv
 

@@ -440,3 +440,13 @@ def test_ee_glue_golden(rec):
     orc.lib().orc_ee_glue(ctypes.byref(p), orc._p(site), ctypes.c_double(rec["q5"]), orc._p(a), orc._p(tgt), ctypes.byref(grip))
     np.testing.assert_array_equal(tgt, np.array(rec["target"]))
     assert grip.value == rec["ctrl5"]
+
+
+@pytest.mark.parametrize("rec", GOLD["ik"], ids=lambda r: f"ik{abs(hash(tuple(r['q0']))) % 1000}")
+def test_ik_loop_golden(rec):
+    """the reference's inverse_kinematics loop (reach:148-221), run unmodified on this repo's FK / Jacobian, vs orc_ik:
+    returned joint target, the overwritten sim qpos (REF-QUIRK-3) and the last site position"""
+    it, qc, qs, sl = orc.ik(np.array(rec["q0"]), np.array(rec["target"]))
+    np.testing.assert_allclose(qc, rec["q_target"], atol=2e-12)     # np.linalg.inv vs Cholesky: rounding only
+    np.testing.assert_allclose(qs, rec["qpos_after"], atol=2e-12)
+    np.testing.assert_allclose(sl, rec["site_after"], atol=2e-12)
