@@ -47,3 +47,51 @@ def timed_region(run_steps, steps, *, dist=None, device_sync=None, tensor_device
 def aggregate_throughput(envs_per_rank, world, steps, worst_seconds):
     """whole-job env-steps/s: units all ranks processed / max-over-ranks time"""
     return int(envs_per_rank) * int(world) * int(steps) / worst_seconds
+
+
+class ShardedVecSim:
+    """Single-process convenience over several GPUs: one VecSim (one C-ABI handle, one HIP stream) per device, contiguous
+    global env-id ranges, launches enqueued on every device before anything is synchronised.  No collective is involved;
+    results are identical to any other sharding of the same global batch."""
+
+    def __init__(self, task, n_envs_total, devices, **kw):
+        from .vecsim import VecSim
+
+        devices = list(devices)
+        if n_envs_total % len(devices):
+            raise ValueError("n_envs_total must be divisible by the number of shards")
+        self.per = n_envs_total // len(devices)
+        self.n = n_envs_total
+        self.shards = [VecSim(task, self.per, device=d, env_id_offset=shard_offset(self.per, i), **kw) for i, d in enumerate(devices)]
+        self.action_dim = self.shards[0].action_dim
+        self._act = [s.alloc_actions() for s in self.shards]
+
+    def fill_random_actions(self, seed, step):
+        for s, a in zip(self.shards, self._act):
+            s.fill_random_actions(a, seed, step)
+
+    def step_device(self):
+        """step every shard on its own action buffer (asynchronous on every device)"""
+        for s, a in zip(self.shards, self._act):
+            s.step_device(a.ptr)
+
+    def sync(self):
+        for s in self.shards:
+            s.sync()
+
+    def get_state(self):
+        import numpy as np
+
+        sts = [s.get_state() for s in self.shards]
+        return {k: np.concatenate([st[k] for st in sts], axis=-1) for k in sts[0]}
+
+    def outputs(self):
+        import numpy as np
+
+        outs = [s.outputs() for s in self.shards]
+        return {k: np.concatenate([o[k] for o in outs]) for k in outs[0]}
+
+    def close(self):
+        for s, a in zip(self.shards, self._act):
+            s.free(a)
+            s.close()

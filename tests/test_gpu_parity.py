@@ -380,3 +380,22 @@ def test_push_loop_parity(hip_lib):
     assert total_success > 20
     rows, cons, _ = o.diag()
     sim.close()
+
+
+def test_sharded_vecsim_single_process(hip_lib):
+    """several handles in one process (here: two shards on the same GPU) reproduce the unsharded batch bit for bit"""
+    from gym_lowcostrobot_amd import VecSim
+    from gym_lowcostrobot_amd.sharding import ShardedVecSim
+    n = 2048
+    whole = VecSim("push", n, observation_mode="state", base_seed=5)
+    sh = ShardedVecSim("push", n, devices=[0, 0], observation_mode="state", base_seed=5)
+    aw = whole.alloc_actions()
+    for t in range(6):
+        whole.fill_random_actions(aw, 3, t); whole.step_device(aw.ptr)
+        sh.fill_random_actions(3, t); sh.step_device()
+    sh.sync()
+    a, b = whole.get_state(), sh.get_state()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(whole.outputs()["reward"], sh.outputs()["reward"])
+    whole.close(); sh.close()
