@@ -233,6 +233,8 @@ DEV void store_state(const LcrDev &P, int e, const EnvState<NC> &S) {
 // ------------------------------------------------------------------------------------------------
 // arm-coupled contact slot: finger sphere vs cube (HASCUBE) or vs floor
 // ------------------------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 struct ArmSlot {
     f3 n, t1, t2, rc;  // frame and contact point relative to the cube centre (cube slots only)
     float f[4], aref[4], inv[4];
@@ -783,7 +785,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 fsub(CL, g);
                 float gg = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; j++) { gg = fmaf(g[j], g[j], gg); lds[s * LDS_SLOT + r * LDS_ROW + j * 64 + lane] = g[j]; }
+                for (int j = 0; j < 6; j++) { gg = fmaf(g[j], g[j], gg); lds[s * LDS_SLOT + r * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j]; }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 T.inv[r] = rcp(gg + diagc + Rr);
@@ -870,13 +872,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * T.f[2];
                 const float u3 = cal[c].z - T.aref[3] + Rt * T.f[3];
                 const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
-                const float Bd1 = minv + iinv * (r.z * r.z + r.x * r.x) + Rf, Bd2 = minv + iinv * (r.z * r.z + r.y * r.y) + Rf, Bd3 = iinv + Rt;
                 float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
                 const float d0 = T.act ? nf - T.f[0] : 0.f;
                 const float d1a = T.act ? -(u1 + B01 * d0) * T.inv[1] : 0.f;
                 const float d2a = T.act ? -(u2 + B02 * d0 + B12 * d1a) * T.inv[2] : 0.f;
                 const float d3a = T.act ? -(u3 + B13 * d1a + B23 * d2a) * T.inv[3] : 0.f;
-                (void)Bd1; (void)Bd2; (void)Bd3;
                 // elliptic cone: radial projection of the friction part
                 const float fn = T.f[0] + d0;
                 const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
@@ -992,11 +992,13 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const int sp = s & 1;
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * (vs_cube ? P.rt_fc : RT_FF);
-                float g[4][6];
+                // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
+                float2v g[4][3];
 #pragma unroll
                 for (int r = 0; r < 4; r++)
 #pragma unroll
-                    for (int j = 0; j < 6; j++) g[r][j] = lds[s * LDS_SLOT + r * LDS_ROW + j * 64 + lane];
+                    for (int k = 0; k < 3; k++) g[r][k] = *reinterpret_cast<const float2v *>(&lds[s * LDS_SLOT + r * LDS_ROW + k * 128 + lane * 2]);
+                float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
                 // pick the cube this slot talks to (wave-divergent only for Stack)
                 f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
                 const bool second = vs_cube && NC == 2 && slot_cube[sp] == 1;
@@ -1005,9 +1007,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
-                    float gy = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 6; j++) gy = fmaf(g[r][j], y[j], gy);
+                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                    const float gy = acc.x + acc.y;
                     f3 rxd = mk(0.f, 0.f, 0.f);
                     float jc_a = 0.f;
                     if (vs_cube) {
@@ -1020,8 +1021,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (r == 0) nf = fmaxf(nf, 0.f);
                     float dlt = T.act ? nf - T.f[r] : 0.f;
                     T.f[r] += dlt;
+                    {
+                        const float2v d2 = {dlt, dlt};
 #pragma unroll
-                    for (int j = 0; j < 6; j++) y[j] = fmaf(g[r][j], dlt, y[j]);
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                    }
                     if (vs_cube) {
                         if (r < 3) { dl_lin = axpy(-minv * dlt, d, dl_lin); dl_ang = axpy(-iinv * dlt, rxd, dl_ang); }
                         else dl_ang = axpy(-iinv * dlt, d, dl_ang);
@@ -1037,14 +1041,18 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         const f3 d = r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n);
                         float dlt = T.f[r] * sc - T.f[r];
                         T.f[r] += dlt;
+                        {
+                            const float2v d2 = {dlt, dlt};
 #pragma unroll
-                        for (int j = 0; j < 6; j++) y[j] = fmaf(g[r][j], dlt, y[j]);
+                            for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                        }
                         if (vs_cube) {
                             if (r < 3) { dl_lin = axpy(-minv * dlt, d, dl_lin); dl_ang = axpy(-iinv * dlt, cross(T.rc, d), dl_ang); }
                             else dl_ang = axpy(-iinv * dlt, d, dl_ang);
                         }
                     }
                 }
+                y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
                 if (vs_cube) {
                     if (NC == 2) {
                         if (second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }

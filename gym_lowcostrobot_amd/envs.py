@@ -12,9 +12,6 @@ import numpy as np
 from . import spaces as sp
 from .vecsim import VecSim
 
-_TASK_DEFAULT_BLOCK = {"reach": True, "push": True, "push_loop": True, "lift": False, "pick_place": False, "stack": False}
-
-
 class _LowCostRobotEnv(sp.EnvBase):
     # reach_cube_env.py:75
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 25}

@@ -133,6 +133,9 @@ class VecSim:
     # ---- lifecycle ----
     def close(self):
         if getattr(self, "handle", None):
+            if getattr(self, "_calib_dst", None) is not None:
+                self.L.lcr_free(self.handle, self._calib_dst)
+                self._calib_dst = None
             self.L.lcr_destroy(self.handle)
             self.handle = None
 
