@@ -9,15 +9,24 @@
 
 namespace lcrdev {
 
-struct f3 { float x, y, z; };
+typedef float f2v __attribute__((ext_vector_type(2)));
+// x and y share a 64-bit register pair so that element-wise vector arithmetic issues as packed v_pk_* instructions
+struct f3 {
+    union {
+        struct { float x, y; };
+        f2v xy;
+    };
+    float z;
+};
 DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
-DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV f3 mk2(f2v xy, float z) { f3 r; r.xy = xy; r.z = z; return r; }
+DEV f3 operator+(f3 a, f3 b) { return mk2(a.xy + b.xy, a.z + b.z); }
+DEV f3 operator-(f3 a, f3 b) { return mk2(a.xy - b.xy, a.z - b.z); }
+DEV f3 operator*(float s, f3 a) { return mk2(f2v{s, s} * a.xy, s * a.z); }
+DEV f3 neg(f3 a) { return mk2(-a.xy, -a.z); }
 DEV float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DEV f3 axpy(float s, f3 a, f3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }  // s*a+b
+DEV f3 axpy(float s, f3 a, f3 b) { return mk2(f2v{s, s} * a.xy + b.xy, fmaf(s, a.z, b.z)); }  // s*a+b
 DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
