@@ -2,7 +2,7 @@
 """Random-action roll-out of one environment through the gymnasium-style facade (the usage pattern of the reference's
 README / examples/gym_manipulation.py), running on the MI355X library.
 
-    python examples/simple.py --env PushCube-v0 --steps 100
+    python examples/random_rollout.py --env PushCube-v0 --steps 100
 """
 import argparse
 import os
