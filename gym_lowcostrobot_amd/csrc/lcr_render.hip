@@ -34,6 +34,8 @@ struct Scene {
     int nbox;
     // screen-space bounding boxes per camera (x0, x1, y0, y1), inclusive
     int bb[2][NPRIM][4];
+    // capsule silhouettes per camera as 2D swept discs: a (u,v), b-a (du,dv), 1/|b-a|^2, conservative radius^2
+    float seg[2][NCAP][6];
 };
 
 DEV void project_bbox(const LcrCam &C, int W, int H, const f3 *pts, int npts, float rad, int *bb) {
@@ -91,27 +93,70 @@ DEV void build_scene(const LcrDev &P, int env, Scene &S) {
     S.nbox = nb;
 }
 
-DEV void build_bboxes(const LcrCam &C, int W, int H, const Scene &S, int (*bb)[4]) {
-    for (int k = 0; k < NCAP; k++) {
-        f3 pts[2] = {S.ca[k], S.cb[k]};
-        project_bbox(C, W, H, pts, 2, S.cr[k], bb[k]);
+// screen bounding box of ONE primitive (called by one thread per (camera, primitive))
+DEV void build_bbox(const LcrCam &C, int W, int H, const Scene &S, int prim, int *bb, float *seg) {
+    if (prim < NCAP) {
+        f3 pts[2] = {S.ca[prim], S.cb[prim]};
+        project_bbox(C, W, H, pts, 2, S.cr[prim], bb);
+        // 2D silhouette (conservative): projected end points and the larger projected radius, +20 % for perspective stretch
+        float uv[2][2], rp[2];
+        bool ok = true;
+        for (int i = 0; i < 2; i++) {
+            f3 d = pts[i] - mk(C.px, C.py, C.pz);
+            float xc = dot(d, mk(C.xx, C.xy, C.xz)), yc = dot(d, mk(C.yx, C.yy, C.yz)), zc = -dot(d, mk(C.zx, C.zy, C.zz));
+            if (zc < 0.02f) { ok = false; zc = 0.02f; }
+            float inv = 1.0f / (zc * C.s);
+            uv[i][0] = 0.5f * W + xc * inv - 0.5f; uv[i][1] = 0.5f * H - yc * inv - 0.5f; rp[i] = S.cr[prim] * inv;
+        }
+        const float du = uv[1][0] - uv[0][0], dv = uv[1][1] - uv[0][1];
+        const float rr = 1.2f * fmaxf(rp[0], rp[1]) + 2.0f;
+        seg[0] = uv[0][0]; seg[1] = uv[0][1]; seg[2] = du; seg[3] = dv;
+        seg[4] = 1.0f / fmaxf(du * du + dv * dv, 1e-6f);
+        seg[5] = ok ? rr * rr : 1e30f;
+        return;
     }
-    for (int k = 0; k < NBOX; k++) {
-        if (k >= S.nbox) { bb[NCAP + k][0] = W; bb[NCAP + k][1] = -1; bb[NCAP + k][2] = H; bb[NCAP + k][3] = -1; continue; }
-        f3 pts[8];
-        for (int i = 0; i < 8; i++)
-            pts[i] = axpy((i & 1) ? S.bh[k].x : -S.bh[k].x, S.bX[k], axpy((i & 2) ? S.bh[k].y : -S.bh[k].y, S.bY[k],
-                     axpy((i & 4) ? S.bh[k].z : -S.bh[k].z, S.bZ[k], S.bc[k])));
-        project_bbox(C, W, H, pts, 8, 0.f, bb[NCAP + k]);
-    }
+    const int k = prim - NCAP;
+    if (k >= S.nbox) { bb[0] = W; bb[1] = -1; bb[2] = H; bb[3] = -1; return; }
+    f3 pts[8];
+    for (int i = 0; i < 8; i++)
+        pts[i] = axpy((i & 1) ? S.bh[k].x : -S.bh[k].x, S.bX[k], axpy((i & 2) ? S.bh[k].y : -S.bh[k].y, S.bY[k],
+                 axpy((i & 4) ? S.bh[k].z : -S.bh[k].z, S.bZ[k], S.bc[k])));
+    project_bbox(C, W, H, pts, 8, 0.f, bb);
 }
 
-// one pixel: returns linear rgb in [0,1]
-DEV f3 shade_pixel(const LcrCam &C, int W, int H, const Scene &S, int u, int v, unsigned prim_mask) {
+// rgb in [0,1] -> 0x00BBGGRR with v_cvt_pk_u8_f32 (saturating float->byte conversion and byte insert in one instruction)
+DEV unsigned pack_rgb(f3 c) {
+    unsigned v = 0u;
+    v = __builtin_amdgcn_cvt_pk_u8_f32(c.x * 255.f, 0, v);
+    v = __builtin_amdgcn_cvt_pk_u8_f32(c.y * 255.f, 1, v);
+    v = __builtin_amdgcn_cvt_pk_u8_f32(c.z * 255.f, 2, v);
+    return v;
+}
+
+// background only (no primitive can cover this pixel): checker floor below the horizon, gradient sky above.
+// rdu = un-normalised ray direction; the floor normal is +z so the headlight Lambert term is 0.3 - 0.6 rd_z.
+DEV unsigned shade_background(f3 ro, f3 rdu) {
+    const float inv = rsq(dot(rdu, rdu));
+    const float rdz = rdu.z * inv;
+    if (rdz < -1e-6f) {
+        const float t = -ro.z * rcp(rdu.z);
+        const float fx = fmaf(t, rdu.x, ro.x), fy = fmaf(t, rdu.y, ro.y);
+        const int cell = ((int)floorf(fx * 10.f) + (int)floorf(fy * 10.f)) & 1;
+        const float lam = fminf(fmaf(-0.6f, rdz, 0.3f), 1.f) * 255.f;
+        unsigned v = 0u;
+        v = __builtin_amdgcn_cvt_pk_u8_f32((cell ? 0.2f : 0.1f) * lam, 0, v);
+        v = __builtin_amdgcn_cvt_pk_u8_f32((cell ? 0.3f : 0.2f) * lam, 1, v);
+        v = __builtin_amdgcn_cvt_pk_u8_f32((cell ? 0.4f : 0.3f) * lam, 2, v);
+        return v;
+    }
+    const float a = clampf(rdz * 2.f, 0.f, 1.f);
+    return pack_rgb(mk(0.15f + a * 0.15f, 0.25f + a * 0.25f, 0.35f + a * 0.35f));
+}
+
+// one pixel with primitives: returns linear rgb in [0,1]
+DEV f3 shade_pixel(const LcrCam &C, const Scene &S, f3 rdu, unsigned prim_mask) {
     const f3 ro = mk(C.px, C.py, C.pz);
-    const float sx = (u + 0.5f - 0.5f * W) * C.s, sy = -(v + 0.5f - 0.5f * H) * C.s;
-    f3 rd = mk(C.xx * sx + C.yx * sy - C.zx, C.xy * sx + C.yy * sy - C.zy, C.xz * sx + C.yz * sy - C.zz);
-    rd = rsq(dot(rd, rd)) * rd;
+    const f3 rd = rsq(dot(rdu, rdu)) * rdu;
     float tbest = 1e30f;
     f3 nbest = mk(0.f, 0.f, 1.f), col;
     // background: sky gradient above the horizon, checker floor below (builtin checker, 0.1 m squares)
@@ -180,8 +225,6 @@ DEV f3 shade_pixel(const LcrCam &C, int W, int H, const Scene &S, int u, int v, 
     return out;
 }
 
-DEV unsigned to_byte(float x) { return (unsigned)(clampf(x, 0.f, 1.f) * 255.f + 0.5f); }
-
 __global__ __launch_bounds__(256) void lcr_render_obs_kernel(LcrDev P, LcrCam front, LcrCam top) {
     // A wave renders one image ROW at a time (320 pixels = 5 per lane, pixel = lane + 64 g): the 960 bytes of the row are
     // staged in LDS and leave as 60 contiguous 16-B non-temporal stores (one store instruction per row).  Primitive
@@ -193,34 +236,57 @@ __global__ __launch_bounds__(256) void lcr_render_obs_kernel(LcrDev P, LcrCam fr
     const int W = 320, H = 240;
     if (threadIdx.x == 0) build_scene(P, env, S);
     __syncthreads();
-    if (threadIdx.x == 0) build_bboxes(front, W, H, S, S.bb[0]);
-    if (threadIdx.x == 64) build_bboxes(top, W, H, S, S.bb[1]);
+    if (threadIdx.x < 2 * NPRIM) {
+        const int cam_id = threadIdx.x / NPRIM, prim = threadIdx.x - cam_id * NPRIM;
+        build_bbox(cam_id ? top : front, W, H, S, prim, S.bb[cam_id][prim], prim < NCAP ? S.seg[cam_id][prim] : nullptr);
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t img_bytes = (size_t)H * W * 3;
     unsigned char *st = stage[wave];
+    // Culling data lives in registers, one primitive per lane (lane k <-> primitive k): the per-row / per-span primitive
+    // masks are then single ballots instead of LDS-latency-bound scalar loops.
+    const int pk = lane < NPRIM ? lane : 0, ck = lane < NCAP ? lane : 0;
+    int bx0[2], bx1[2], by0[2], by1[2];
+    float sgp[2][6];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        bx0[c] = S.bb[c][pk][0]; bx1[c] = S.bb[c][pk][1]; by0[c] = S.bb[c][pk][2]; by1[c] = S.bb[c][pk][3];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sgp[c][i] = S.seg[c][ck][i];
+    }
     for (int task = blockIdx.y * 4 + wave; task < 2 * H; task += gridDim.y * 4) {
         const bool is_top = task >= H;
         const int row = is_top ? task - H : task;
         const LcrCam &C = is_top ? top : front;
-        const int cam = is_top ? 1 : 0;
-        unsigned rowmask = 0u;
-        for (int k = 0; k < NPRIM; k++)
-            if (row >= S.bb[cam][k][2] && row <= S.bb[cam][k][3]) rowmask |= 1u << k;
-        rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+        const int x0 = is_top ? bx0[1] : bx0[0], x1 = is_top ? bx1[1] : bx1[0], y0 = is_top ? by0[1] : by0[0], y1 = is_top ? by1[1] : by1[0];
+        const bool in_row = lane < NPRIM && row >= y0 && row <= y1;
+        // per-row constants of the ray: rd(px) = rbase + X * sx(px), camera looks along -Z
+        const float sy = -(row + 0.5f - 0.5f * H) * C.s;
+        const f3 ro = mk(C.px, C.py, C.pz);
+        const f3 rbase = mk(C.yx * sy - C.zx, C.yy * sy - C.zy, C.yz * sy - C.zz);
 #pragma unroll
         for (int g = 0; g < 5; g++) {
-            unsigned m = 0u;
-            for (unsigned r = rowmask; r; r &= r - 1u) {
-                const int k = __builtin_ctz(r);
-                if (S.bb[cam][k][1] >= 64 * g && S.bb[cam][k][0] <= 64 * g + 63) m |= 1u << k;
-            }
-            m = __builtin_amdgcn_readfirstlane(m);
+            unsigned m = (unsigned)__ballot(in_row && x1 >= 64 * g && x0 <= 64 * g + 63);
             const int px = lane + 64 * g;
-            const f3 c = shade_pixel(C, W, H, S, px, row, m);
-            st[3 * px + 0] = (unsigned char)to_byte(c.x);
-            st[3 * px + 1] = (unsigned char)to_byte(c.y);
-            st[3 * px + 2] = (unsigned char)to_byte(c.z);
+            // refine: keep a capsule only if some pixel of this 64-pixel span lies inside its 2D silhouette
+            for (unsigned r = m & ((1u << NCAP) - 1u); r; r &= r - 1u) {
+                const int k = __builtin_ctz(r);
+                float sg[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    sg[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(is_top ? sgp[1][i] : sgp[0][i]), k));
+                const float pu = (float)px - sg[0], pv = (float)row - sg[1];
+                const float t = clampf((pu * sg[2] + pv * sg[3]) * sg[4], 0.f, 1.f);
+                const float eu = pu - t * sg[2], ev = pv - t * sg[3];
+                if (!__any(eu * eu + ev * ev <= sg[5])) m &= ~(1u << k);
+            }
+            const float sx = (px + 0.5f - 0.5f * W) * C.s;
+            const f3 rdu = axpy(sx, mk(C.xx, C.xy, C.xz), rbase);
+            const unsigned rgb = m ? pack_rgb(shade_pixel(C, S, rdu, m)) : shade_background(ro, rdu);
+            st[3 * px + 0] = (unsigned char)rgb;
+            st[3 * px + 1] = (unsigned char)(rgb >> 8);
+            st[3 * px + 2] = (unsigned char)(rgb >> 16);
         }
         if (lane < 60) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(st + 16 * lane);
@@ -238,17 +304,19 @@ __global__ __launch_bounds__(256) void lcr_render_single_kernel(LcrDev P, LcrCam
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= W * H) return;
     const int v = pix / W, u = pix - v * W;
-    const f3 c = shade_pixel(cam, W, H, S, u, v, (1u << NPRIM) - 1u);
-    out[3 * (size_t)pix + 0] = (unsigned char)to_byte(c.x);
-    out[3 * (size_t)pix + 1] = (unsigned char)to_byte(c.y);
-    out[3 * (size_t)pix + 2] = (unsigned char)to_byte(c.z);
+    const float sx = (u + 0.5f - 0.5f * W) * cam.s, sy = -(v + 0.5f - 0.5f * H) * cam.s;
+    const f3 rdu = mk(cam.xx * sx + cam.yx * sy - cam.zx, cam.xy * sx + cam.yy * sy - cam.zy, cam.xz * sx + cam.yz * sy - cam.zz);
+    const unsigned rgb = pack_rgb(shade_pixel(cam, S, rdu, (1u << NPRIM) - 1u));
+    out[3 * (size_t)pix + 0] = (unsigned char)rgb;
+    out[3 * (size_t)pix + 1] = (unsigned char)(rgb >> 8);
+    out[3 * (size_t)pix + 2] = (unsigned char)(rgb >> 16);
 }
 
 }  // namespace
 
 int lcr_launch_render_obs(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream) {
     if (!P.img_front || !P.img_top) return 0;
-    hipLaunchKernelGGL(lcr_render_obs_kernel, dim3(P.n, 4), dim3(256), 0, (hipStream_t)stream, P, front, top);
+    hipLaunchKernelGGL(lcr_render_obs_kernel, dim3(P.n, 2), dim3(256), 0, (hipStream_t)stream, P, front, top);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
