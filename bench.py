@@ -215,6 +215,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(task, action_mode)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            try:  # real MuJoCo only if it happens to be importable on this box
+                from tools import mujoco_opportunistic
+
+                out["cpu_baseline"]["mujoco_opportunistic"] = mujoco_opportunistic.run(300)
+            except Exception as e:
+                out["cpu_baseline"]["mujoco_opportunistic"] = {"status": "reference MuJoCo unavailable", "error": repr(e)}
         print(json.dumps(out), flush=True)
     for b in bufs:
         sim.free(b)

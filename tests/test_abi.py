@@ -83,3 +83,19 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "lcr_oracle" not in txt, f
+
+
+def test_opportunistic_mujoco_harness_is_inert_without_mujoco():
+    """the self-authored MJCF is well-formed XML and, MuJoCo being absent here, the harness says so"""
+    import xml.dom.minidom
+
+    from tools import mujoco_opportunistic as mo
+
+    doc = xml.dom.minidom.parseString(mo.build_mjcf())
+    assert len(doc.getElementsByTagName("joint")) == 6 and len(doc.getElementsByTagName("position")) == 6
+    assert len(doc.getElementsByTagName("freejoint")) == 1
+    res = mo.run(1)
+    try:
+        import mujoco  # noqa: F401
+    except Exception:
+        assert res == {"status": "reference MuJoCo unavailable"}
