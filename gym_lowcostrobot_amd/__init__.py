@@ -9,6 +9,6 @@ __version__ = "0.1.0"
 from .vecsim import VecSim  # noqa: F401
 from . import envs  # noqa: F401,E402
 from .envs import register_envs  # noqa: F401,E402
-from .vecenv import LowCostRobotVecEnv  # noqa: F401,E402
+from .vecenv import LowCostRobotVecEnv, LowCostRobotVectorEnv  # noqa: F401,E402
 
 register_envs()

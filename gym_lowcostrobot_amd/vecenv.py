@@ -96,3 +96,53 @@ class LowCostRobotVecEnv(_SB3VecEnv):
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         return [False] * self.num_envs
+
+
+class LowCostRobotVectorEnv:
+    """gymnasium.vector.VectorEnv-style API (gymnasium >= 1.0 conventions) over one VecSim:
+
+        obs, infos = venv.reset(seed=...)                       # seed: None | int (env i gets seed + i) | sequence of ints
+        obs, rewards, terminations, truncations, infos = venv.step(actions)
+
+    Autoreset happens in the SAME step (fused in the kernel): the returned observation of a finished env is its reset
+    observation, `infos["final_obs"]` holds the terminal observations and `infos["_final_obs"]` the mask, as with
+    gymnasium's AutoresetMode.SAME_STEP.  Arrays are batched numpy arrays, observations a dict of (N, .) float32.
+    """
+
+    def __init__(self, task, num_envs, seed=0, device=0, env_id_offset=0, **kw):
+        kw.setdefault("observation_mode", "state")
+        self._v = LowCostRobotVecEnv(task, num_envs, seed=seed, device=device, env_id_offset=env_id_offset, **kw)
+        self.num_envs = self._v.num_envs
+        self.single_action_space = self._v.action_space
+        self.single_observation_space = self._v.observation_space
+        self.task = task
+
+    def reset(self, *, seed=None, options=None):
+        sim = self._v.sim
+        if seed is None:
+            sim.reset()
+        elif np.isscalar(seed):
+            sim.reset(seeds=np.arange(self.num_envs, dtype=np.uint64) + np.uint64(int(seed)))
+        else:
+            sim.reset(seeds=np.asarray(seed, np.uint64))
+        return self._v._obs(), {}
+
+    def step(self, actions):
+        sim = self._v.sim
+        sim.step(np.asarray(actions, np.float32))
+        out = sim.outputs()
+        obs = self._v._obs()
+        infos = {}
+        if self.task != "lift":
+            infos["is_success"] = out["is_success"]
+        if out["did_reset"].any():
+            t = sim.terminal_obs.numpy().T
+            fin = {"arm_qpos": t[:, 0:6], "arm_qvel": t[:, 6:12], sim.cube_name: t[:, 12:15]}
+            if sim.aux_name:
+                fin[sim.aux_name] = t[:, 15:18]
+            infos["final_obs"] = fin
+            infos["_final_obs"] = out["did_reset"]
+        return obs, out["reward"].copy(), out["terminated"], out["truncated"], infos
+
+    def close(self):
+        self._v.close()

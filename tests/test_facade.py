@@ -149,3 +149,21 @@ def test_zero_copy_torch_views_and_device_actions(hip_lib):
     r = sim.reward.torch()
     assert r.shape == (n,) and torch.all((r == 0) | (r == -1))
     sim.close()
+
+
+@pytest.mark.gpu
+def test_vector_env_same_step_autoreset(hip_lib):
+    from gym_lowcostrobot_amd import LowCostRobotVectorEnv
+
+    n = 32
+    v = LowCostRobotVectorEnv("reach", n, max_episode_steps=4)
+    obs, infos = v.reset(seed=7)
+    assert infos == {} and obs["cube_pos"].shape == (n, 3)
+    obs_b, _ = v.reset(seed=7)
+    np.testing.assert_array_equal(obs["cube_pos"], obs_b["cube_pos"])
+    for t in range(4):
+        obs, r, term, trunc, infos = v.step(np.zeros((n, 5), np.float32))
+        assert r.shape == (n,) and term.dtype == bool and trunc.dtype == bool
+    assert trunc.all() and "final_obs" in infos and infos["_final_obs"].all()
+    assert np.abs(infos["final_obs"]["arm_qpos"]).max() > 0 and np.all(obs["arm_qpos"] == 0)   # terminal vs reset observation
+    v.close()
