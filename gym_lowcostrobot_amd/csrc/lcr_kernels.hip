@@ -383,24 +383,46 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         for (int s = 0; s < 4; s++) { FS[c][s].act = false; FS[c][s].r = mk(0.f, 0.f, 0.f); FS[c][s].Rn = 1.f;
 #pragma unroll
             for (int k = 0; k < 4; k++) { FS[c][s].f[k] = 0.f; FS[c][s].aref[k] = 0.f; FS[c][s].inv[k] = 0.f; } }
-        int cnt = 0;
         float sdist[4] = {0.f, 0.f, 0.f, 0.f};
+        // vertex i = (+-h, +-h, +-h) by bits 0,1,2 of i, relative to the cube centre
+        const f3 hx = CH * CR[c].X, hy = CH * CR[c].Y, hz = CH * CR[c].Z;
+        f3 rv[8];
+        float vd[8];
+        bool lower_same = true, upper_none = true;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
-            f3 rv = axpy(sx, CR[c].X, axpy(sy, CR[c].Y, sz * CR[c].Z));
-            float dist = S.cp[c].z + rv.z;
-            bool pen = dist < 0.f && cnt < 4;
+            f3 a = (i & 1) ? hx : neg(hx), b = (i & 2) ? hy : neg(hy), d = (i & 4) ? hz : neg(hz);
+            rv[i] = a + b + d;
+            vd[i] = S.cp[c].z + rv[i].z;
+            if (i >= 4) upper_none = upper_none && !(vd[i] < 0.f);
+            else if (i > 0) lower_same = lower_same && ((vd[i] < 0.f) == (vd[0] < 0.f));
+        }
+        if (__all(lower_same && upper_none)) {
+            // common case (upright cubes resting or airborne in every lane): the penetrating set is exactly {0,1,2,3} or
+            // empty, so slot s holds vertex s -- the same assignment as the general rule, without the select chains
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                bool take = pen && cnt == s;
-                FS[c][s].r.x = take ? rv.x : FS[c][s].r.x;
-                FS[c][s].r.y = take ? rv.y : FS[c][s].r.y;
-                FS[c][s].r.z = take ? rv.z - 0.5f * dist : FS[c][s].r.z;  // contact point midway between vertex and plane
-                sdist[s] = take ? dist : sdist[s];
-                FS[c][s].act = FS[c][s].act || take;
+                FS[c][s].r = mk(rv[s].x, rv[s].y, rv[s].z - 0.5f * vd[s]);
+                sdist[s] = vd[s];
+                FS[c][s].act = vd[s] < 0.f;
             }
-            cnt += pen ? 1 : 0;
+        } else {
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float dist = vd[i];
+                bool pen = dist < 0.f && cnt < 4;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    bool take = pen && cnt == s;
+                    FS[c][s].r.x = take ? rv[i].x : FS[c][s].r.x;
+                    FS[c][s].r.y = take ? rv[i].y : FS[c][s].r.y;
+                    FS[c][s].r.z = take ? rv[i].z - 0.5f * dist : FS[c][s].r.z;  // contact point midway between vertex and plane
+                    sdist[s] = take ? dist : sdist[s];
+                    FS[c][s].act = FS[c][s].act || take;
+                }
+                cnt += pen ? 1 : 0;
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -699,6 +721,14 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             // sphere vs box: closest point on the box in the box frame
             float bestd = 1e30f;
             pos = mk(0.f, 0.f, 0.f); n = mk(0.f, 0.f, 1.f);
+            // broad phase (wave-uniform): a sphere farther than r + h*sqrt(3) from every cube centre cannot touch
+            bool near_any = false;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const f3 dd = sph[sp] - S.cp[c];
+                near_any = near_any || dot(dd, dd) < (srad[sp] + 1.7321f * CH) * (srad[sp] + 1.7321f * CH);
+            }
+            if (__any(near_any))
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 f3 d = sph[sp] - S.cp[c];
