@@ -74,10 +74,12 @@ DEV void make_frame(f3 n, f3 &t1, f3 &t2) {
 }
 
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
-DEV f3 symv(const Sym3 &S, f3 v) {
-    return mk(fmaf(S.xx, v.x, fmaf(S.xy, v.y, S.xz * v.z)), fmaf(S.xy, v.x, fmaf(S.yy, v.y, S.yz * v.z)),
-              fmaf(S.xz, v.x, fmaf(S.yz, v.y, S.zz * v.z)));
+DEV f3 symv(const Sym3 &S, f3 v) {  // columns of a symmetric matrix: (xx,xy | xz) v.x + (xy,yy | yz) v.y + (xz,yz | zz) v.z
+    const f2v xy = f2v{S.xx, S.xy} * f2v{v.x, v.x} + f2v{S.xy, S.yy} * f2v{v.y, v.y} + f2v{S.xz, S.yz} * f2v{v.z, v.z};
+    return mk2(xy, fmaf(S.xz, v.x, fmaf(S.yz, v.y, S.zz * v.z)));
 }
+// w x (w x r) = w (w.r) - r |w|^2   (ww = |w|^2 is shared by the two uses per link)
+DEV f3 wxwxr(f3 w, f3 r, float ww) { return axpy(dot(w, r), w, (-ww) * r); }
 // world inertia about the link com: R Ic R^T with R = [X Y Z]
 DEV Sym3 world_inertia(f3 X, f3 Y, f3 Z, float ixx, float ixy, float ixz, float iyy, float iyz, float izz) {
     f3 Tx = axpy(ixx, X, axpy(ixy, Y, ixz * Z));
@@ -335,12 +337,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             f3 r = F.p[i] - pprev;
-            a = a + cross(wd, r) + cross(w, cross(w, r));  // acceleration of this link's origin (rigid with the parent)
+            a = a + cross(wd, r) + wxwxr(w, r, dot(w, w));  // acceleration of this link's origin (rigid with the parent)
             f3 zq = S.qd[i] * z[i];
             wd = wd + cross(w, zq);
             w = w + zq;
             f3 rc = com[i] - F.p[i];
-            f3 ac = a + cross(wd, rc) + cross(w, cross(w, rc));
+            f3 ac = a + cross(wd, rc) + wxwxr(w, rc, dot(w, w));
             Fi[i] = mass[i] * ac;
             Ni[i] = symv(Iw[i], wd) + cross(w, symv(Iw[i], w));
             pprev = F.p[i];
