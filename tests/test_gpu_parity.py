@@ -431,3 +431,24 @@ def test_free_running_statistics_match(hip_lib, task):
     assert abs(rew_h - rew_o) <= 0.01 * abs(rew_o) + 5 * sigma, (rew_h, rew_o)
     print(f"[free-run] {task}: successes hip {succ_h} oracle {succ_o}; still-close fraction at steps 1/5/20/50: {close}")
     sim.close()
+
+
+def test_compat_zero_qvel_on_reset(hip_lib):
+    """compat bit 0 deviates from REF-QUIRK-1 (the reference keeps qvel across reset): velocities are zeroed instead"""
+    rng = np.random.default_rng(51)
+    n = 128
+    for compat in (0, 1):
+        sim, o = util.make_pair("reach", n, max_episode_steps=2, compat=compat)
+        o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+        for t in range(2):
+            util.sync_oracle_to_f32(o); util.push_state(sim, o)
+            a = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+            o.step(a, threads=0); sim.step(a)
+        st = util.pull_state(sim)
+        assert o.did_reset.all() and sim.outputs()["did_reset"].all()
+        if compat:
+            assert np.all(st["qvel"] == 0) and np.all(o.qvel[:, :12] == 0)
+        else:
+            assert np.abs(st["qvel"][:, :6]).max() > 0.1                      # carried over, as in the reference
+            np.testing.assert_allclose(st["qvel"], o.qvel[:, :12], atol=2e-3)
+        sim.close()
