@@ -68,8 +68,8 @@ def cpu_baseline(task, action_mode, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="ReachCube-v0", choices=sorted(WORKLOADS))
     ap.add_argument("--pgs-iters", type=int, default=4)
