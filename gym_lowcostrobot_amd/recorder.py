@@ -1,0 +1,153 @@
+"""Episode recorder writing the on-disk layout of the reference's RecordHDF5Wrapper
+(gym_lowcostrobot/envs/wrappers/record_hdf5.py:52-61,111):
+
+    one file per episode  "{name_prefix}-episode-{id}.hdf5"  with datasets
+        observations/images/front   (T, 240, 320, 3) uint8      <- obs["image_front"]
+        observations/images/top     (T, 240, 320, 3) uint8      <- obs["image_top"]
+        observations/qpos           (T, 6) float32               <- obs["arm_qpos"]
+        observations/qvel           (T, 6) float32               <- obs["arm_qvel"]
+        action                      (T, k) float32
+
+h5py is used when it is importable; in images without it (this project's build image and GPU boxes) the same arrays go
+to "{...}.npz" under the same dataset names, so downstream code only switches the loader.
+
+`RecordHDF5Wrapper` wraps ONE gymnasium-style env (the reference's usage, examples/hdf5_record.py:9-21);
+`VecRecorder` records a chosen subset of a batched VecSim, one file per (env, episode).
+"""
+import os
+import warnings
+
+import numpy as np
+
+try:  # pragma: no cover - depends on the environment
+    import h5py
+except Exception:
+    h5py = None
+
+DATASETS = ("observations/images/front", "observations/images/top", "observations/qpos", "observations/qvel", "action")
+
+
+def write_episode(path_hdf5, observations, actions):
+    """observations: list of dicts (arm_qpos, arm_qvel, optional image_front/image_top); actions: list of arrays."""
+    data = {
+        "observations/qpos": np.stack([o["arm_qpos"] for o in observations]),
+        "observations/qvel": np.stack([o["arm_qvel"] for o in observations]),
+        "action": np.stack([np.asarray(a, np.float32) for a in actions]),
+    }
+    if "image_front" in observations[0]:
+        data["observations/images/front"] = np.stack([o["image_front"] for o in observations])
+        data["observations/images/top"] = np.stack([o["image_top"] for o in observations])
+    if h5py is not None:
+        with h5py.File(path_hdf5, "w") as f:
+            for k, v in data.items():
+                f.create_dataset(k, data=v)
+        return path_hdf5
+    path = os.path.splitext(path_hdf5)[0] + ".npz"
+    np.savez(path, **data)
+    return path
+
+
+def load_episode(path):
+    if path.endswith(".npz"):
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}
+    with h5py.File(path, "r") as f:  # pragma: no cover
+        return {k: f[k][()] for k in DATASETS if k in f}
+
+
+class RecordHDF5Wrapper:
+    """Single-env recorder with the reference's constructor arguments (record_hdf5.py:66-73)."""
+
+    def __init__(self, env, hdf5_folder, length=0, name_prefix="hdf5_record", disable_logger=False):
+        self.env = env
+        self.hdf5_folder = os.path.abspath(hdf5_folder)
+        if os.path.isdir(self.hdf5_folder) and not disable_logger:
+            warnings.warn(f"Overwriting existing recordings at {self.hdf5_folder}")
+        os.makedirs(self.hdf5_folder, exist_ok=True)
+        self.name_prefix = name_prefix
+        self.length = length
+        self.episode_id = 0
+        self.files = []
+        self._obs, self._act, self._path = [], [], None
+        if h5py is None and not disable_logger:
+            warnings.warn("h5py is not installed: episodes are written as .npz with the HDF5 dataset names")
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def _start(self):
+        self._flush()
+        self._path = os.path.join(self.hdf5_folder, f"{self.name_prefix}-episode-{self.episode_id}.hdf5")  # record_hdf5.py:111
+        self.episode_id += 1
+
+    def _flush(self):
+        if self._path is not None and self._obs:
+            self.files.append(write_episode(self._path, self._obs, self._act))
+        self._obs, self._act, self._path = [], [], None
+
+    def reset(self, **kwargs):
+        out = self.env.reset(**kwargs)
+        self._start()
+        return out
+
+    def step(self, action):
+        observations, reward, terminated, truncated, info = self.env.step(action)
+        if self._path is not None:
+            self._obs.append({k: np.array(v) for k, v in observations.items()})
+            self._act.append(np.array(action, np.float32))
+            if self.length > 0:
+                if len(self._obs) >= self.length:
+                    self._flush()
+            elif terminated or truncated:
+                self._start()  # closes the finished episode and opens the next file (record_hdf5.py:131-134)
+        return observations, reward, terminated, truncated, info
+
+    def close(self):
+        self._flush()
+        if hasattr(self.env, "close"):
+            self.env.close()
+
+
+class VecRecorder:
+    """Records env indices `which` of a VecSim while the caller steps it; call after_step(actions) once per step."""
+
+    def __init__(self, sim, folder, which=(0,), name_prefix="hdf5_record"):
+        self.sim, self.which = sim, list(which)
+        self.folder = os.path.abspath(folder)
+        os.makedirs(self.folder, exist_ok=True)
+        self.name_prefix = name_prefix
+        self.episode_id = {e: 0 for e in self.which}
+        self._obs = {e: [] for e in self.which}
+        self._act = {e: [] for e in self.which}
+        self.files = []
+
+    def after_step(self, actions):
+        """actions: (N, k) host array that was just applied"""
+        obs = self.sim.observations()
+        out = self.sim.outputs()
+        tobs = self.sim.terminal_obs.numpy().T if out["did_reset"].any() else None
+        for e in self.which:
+            o = {"arm_qpos": obs["arm_qpos"][e], "arm_qvel": obs["arm_qvel"][e]}
+            if out["did_reset"][e]:  # the kernel already reset this env: its last observation is the terminal one
+                o = {"arm_qpos": tobs[e, 0:6].copy(), "arm_qvel": tobs[e, 6:12].copy()}
+            elif "image_front" in obs:
+                o["image_front"], o["image_top"] = obs["image_front"][e], obs["image_top"][e]
+            self._obs[e].append(o)
+            self._act[e].append(np.asarray(actions[e], np.float32))
+            if out["did_reset"][e]:
+                self._flush(e)
+
+    def _flush(self, e):
+        if self._obs[e]:
+            keep = [o for o in self._obs[e]]
+            if any("image_front" in o for o in keep) and not all("image_front" in o for o in keep):
+                for o in keep:  # terminal frames of auto-reset envs have no image: drop the image datasets consistently
+                    o.pop("image_front", None); o.pop("image_top", None)
+            path = os.path.join(self.folder, f"{self.name_prefix}-env{e}-episode-{self.episode_id[e]}.hdf5")
+            self.files.append(write_episode(path, keep, self._act[e]))
+            self.episode_id[e] += 1
+        self._obs[e], self._act[e] = [], []
+
+    def close(self):
+        for e in self.which:
+            self._flush(e)

@@ -167,3 +167,21 @@ def test_vector_env_same_step_autoreset(hip_lib):
     assert trunc.all() and "final_obs" in infos and infos["_final_obs"].all()
     assert np.abs(infos["final_obs"]["arm_qpos"]).max() > 0 and np.all(obs["arm_qpos"] == 0)   # terminal vs reset observation
     v.close()
+
+
+@pytest.mark.gpu
+def test_vec_recorder_writes_reference_layout(hip_lib, tmp_path):
+    from gym_lowcostrobot_amd import VecSim, recorder
+
+    sim = VecSim("reach", 16, observation_mode="both", max_episode_steps=4)
+    rec = recorder.VecRecorder(sim, str(tmp_path), which=(0, 5))
+    rng = np.random.default_rng(0)
+    for t in range(9):
+        a = rng.uniform(-1, 1, (16, 5)).astype(np.float32)
+        sim.step(a)
+        rec.after_step(a)
+    rec.close()
+    assert len(rec.files) == 6                                     # two episodes of 4 steps + one partial, for two envs
+    ep = recorder.load_episode(sorted(rec.files)[0])
+    assert ep["observations/qpos"].shape == (4, 6) and ep["action"].shape == (4, 5)
+    sim.close()
