@@ -194,7 +194,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
     size_t o_img0 = off, o_img1 = off;
     const size_t img_bytes = (size_t)LCR_IMG_H * LCR_IMG_W * 3;
-    if (s->has_images) { o_img0 = off; off += al(img_bytes * N); o_img1 = off; off += al(img_bytes * N); }
+    size_t o_bg = off;
+    if (s->has_images) { o_img0 = off; off += al(img_bytes * N); o_img1 = off; off += al(img_bytes * N); o_bg = off; off += al(2 * img_bytes); }
     s->arena_bytes = off;
     e = hipMalloc(&s->arena, off);
     if (e != hipSuccess) { delete s; return fail(LCR_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(e)); }
@@ -266,6 +267,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.term_obs = (float *)(base + o_tobs);
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
+    D.img_bg = s->has_images ? (unsigned char *)(base + o_bg) : nullptr;
     make_cameras(cfg->task, s->cam_front, s->cam_top, s->cam_vizu);
     s->render_dev = nullptr;
     s->render_bytes = 0;
@@ -279,7 +281,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     // initial state: reset of seed (base_seed + global env id) for every env
     int rc = lcr_launch_reset(D, nullptr, nullptr, 1, cfg->base_seed, s->stream);
     if (rc) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); }
-    if (s->has_images) lcr_launch_render_obs(D, s->cam_front, s->cam_top, s->stream);
+    if (s->has_images) {
+        lcr_launch_render_bg(D, s->cam_front, s->cam_top, s->stream);
+        lcr_launch_render_obs(D, s->cam_front, s->cam_top, s->stream);
+    }
     e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e)); }
     *out = s;

@@ -45,6 +45,7 @@ struct LcrDev {
     float *term_obs;  // [18][n]
     // image observations
     unsigned char *img_front, *img_top;  // [n][240][320][3] or null
+    unsigned char *img_bg;               // [2][240][320][3] env-independent background of camera_front / camera_top, or null
 };
 
 // pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height
@@ -61,5 +62,6 @@ int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsig
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,
                             unsigned long long step, void *stream);
 int lcr_launch_render_obs(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream);
+int lcr_launch_render_bg(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream);
 int lcr_launch_render_single(const LcrDev &P, const LcrCam &cam, int env, int W, int H, unsigned char *out_dev, void *stream);
 int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream);
