@@ -198,7 +198,7 @@ def main():
         try:
             import glob
 
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]
             with open(pm) as f:
                 pj = json.load(f)
             pmc = pj["step_kernel_pmc_per_launch"]
@@ -210,6 +210,20 @@ def main():
                     "wait_frac_of_wave_cycles": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
                     "note": "one wave per SIMD at 65 536 envs; plain fp32 VALU issues ~1 instruction per 4 cycles per SIMD",
                 }
+                # flops: executed by the kernel (measured VALU instructions x flop weight of its instruction
+                # mix) and, for reference, the census of the CPU oracle's dense formulation (tools/count_flops.py)
+                with open(os.path.join(ROOT, "profiles", "flops.json")) as f:
+                    fj = json.load(f)
+                steps_per_s = out["value"] / world
+                mix = fj["kernel_isa_mix"]["flops_per_valu_instruction"]
+                kflops = out["valu"]["valu_insts_per_wave_per_launch"] * mix     # per lane == per env-step
+                out["valu"].update({
+                    "kernel_flops_per_env_step_est": kflops,
+                    "kernel_tflops_est": kflops * steps_per_s / 1e12,
+                    "frac_of_fp32_vector_peak": kflops * steps_per_s / 1e12 / VALU_PEAK_TFLOPS,
+                    "peak_tflops": VALU_PEAK_TFLOPS,
+                    "oracle_census_flops_per_env_step": fj["oracle_census_per_env_step"][args.workload]["flops"],
+                })
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:

@@ -69,10 +69,11 @@ _libs = {}
 
 
 def lib(f32=False):
-    key = bool(f32)
+    """f32: False -> fp64 oracle, True -> fp32-arithmetic twin, "count" -> flop-census build (instrumented scalar)"""
+    key = "count" if f32 == "count" else bool(f32)
     if key not in _libs:
         build()
-        name = "liblcr_oracle_f32.so" if f32 else "liblcr_oracle.so"
+        name = {False: "liblcr_oracle.so", True: "liblcr_oracle_f32.so", "count": "liblcr_oracle_count.so"}[key]
         L = ctypes.CDLL(os.path.join(_HERE, name))
         L.orc_rng_double.restype = ctypes.c_double
         L.orc_nq.restype = ctypes.c_int

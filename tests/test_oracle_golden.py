@@ -450,3 +450,23 @@ def test_ik_loop_golden(rec):
     np.testing.assert_allclose(qc, rec["q_target"], atol=2e-12)     # np.linalg.inv vs Cholesky: rounding only
     np.testing.assert_allclose(qs, rec["qpos_after"], atol=2e-12)
     np.testing.assert_allclose(sl, rec["site_after"], atol=2e-12)
+
+
+def test_flop_census_build_is_the_same_algorithm():
+    """the instrumented-scalar build used for the 'algorithmic flops' figure must compute exactly what the
+    fp64 oracle computes, and count a plausible number of operations"""
+    import ctypes
+    a, b = orc.Oracle("push", 4), orc.Oracle("push", 4, f32="count")
+    seeds = np.arange(4, dtype=np.uint64) + 9
+    a.reset(seeds); b.reset(seeds)
+    rng = np.random.default_rng(2)
+    b.L.orc_count_reset()
+    for _ in range(5):
+        act = rng.uniform(-1, 1, (4, a.action_dim)).astype(np.float32)
+        a.step(act, 1); b.step(act, 1)
+    np.testing.assert_array_equal(a.qpos, b.qpos)
+    np.testing.assert_array_equal(a.reward, b.reward)
+    out = (ctypes.c_uint64 * 7)()
+    b.L.orc_count_get(out)
+    flops = sum(list(out)[:5]) / (4 * 5)
+    assert 1e5 < flops < 5e6, flops
