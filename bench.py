@@ -55,7 +55,17 @@ def cpu_baseline(task, action_mode, budget_s=12.0):
         a = rng.uniform(-1, 1, (n, o.action_dim)).astype(np.float32)
         o.step(a, threads=threads)
     dt = time.perf_counter() - t0
+    # config 1 of BASELINE.json: one env on one thread (latency per control step)
+    o1 = orc.Oracle(task, 1, action_mode={"joint": 0, "ee": 1}[action_mode])
+    o1.reset(seeds=np.zeros(1, np.uint64))
+    a1 = rng.uniform(-1, 1, (200, 1, o1.action_dim)).astype(np.float32)
+    t1 = time.perf_counter()
+    for i in range(200):
+        o1.step(a1[i], threads=1)
+    dt1 = time.perf_counter() - t1
     return {
+        "single_env_single_thread": {"value": 200 / dt1, "unit": "env-steps/s", "ms_per_step": 1e3 * dt1 / 200},
+        "value_per_core": n * steps / dt / threads,
         "value": n * steps / dt,
         "unit": "env-steps/s",
         "cores": threads,
