@@ -96,6 +96,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hooks (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): several ranks may share GPU 0 and rendezvous
+    # over gloo, which exercises the whole N>1 code path on a 1-GPU box; the driver's runs use neither
+    backend = os.environ.get("LCR_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("LCR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
@@ -104,7 +109,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     else:
         torch.cuda.set_device(local_rank)
@@ -142,7 +150,7 @@ def main():
         if i == args.steps - 1:
             ev["ms"] = sim.timer_end()
 
-    dt, _ = sharding.timed_region(run, args.steps, dist=dist, device_sync=torch.cuda.synchronize, tensor_device="cuda")
+    dt, _ = sharding.timed_region(run, args.steps, dist=dist, device_sync=torch.cuda.synchronize, tensor_device="cuda" if backend == "nccl" else "cpu")
     ev_ms = ev["ms"]
 
     calib_bytes = 0

@@ -475,3 +475,21 @@ def test_compat_zero_qvel_on_reset(hip_lib):
             assert np.abs(st["qvel"][:, :6]).max() > 0.1                      # carried over, as in the reference
             np.testing.assert_allclose(st["qvel"], o.qvel[:, :12], atol=2e-3)
         sim.close()
+
+
+def test_bench_two_ranks_on_one_gpu(hip_lib):
+    """bench.py's N>1 path end to end (torchrun launch line of the driver, env-id sharding, barrier + MAX-over-ranks timing,
+    ONE JSON line from rank 0) with two ranks sharing this box's single GPU and rendezvousing over gloo"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LCR_BENCH_DIST_BACKEND="gloo", LCR_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+           "--envs-per-gpu", "4096", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["scaling"] == "weak" and j["config"]["global_envs"] == 8192
+    assert j["value"] == pytest.approx(8192 * 20 / (j["ms_per_step"] * 20e-3), rel=1e-6) and j["state_finite"]
