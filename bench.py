@@ -30,6 +30,8 @@ WORKLOADS = {
     "PickPlaceCube-v0": ("pick_place", "ee", 338),
     "LiftCube-v0": ("lift", "joint", 294),
     "StackTwoCubes-v0": ("stack", "joint", 414),
+    # Reach layout + current_goal r/w (8) + accumulated sim time f64 r/w (16); obs has no cube/target aux (-0)
+    "PushCubeLoop-v0": ("push_loop", "joint", 318),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
