@@ -138,6 +138,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         return fail(LCR_ERR_INVALID, "lcr_config size mismatch (got %u, want %zu): ABI version skew", cfg->struct_size, sizeof(lcr_config));
     if (cfg->task < LCR_TASK_REACH || cfg->task > LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_INVALID, "unknown task %d", cfg->task);
     if (cfg->n_envs <= 0) return fail(LCR_ERR_INVALID, "n_envs must be positive");
+    // the kernels index [component][env] arrays with 32-bit products (20 components at most): keep 20 * n_envs < 2^31
+    if (cfg->n_envs > (1 << 26)) return fail(LCR_ERR_INVALID, "n_envs %d exceeds 67108864 per handle; shard the batch over several handles", cfg->n_envs);
     if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
     if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters must be >= 0");
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");

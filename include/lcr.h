@@ -63,7 +63,7 @@ enum {
 typedef struct lcr_config {
     uint32_t struct_size;      /* = sizeof(lcr_config), ABI check */
     int32_t task;              /* lcr_task */
-    int32_t n_envs;            /* envs on this GPU */
+    int32_t n_envs;            /* envs on this GPU, 1 .. 67 108 864 (2^26) per handle */
     int32_t device;            /* HIP device ordinal */
     int64_t env_id_offset;     /* global id of env 0 (sharding: GPU g owns [g*N/G, (g+1)*N/G)) */
     int32_t action_mode;

@@ -56,6 +56,9 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
     hip_lib.lcr_config_default(ctypes.byref(cfg), 0)
     cfg.n_envs = 0
     assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
+    cfg.n_envs = (1 << 26) + 1
+    assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
+    assert b"shard" in hip_lib.lcr_last_error()
     hip_lib.lcr_config_default(ctypes.byref(cfg), 0)
     cfg.action_mode = 7
     assert hip_lib.lcr_action_dim(ctypes.byref(cfg)) == _capi.LCR_ERR_INVALID
