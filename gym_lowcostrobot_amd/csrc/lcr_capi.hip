@@ -327,7 +327,10 @@ int lcr_reset(lcr_sim *s, const uint8_t *mask_host, const uint64_t *seeds_host) 
     if (seeds_host) HIPCHK(hipMemcpyAsync(s->seeds_dev, seeds_host, N * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
     int rc = lcr_launch_reset(s->dev, mask_host ? s->mask_dev : nullptr, seeds_host ? s->seeds_dev : nullptr, 0, 0, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (s->has_images) lcr_launch_render_obs(s->dev, s->cam_front, s->cam_top, s->stream);
+    if (s->has_images) {
+        rc = lcr_launch_render_obs(s->dev, s->cam_front, s->cam_top, s->stream);
+        if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
     // the staging copies above read caller memory: do not return before they are consumed
     if (mask_host || seeds_host) HIPCHK(hipStreamSynchronize(s->stream));
     return LCR_OK;
