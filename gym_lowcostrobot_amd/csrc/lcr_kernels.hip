@@ -623,9 +623,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     }
 
     // ---- collision: PushCubeLoop rails.  The four wall boxes act as their inner faces (vertical half-spaces below the wall
-    //      top); per wall (left, right, top, bottom) the two deepest cube vertices beyond its face, at most 4 in total. ----
-    FloorSlot WS[4];   // same record as a floor slot; the frame depends on the wall
-    int wall_id[4] = {0, 0, 0, 0};
+    //      top).  The pen is wider than the cube in both directions, so at most one x rail and one y rail can be touched:
+    //      slots 0,1 belong to the x pair (left rail if any vertex is beyond it, else right), slots 2,3 to the y pair
+    //      (bottom if touched, else top); each pair keeps its two deepest vertices.  With axis-aligned normals the rows
+    //      have the closed form of the floor rows; the y pair is the x pair under the cyclic relabelling x->y->z->x. ----
+    FloorSlot WS[4];   // r holds the contact point in the pair's (cyclically permuted) coordinates
+    float wsg[2] = {1.f, 1.f};   // sign of the pair's normal along its axis
     bool wall_any = false;
     if constexpr (WALLS) {
 #pragma unroll
@@ -634,20 +637,26 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int k = 0; k < 4; k++) { WS[s].f[k] = 0.f; WS[s].aref[k] = 0.f; WS[s].inv[k] = 0.f; } }
         f3 vw[8];
         float worst = 1.f;
+        bool lo_x = false, lo_y = false;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
             vw[i] = axpy(sx, CR[0].X, axpy(sy, CR[0].Y, sz * CR[0].Z));   // relative to the cube centre
             const f3 p = vw[i] + S.cp[0];
+            const bool low = p.z < WALL_TOP;
             const float dmin = fminf(fminf(p.x + WALL_X, WALL_X - p.x), fminf(p.y - WALL_Y0, WALL_Y1 - p.y));
-            worst = fminf(worst, p.z < WALL_TOP ? dmin : 1.f);
+            worst = fminf(worst, low ? dmin : 1.f);
+            lo_x = lo_x || (low && p.x + WALL_X < 0.f);
+            lo_y = lo_y || (low && p.y - WALL_Y0 < 0.f);
         }
         wall_any = __any(worst < 0.f) != 0;
         if (wall_any) {
-            int cnt = 0;
-            float wdist[4] = {0.f, 0.f, 0.f, 0.f};
+            wsg[0] = lo_x ? 1.f : -1.f;
+            wsg[1] = lo_y ? 1.f : -1.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int pr = 0; pr < 2; pr++) {
+                const float sg = wsg[pr];
+                const float off = pr == 0 ? WALL_X : (sg > 0.f ? -WALL_Y0 : WALL_Y1);
                 // the two deepest vertices beyond this face (ties: lower vertex index first)
                 float d1 = 0.f, d2 = 0.f;
                 bool h1 = false, h2 = false;
@@ -655,11 +664,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const f3 p = vw[i] + S.cp[0];
-                    const float dist = w == 0 ? p.x + WALL_X : (w == 1 ? WALL_X - p.x : (w == 2 ? p.y - WALL_Y0 : WALL_Y1 - p.y));
+                    const float dist = fmaf(sg, pr == 0 ? p.x : p.y, off);
                     const bool pen = dist < 0.f && p.z < WALL_TOP;
                     const bool first = pen && (!h1 || dist < d1);
                     const bool second = pen && !first && (!h2 || dist < d2);
-                    // demote the current best when a deeper one arrives
                     d2 = first ? d1 : (second ? dist : d2);
                     r2 = first ? r1 : (second ? vw[i] : r2);
                     h2 = first ? h1 : (second ? true : h2);
@@ -667,51 +675,42 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     r1 = first ? vw[i] : r1;
                     h1 = h1 || first;
                 }
-                const float nx = w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), ny = w == 2 ? 1.f : (w == 3 ? -1.f : 0.f);
+                // pair coordinates (a, b, c) = (x, y, z) for the x pair, (y, z, x) for the y pair
+                const f3 v = pr == 0 ? S.cv[0] : mk(S.cv[0].y, S.cv[0].z, S.cv[0].x);
+                const f3 w = pr == 0 ? cww[0] : mk(cww[0].y, cww[0].z, cww[0].x);
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const bool have = (c == 0 ? h1 : h2) && cnt < 4;
+                    FloorSlot &T = WS[2 * pr + c];
                     const float dist = c == 0 ? d1 : d2;
-                    const f3 rv = c == 0 ? r1 : r2;
+                    const f3 rw = c == 0 ? r1 : r2;
+                    T.act = c == 0 ? h1 : h2;
+                    f3 r = pr == 0 ? rw : mk(rw.y, rw.z, rw.x);
+                    r.x = fmaf(-0.5f * dist, sg, r.x);   // contact point midway between vertex and face
+                    T.r = r;
+                    float imp = impedance(dist, D0_DEF, DW_DEF, 1.0f / W_DEF);
+                    float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
+                    float Rf = Rn * P.inv_impratio;
+                    float Rt = Rf * P.rt_cube;
+                    T.Rn = Rn;
+                    const f3 vp = v + cross(w, r);   // velocity of the contact point; n = (sg,0,0), t1 = (0,1,0), t2 = (0,0,sg)
+                    T.aref[0] = -B_DEF * sg * vp.x - K_DEF * imp * dist;
+                    T.aref[1] = -B_DEF * vp.y;
+                    T.aref[2] = -B_DEF * sg * vp.z;
+                    T.aref[3] = -B_DEF * sg * w.x;
+                    T.inv[0] = rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn);
+                    T.inv[1] = rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf);
+                    T.inv[2] = rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf);
+                    T.inv[3] = rcp(iinv + Rt);
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        const bool take = have && cnt == s;
-                        WS[s].r.x = take ? rv.x - 0.5f * dist * nx : WS[s].r.x;
-                        WS[s].r.y = take ? rv.y - 0.5f * dist * ny : WS[s].r.y;
-                        WS[s].r.z = take ? rv.z : WS[s].r.z;
-                        wdist[s] = take ? dist : wdist[s];
-                        wall_id[s] = take ? w : wall_id[s];
-                        WS[s].act = WS[s].act || take;
-                    }
-                    cnt += have ? 1 : 0;
+                    for (int k = 0; k < 4; k++) T.f[k] = T.act ? W.wall[2 * pr + c][k] : 0.f;   // warm start
+                    // a += M^-1 J^T f in pair coordinates
+                    const float la = minv * sg * T.f[0], lb = minv * T.f[1], lc = minv * sg * T.f[2];
+                    const float aa = iinv * (-r.z * T.f[1] + sg * r.y * T.f[2] + sg * T.f[3]);
+                    const float ab = iinv * sg * (r.z * T.f[0] - r.x * T.f[2]);
+                    const float ac = iinv * (-sg * r.y * T.f[0] + r.x * T.f[1]);
+                    if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
+                    else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
                 }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                FloorSlot &T = WS[s];
-                const int w = wall_id[s];
-                const f3 n = mk(w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), w == 2 ? 1.f : (w == 3 ? -1.f : 0.f), 0.f);
-                const f3 t1 = w < 2 ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f);   // mju_makeFrame of an axis-aligned normal
-                const f3 t2 = cross(n, t1);
-                float imp = impedance(wdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
-                float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
-                float Rf = Rn * P.inv_impratio;
-                float Rt = Rf * P.rt_cube;
-                T.Rn = Rn;
-                const f3 vp = S.cv[0] + cross(cww[0], T.r);
-                const f3 c0 = cross(T.r, n), c1 = cross(T.r, t1), c2 = cross(T.r, t2);
-                T.aref[0] = -B_DEF * dot(n, vp) - K_DEF * imp * wdist[s];
-                T.aref[1] = -B_DEF * dot(t1, vp);
-                T.aref[2] = -B_DEF * dot(t2, vp);
-                T.aref[3] = -B_DEF * dot(n, cww[0]);
-                T.inv[0] = rcp(minv + iinv * dot(c0, c0) + Rn);
-                T.inv[1] = rcp(minv + iinv * dot(c1, c1) + Rf);
-                T.inv[2] = rcp(minv + iinv * dot(c2, c2) + Rf);
-                T.inv[3] = rcp(iinv + Rt);
-#pragma unroll
-                for (int k = 0; k < 4; k++) T.f[k] = T.act ? W.wall[s][k] : 0.f;   // warm start
-                ca[0] = axpy(minv * T.f[0], n, axpy(minv * T.f[1], t1, axpy(minv * T.f[2], t2, ca[0])));
-                cal[0] = axpy(iinv * T.f[0], c0, axpy(iinv * T.f[1], c1, axpy(iinv * T.f[2], c2, axpy(iinv * T.f[3], n, cal[0]))));
             }
         }
     }
@@ -1000,41 +999,42 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
         }
-        // rails (PushCubeLoop)
+        // rails (PushCubeLoop): block form of the four rows of each contact, as for the floor
         if constexpr (WALLS) {
             if (wall_any) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     FloorSlot &T = WS[s];
-                    const int w = wall_id[s];
-                    const f3 n = mk(w == 0 ? 1.f : (w == 1 ? -1.f : 0.f), w == 2 ? 1.f : (w == 3 ? -1.f : 0.f), 0.f);
-                    const f3 t1 = w < 2 ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f);
-                    const f3 t2 = cross(n, t1);
+                    const int pr = s >> 1;
+                    const float sg = wsg[pr];
+                    const f3 r = T.r;
                     const float Rf = T.Rn * P.inv_impratio, Rt = Rf * P.rt_cube;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const f3 d = r == 0 ? n : (r == 1 ? t1 : (r == 2 ? t2 : n));
-                        const f3 c = cross(T.r, d);
-                        const float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
-                        float res = (r < 3 ? dot(d, ca[0]) + dot(c, cal[0]) : dot(d, cal[0])) - T.aref[r] + Rr * T.f[r];
-                        float nf = T.f[r] - res * T.inv[r];
-                        if (r == 0) nf = fmaxf(nf, 0.f);
-                        const float dlt = T.act ? nf - T.f[r] : 0.f;
-                        T.f[r] += dlt;
-                        if (r < 3) { ca[0] = axpy(minv * dlt, d, ca[0]); cal[0] = axpy(iinv * dlt, c, cal[0]); }
-                        else cal[0] = axpy(iinv * dlt, d, cal[0]);
-                    }
-                    const float fn = T.f[0];
-                    const float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * P.inv_mu_c2 + T.f[3] * T.f[3] * P.inv_mu_ct2;
+                    const f3 a = pr == 0 ? ca[0] : mk(ca[0].y, ca[0].z, ca[0].x);
+                    const f3 w = pr == 0 ? cal[0] : mk(cal[0].y, cal[0].z, cal[0].x);
+                    const float u0 = sg * (a.x + r.z * w.y - r.y * w.z) - T.aref[0] + T.Rn * T.f[0];
+                    const float u1 = a.y - r.z * w.x + r.x * w.z - T.aref[1] + Rf * T.f[1];
+                    const float u2 = sg * (a.z + r.y * w.x - r.x * w.y) - T.aref[2] + Rf * T.f[2];
+                    const float u3 = sg * w.x - T.aref[3] + Rt * T.f[3];
+                    const float B01 = -sg * iinv * r.x * r.y, B02 = -iinv * r.x * r.z, B12 = -sg * iinv * r.y * r.z;
+                    const float B13 = -sg * iinv * r.z, B23 = iinv * r.y;
+                    const float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
+                    const float d0 = T.act ? nf - T.f[0] : 0.f;
+                    const float d1a = T.act ? -(u1 + B01 * d0) * T.inv[1] : 0.f;
+                    const float d2a = T.act ? -(u2 + B02 * d0 + B12 * d1a) * T.inv[2] : 0.f;
+                    const float d3a = T.act ? -(u3 + B13 * d1a + B23 * d2a) * T.inv[3] : 0.f;
+                    // elliptic cone: radial projection of the friction part
+                    const float fn = T.f[0] + d0;
+                    const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
                     const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
-#pragma unroll
-                    for (int r = 1; r < 4; r++) {
-                        const f3 d = r == 1 ? t1 : (r == 2 ? t2 : n);
-                        const float dlt = T.f[r] * sc - T.f[r];
-                        T.f[r] += dlt;
-                        if (r < 3) { ca[0] = axpy(minv * dlt, d, ca[0]); cal[0] = axpy(iinv * dlt, cross(T.r, d), cal[0]); }
-                        else cal[0] = axpy(iinv * dlt, d, cal[0]);
-                    }
+                    const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
+                    T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                    const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
+                    const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
+                    const float ab = iinv * sg * (r.z * d0 - r.x * d2);
+                    const float ac = iinv * (-sg * r.y * d0 + r.x * d1);
+                    if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
+                    else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
                 }
             }
         }

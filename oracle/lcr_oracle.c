@@ -469,9 +469,10 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     return 1;
 }
 /* (D7) PushCubeLoop rails (push_cube_loop.xml:44-47): the four wall boxes are restated as their inner faces -- vertical
- * half-spaces that only act below the wall top (z < 0.012).  Cube vertices beyond a face (in wall order left, right,
- * top, bottom) give contacts: the two deepest per wall, at most 4 in total (so that a corner keeps both walls);
- * frame normal points from the wall into the pen. */
+ * half-spaces that only act below the wall top (z < 0.012).  The pen is wider than the cube in x and in y, so the cube
+ * can reach at most one x rail and one y rail: contact slots 8,9 belong to the x pair (the x = -0.115 rail if any vertex
+ * is beyond it, else the x = +0.115 rail), slots 10,11 to the y pair (y = 0.10 rail if touched, else y = 0.17); each
+ * pair keeps its two deepest vertices (ties: lower vertex index first).  Frame normal points from the wall into the pen. */
 static int collide_walls(const kin_t *K, contact_t *out) {
     int n = 0;
     real P[8][3];
@@ -481,10 +482,17 @@ static int collide_walls(const kin_t *K, contact_t *out) {
         m3v(P[i], K->cR[0], v);
         v3add(P[i], P[i], K->cp[0]);
     }
-    for (int w = 0; w < 4; w++) {
+    for (int pr = 0; pr < 2; pr++) {
+        /* which rail of the pair: the low-coordinate one if any vertex is beyond it */
+        int lo = 0;
+        for (int i = 0; i < 8; i++) {
+            const real *p = P[i];
+            real dist = pr == 0 ? p[0] + (real)WALL_X : p[1] - (real)WALL_Y0;
+            if (dist < 0 && p[2] < (real)WALL_TOP) lo = 1;
+        }
+        int w = 2 * pr + (lo ? 0 : 1);
         real nw[3] = {0, 0, 0};
         if (w == 0) nw[0] = 1; else if (w == 1) nw[0] = -1; else if (w == 2) nw[1] = 1; else nw[1] = -1;
-        /* the two deepest vertices beyond this face (ties: lower vertex index first) */
         real d1 = 0, d2 = 0; int i1 = -1, i2 = -1;
         for (int i = 0; i < 8; i++) {
             const real *p = P[i];
@@ -493,12 +501,12 @@ static int collide_walls(const kin_t *K, contact_t *out) {
             if (i1 < 0 || dist < d1) { d2 = d1; i2 = i1; d1 = dist; i1 = i; }
             else if (i2 < 0 || dist < d2) { d2 = dist; i2 = i; }
         }
-        for (int c = 0; c < 2 && n < 4; c++) {
+        for (int c = 0; c < 2; c++) {
             int i = c == 0 ? i1 : i2;
             real dist = c == 0 ? d1 : d2;
             if (i < 0) continue;
             contact_t *ct = &out[n];
-            ct->slot = 8 + n;
+            ct->slot = 8 + 2 * pr + c;
             n++;
             ct->b1 = -1; ct->b2 = 6; ct->dist = dist;
             v3set(ct->pos, P[i][0] - nw[0] * dist * (real)0.5, P[i][1] - nw[1] * dist * (real)0.5, P[i][2]);
