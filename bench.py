@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--pgs-iters", type=int, default=4)
     ap.add_argument("--obs", default="state", choices=["state", "both"], help="both: also ray-cast the two 240x320x3 observation frames per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-tasks", action="store_true", help="BASELINE.md B2: also time the CPU oracle on every workload (adds ~1 min)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for a single rank (tests the N>1 code path on one GPU)")
     ap.add_argument("--calibrate", type=int, default=0, help="after timing, launch the known-byte-count copy kernel this many times (PMC calibration)")
     args = ap.parse_args()
@@ -249,6 +250,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(task, action_mode)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if args.cpu_all_tasks:
+                out["cpu_baseline"]["all_tasks"] = {w: {k: v for k, v in cpu_baseline(t, m, budget_s=6.0).items() if k in ("value", "value_per_core", "cores", "sample")}
+                                                    for w, (t, m, _) in WORKLOADS.items()}
             try:  # real MuJoCo only if it happens to be importable on this box
                 from tools import mujoco_opportunistic
 
