@@ -948,54 +948,54 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
             }
         }
-        // cube <-> cube (Stack)
+        // cube <-> cube (Stack): block form of the four rows of each contact.  With an orthonormal frame the couplings between
+        // the rows need only the projections of the two lever arms on the frame: (r x d_i).(r x d_j) = -(r.d_i)(r.d_j), i != j.
         if constexpr (NC == 2) {
             if (cc_any) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
+                    const bool act = cc_act[s];
                     const f3 pos = mk(ccl[(s * CC_REC + 0) * 64], ccl[(s * CC_REC + 1) * 64], ccl[(s * CC_REC + 2) * 64]);
                     const f3 r0 = pos - S.cp[0], r1 = pos - S.cp[1];
                     const float Rn = ccl[(s * CC_REC + 15) * 64];
                     const float Rf = Rn * P.inv_impratio;
                     const float Rt = Rf * P.rt_cube;
-                    float f[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) f[r] = ccl[(s * CC_REC + 3 + r) * 64];
+                    float f[4], aref[4], inv[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
-                        const float aref = ccl[(s * CC_REC + 7 + r) * 64], inv = ccl[(s * CC_REC + 11 + r) * 64];
-                        const float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
-                        f3 a0 = mk(0.f, 0.f, 0.f), a1 = mk(0.f, 0.f, 0.f);
-                        float ja;
-                        if (r < 3) { a0 = cross(r0, d); a1 = cross(r1, d); ja = dot(d, ca[1] - ca[0]) + dot(a1, cal[1]) - dot(a0, cal[0]); }
-                        else ja = dot(d, cal[1] - cal[0]);
-                        float res = ja - aref + Rr * f[r];
-                        float nf = f[r] - res * inv;
-                        if (r == 0) nf = fmaxf(nf, 0.f);
-                        float dlt = cc_act[s] ? nf - f[r] : 0.f;
-                        f[r] += dlt;
-                        if (r < 3) {
-                            ca[1] = axpy(minv * dlt, d, ca[1]); ca[0] = axpy(-minv * dlt, d, ca[0]);
-                            cal[1] = axpy(iinv * dlt, a1, cal[1]); cal[0] = axpy(-iinv * dlt, a0, cal[0]);
-                        } else { cal[1] = axpy(iinv * dlt, d, cal[1]); cal[0] = axpy(-iinv * dlt, d, cal[0]); }
+                        f[r] = ccl[(s * CC_REC + 3 + r) * 64];
+                        aref[r] = ccl[(s * CC_REC + 7 + r) * 64];
+                        inv[r] = ccl[(s * CC_REC + 11 + r) * 64];
                     }
-                    float fn = f[0];
-                    float s2 = (f[1] * f[1] + f[2] * f[2]) * P.inv_mu_c2 + f[3] * f[3] * P.inv_mu_ct2;
-                    float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
-#pragma unroll
-                    for (int r = 1; r < 4; r++) {
-                        const f3 d = r == 1 ? cct1 : (r == 2 ? cct2 : ccn);
-                        float dlt = f[r] * sc - f[r];
-                        f[r] += dlt;
-                        if (r < 3) {
-                            f3 a0 = cross(r0, d), a1 = cross(r1, d);
-                            ca[1] = axpy(minv * dlt, d, ca[1]); ca[0] = axpy(-minv * dlt, d, ca[0]);
-                            cal[1] = axpy(iinv * dlt, a1, cal[1]); cal[0] = axpy(-iinv * dlt, a0, cal[0]);
-                        } else { cal[1] = axpy(iinv * dlt, d, cal[1]); cal[0] = axpy(-iinv * dlt, d, cal[0]); }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) ccl[(s * CC_REC + 3 + r) * 64] = f[r];
+                    // relative acceleration of the contact point (cube 1 minus cube 0) and relative angular acceleration
+                    const f3 A = (ca[1] + cross(cal[1], r1)) - (ca[0] + cross(cal[0], r0));
+                    const f3 Wr = cal[1] - cal[0];
+                    const float u0 = dot(ccn, A) - aref[0] + Rn * f[0];
+                    const float u1 = dot(cct1, A) - aref[1] + Rf * f[1];
+                    const float u2 = dot(cct2, A) - aref[2] + Rf * f[2];
+                    const float u3 = dot(ccn, Wr) - aref[3] + Rt * f[3];
+                    const float p00 = dot(r0, ccn), p01 = dot(r0, cct1), p02 = dot(r0, cct2);
+                    const float p10 = dot(r1, ccn), p11 = dot(r1, cct1), p12 = dot(r1, cct2);
+                    const float B01 = -iinv * (p00 * p01 + p10 * p11), B02 = -iinv * (p00 * p02 + p10 * p12), B12 = -iinv * (p01 * p02 + p11 * p12);
+                    const float B13 = -iinv * (p02 + p12), B23 = iinv * (p01 + p11);   // n.((r0+r1) x t1) = -(r0+r1).t2, n.((r0+r1) x t2) = (r0+r1).t1
+                    const float nf = fmaxf(f[0] - u0 * inv[0], 0.f);
+                    const float d0 = act ? nf - f[0] : 0.f;
+                    const float d1a = act ? -(u1 + B01 * d0) * inv[1] : 0.f;
+                    const float d2a = act ? -(u2 + B02 * d0 + B12 * d1a) * inv[2] : 0.f;
+                    const float d3a = act ? -(u3 + B13 * d1a + B23 * d2a) * inv[3] : 0.f;
+                    // elliptic cone: radial projection of the friction part
+                    const float fn = f[0] + d0;
+                    const float g1 = f[1] + d1a, g2 = f[2] + d2a, g3 = f[3] + d3a;
+                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                    const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                    const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
+                    ccl[(s * CC_REC + 3) * 64] = fn; ccl[(s * CC_REC + 4) * 64] = f[1] + e1;
+                    ccl[(s * CC_REC + 5) * 64] = f[2] + e2; ccl[(s * CC_REC + 6) * 64] = f[3] + e3;
+                    // a += M^-1 J^T delta: the force change F acts at the contact point on cube 1 and, negated, on cube 0
+                    const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
+                    const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
+                    ca[1] = axpy(minv, Fd, ca[1]); ca[0] = axpy(-minv, Fd, ca[0]);
+                    cal[1] = axpy(iinv, T1, cal[1]); cal[0] = axpy(-iinv, T0, cal[0]);
                 }
             }
         }
