@@ -1066,18 +1066,41 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
                 const bool second = vs_cube && NC == 2 && slot_cube[sp] == 1;
                 if (vs_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
-                f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // accumulated change of the cube acceleration
+                // The cube's share of the four row residuals is tracked as SCALARS: v_r = d_r . (acceleration of the contact
+                // point of the cube), wn = n . (angular acceleration).  A force change dlt on row j moves them by closed-form
+                // couplings, because (rc x d_i).(rc x d_j) = |rc|^2 delta_ij - (rc.d_i)(rc.d_j) for the orthonormal frame:
+                //   v_i -= dlt (k delta_ij - iinv p_i p_j), k = minv + iinv |rc|^2, p_i = rc . d_i;   wn -= iinv dlt n.(rc x d_j)
+                // and the summed force is applied to the cube once at the end of the slot.
+                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f;
+                float f_in[4] = {T.f[0], T.f[1], T.f[2], T.f[3]};
+                if (vs_cube) {
+                    const f3 Ac = a_lin + cross(a_ang, T.rc);
+                    vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
+                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
+                    wn = dot(T.n, a_ang);
+                    kq = fmaf(iinv, dot(T.rc, T.rc), minv);
+                }
+                // effect of a force change dlt on row j on the tracked scalars
+                auto couple = [&](int j, float dlt) {
+                    if (j < 3) {
+                        const float c = iinv * pq[j] * dlt;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
+                        vq[j] = fmaf(-kq, dlt, vq[j]);
+                        // n.(rc x t1) = -rc.t2, n.(rc x t2) = rc.t1, n.(rc x n) = 0
+                        if (j == 1) wn = fmaf(iinv * dlt, pq[2], wn);
+                        if (j == 2) wn = fmaf(-iinv * dlt, pq[1], wn);
+                    } else {   // torsion: angular acceleration changes by -iinv dlt n; contact point by (-iinv dlt n) x rc
+                        wn = fmaf(-iinv, dlt, wn);
+                        vq[1] = fmaf(iinv * dlt, pq[2], vq[1]);    // t1.(n x rc) = -p_2
+                        vq[2] = fmaf(-iinv * dlt, pq[1], vq[2]);   // t2.(n x rc) =  p_1
+                    }
+                };
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
                     const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
                     const float gy = acc.x + acc.y;
-                    f3 rxd = mk(0.f, 0.f, 0.f);
-                    float jc_a = 0.f;
-                    if (vs_cube) {
-                        if (r < 3) { rxd = cross(T.rc, d); jc_a = -(dot(d, a_lin + dl_lin) + dot(rxd, a_ang + dl_ang)); }
-                        else jc_a = -dot(d, a_ang + dl_ang);
-                    }
+                    const float jc_a = vs_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
                     const float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
                     float res = gy + jc_a - arefv[r] + Rr * T.f[r];
                     float nf = T.f[r] - res * invv[r];
@@ -1089,10 +1112,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                         for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
                     }
-                    if (vs_cube) {
-                        if (r < 3) { dl_lin = axpy(-minv * dlt, d, dl_lin); dl_ang = axpy(-iinv * dlt, rxd, dl_ang); }
-                        else dl_ang = axpy(-iinv * dlt, d, dl_ang);
-                    }
+                    if (vs_cube) couple(r, dlt);
                 }
                 // cone projection
                 {
@@ -1101,19 +1121,20 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
 #pragma unroll
                     for (int r = 1; r < 4; r++) {
-                        const f3 d = r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n);
                         float dlt = T.f[r] * sc - T.f[r];
                         T.f[r] += dlt;
-                        {
-                            const float2v d2 = {dlt, dlt};
+                        const float2v d2 = {dlt, dlt};
 #pragma unroll
-                            for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                        }
-                        if (vs_cube) {
-                            if (r < 3) { dl_lin = axpy(-minv * dlt, d, dl_lin); dl_ang = axpy(-iinv * dlt, cross(T.rc, d), dl_ang); }
-                            else dl_ang = axpy(-iinv * dlt, d, dl_ang);
-                        }
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                        // (the tracked scalars are not needed any more: the next slot starts from the updated accelerations)
                     }
+                }
+                f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
+                if (vs_cube) {
+                    const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
+                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the finger; the cube gets -Fd at rc
+                    dl_lin = (-minv) * Fd;
+                    dl_ang = (-iinv) * axpy(e3, T.n, cross(T.rc, Fd));
                 }
                 y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
                 if (vs_cube) {
