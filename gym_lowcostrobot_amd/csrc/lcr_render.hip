@@ -51,7 +51,9 @@ DEV void project_bbox(const LcrCam &C, int W, int H, const f3 *pts, int npts, fl
         float xc = dot(d, mk(C.xx, C.xy, C.xz)), yc = dot(d, mk(C.yx, C.yy, C.yz)), zc = -dot(d, mk(C.zx, C.zy, C.zz));
         if (zc < 0.02f) { behind = true; continue; }
         float inv = 1.0f / (zc * C.s);
-        float u = 0.5f * W + xc * inv - 0.5f, v = 0.5f * H - yc * inv - 0.5f, rp = rad * inv + 1.5f;
+        // a sphere of radius rad projects to an ellipse stretched radially by <= 1 + tan^2(off-axis angle)
+        const float stretch = 1.0f + (xc * xc + yc * yc) / (zc * zc);
+        float u = 0.5f * W + xc * inv - 0.5f, v = 0.5f * H - yc * inv - 0.5f, rp = rad * inv * stretch + 1.5f;
         x0 = min(x0, (int)floorf(u - rp)); x1 = max(x1, (int)ceilf(u + rp));
         y0 = min(y0, (int)floorf(v - rp)); y1 = max(y1, (int)ceilf(v + rp));
     }
@@ -112,7 +114,7 @@ DEV void build_bbox(const LcrCam &C, int W, int H, const Scene &S, int prim, int
             cc[8] = ob.x; cc[9] = ob.y; cc[10] = ob.z; cc[11] = baba * oaoa - baoa * baoa - r * r * baba;
             cc[12] = oaoa - r * r; cc[13] = dot(ob, ob) - r * r; cc[14] = 1.0f / r; cc[15] = 1.0f / fmaxf(baba, 1e-12f);
         }
-        // 2D silhouette (conservative): projected end points and the larger projected radius, +20 % for perspective stretch
+        // 2D silhouette (conservative): projected end points and the larger projected (perspective-stretched) radius
         float uv[2][2], rp[2];
         bool ok = true;
         for (int i = 0; i < 2; i++) {
@@ -120,10 +122,11 @@ DEV void build_bbox(const LcrCam &C, int W, int H, const Scene &S, int prim, int
             float xc = dot(d, mk(C.xx, C.xy, C.xz)), yc = dot(d, mk(C.yx, C.yy, C.yz)), zc = -dot(d, mk(C.zx, C.zy, C.zz));
             if (zc < 0.02f) { ok = false; zc = 0.02f; }
             float inv = 1.0f / (zc * C.s);
-            uv[i][0] = 0.5f * W + xc * inv - 0.5f; uv[i][1] = 0.5f * H - yc * inv - 0.5f; rp[i] = S.cr[prim] * inv;
+            uv[i][0] = 0.5f * W + xc * inv - 0.5f; uv[i][1] = 0.5f * H - yc * inv - 0.5f;
+            rp[i] = S.cr[prim] * inv * (1.0f + (xc * xc + yc * yc) / (zc * zc));   // perspective stretch of the silhouette
         }
         const float du = uv[1][0] - uv[0][0], dv = uv[1][1] - uv[0][1];
-        const float rr = 1.2f * fmaxf(rp[0], rp[1]) + 2.0f;
+        const float rr = fmaxf(rp[0], rp[1]) + 1.5f;
         seg[0] = uv[0][0]; seg[1] = uv[0][1]; seg[2] = du; seg[3] = dv;
         seg[4] = 1.0f / fmaxf(du * du + dv * dv, 1e-6f);
         seg[5] = ok ? rr : 1e15f;
