@@ -92,6 +92,14 @@ def main():
     ap.add_argument("--calibrate", type=int, default=0, help="after timing, launch the known-byte-count copy kernel this many times (PMC calibration)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched directly instead of through torchrun: start one rank per GPU ourselves (same command line the driver uses)
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
 
     from gym_lowcostrobot_amd import VecSim, build, sharding
