@@ -59,7 +59,8 @@ class _LowCostRobotEnv(sp.EnvBase):
     # ---- gymnasium.Env protocol ----
     def get_observation(self):
         obs = self._sim.observations()
-        return {k: (v[0] if v.ndim >= 2 else v) for k, v in obs.items() if k in self.observation_space}
+        keys = self.observation_space.spaces  # gymnasium.spaces.Dict has no key-membership __contains__; .spaces is the mapping
+        return {k: (v[0] if v.ndim >= 2 else v) for k, v in obs.items() if k in keys}
 
     def reset(self, seed=None, options=None):
         try:
@@ -78,10 +79,17 @@ class _LowCostRobotEnv(sp.EnvBase):
         terminated = np.bool_(out["terminated"][0])
         r = out["reward"][0]
         if self._task == "lift":  # lift_cube_env.py:336-345: dense float64, info = {}
-            return observation, np.float64(r), False, False, {}
+            div = bool(out["did_reset"][0])
+            return observation, np.float64(r), False, div, ({"diverged": True} if div else {})
         reward = np.float32(r) if self.reward_type == "sparse" else np.float64(r)  # reach_cube_env.py:345-348
         info = {"is_success": np.bool_(out["is_success"][0])}
-        return observation, reward, terminated, False, info
+        # the bare class never truncates (reach_cube_env.py:331).  The one exception is the kernel's divergence guard (the
+        # analogue of MuJoCo's mj_checkPos/mj_checkVel auto-reset): it re-initialises the env in place, so the episode
+        # boundary is reported instead of being swallowed
+        diverged = bool(out["did_reset"][0])
+        if diverged:
+            info["diverged"] = True
+        return observation, reward, terminated, diverged, info
 
     def render(self):
         if self.render_mode == "rgb_array":  # 640x640 frame of camera_vizu (reach_cube_env.py:350-355), ray-cast approximation
@@ -179,7 +187,10 @@ class PushCubeLoopEnv(_LowCostRobotEnv):
         self._sim.step(np.asarray(action, np.float32)[None, :])
         out = self._sim.outputs()
         info = {"timestamp": float(self._sim.timestamp.numpy()[0]), "success": int(out["is_success"][0])}  # :328
-        return self.get_observation(), float(out["reward"][0]), False, False, info
+        div = bool(out["did_reset"][0])
+        if div:
+            info["diverged"] = True
+        return self.get_observation(), float(out["reward"][0]), False, div, info
 
 
 class StackTwoCubesEnv(_LowCostRobotEnv):

@@ -195,6 +195,9 @@ class VecSim:
     def calibrate_copy(self, n_floats):
         """launch the known-byte-count copy kernel once (profiling calibration); returns bytes read == bytes written"""
         if getattr(self, "_calib_dst", None) is None or self._calib_n < n_floats:
+            if getattr(self, "_calib_dst", None) is not None:
+                check(self.L.lcr_free(self.handle, self._calib_dst))
+                self._calib_dst = None
             p = ctypes.c_void_p()
             check(self.L.lcr_malloc(self.handle, 4 * n_floats, ctypes.byref(p)))
             self._calib_dst, self._calib_n = p, n_floats

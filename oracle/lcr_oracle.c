@@ -82,6 +82,32 @@ static const double SITE_POS[3] = {-0.06429, 0.00327, 0.0011}; /* follower.xml:9
 static const int SPH_LINK[NSPH] = {4, 5};
 static const double SPH_POS[NSPH][3] = {{-0.0610, 0.0142, 0.0005}, {-0.0490, 0.0072, -0.0140}};
 static const double SPH_RAD[NSPH] = {0.0065, 0.0065};
+/* (D3) arm-link proxies: the remaining arm geoms that can reach the floor or the cube (follower.xml:10 visual geoms have
+ * contype=conaffinity=1, :13 collision hulls; geoms :70-98) are restated as spheres inscribed in the motor / bracket
+ * volumes of their hulls (mesh extents: tests/golden/model_golden.json "mesh_aabb").  link_1 / link_2 / base cannot
+ * reach the floor inside the joint-mode target box (reach_cube_env.py:249-250) and carry no proxy.
+ * Proxies are grouped; each GROUP yields at most ONE contact per substep -- the deepest penetration of its members
+ * (ties: lower index) -- the way MuJoCo's convex collider yields one point per geom pair.
+ *   group 0 "forearm" (both ends of link_3, link_4 motor): vs floor only
+ *   group 1 "gripper body" (link_5 motor body, link_6 jaw root): vs floor and vs the cube(s)
+ * {link index 0..5, centre in link frame, radius, group} */
+#define NLPX 5
+#define NLGRP 2
+static const int LPX_LINK[NLPX] = {2, 2, 3, 4, 5};
+static const double LPX_POS[NLPX][3] = {
+    {-0.0050, 0.0145, 0.0030},  /* elbow end of link_3            (link_3_collision x[-0.111,0.009] y[-0.004,0.033] z[-0.009,0.015]) */
+    {-0.0950, 0.0145, 0.0030},  /* wrist-motor end of link_3      (same hull, x[-0.111,-0.081]) */
+    {-0.0320, 0.0206, 0.0000},  /* link_4 motor                   (link_4_collision x[-0.045,-0.018] y[0.003,0.038] z[-0.010,0.010]) */
+    {-0.0130, 0.0015, 0.0000},  /* link_5 motor body              (link_5_collision x[-0.026,0] y[-0.018,0.021] z[-0.015,0.015]) */
+    {-0.0120, 0.0000, -0.0145}, /* jaw root on link_6             (link_6_collision x[-0.032,0.008] y[-0.008,0.008] z[-0.032,0.003]) */
+};
+/* (against a plane a set of spheres acts like its convex hull, so the two ends of a link stand for the whole link; the
+ * fixed finger between the link_5 body and the finger-tip sphere needs no proxy of its own, and the grasp gap stays free) */
+static const double LPX_RAD[NLPX] = {0.0120, 0.0120, 0.0105, 0.0150, 0.0078};
+static const int LPX_GROUP[NLPX] = {0, 0, 0, 1, 1};
+/* link geoms: MuJoCo geom defaults friction (1, 0.005, 0.0001), condim 3, priority 0.  vs floor (priority 0, friction 0.1):
+ * max rule -> mu 1, condim 3, default solref/solimp.  vs cube (priority 1): the cube's condim 4, friction, solimp win (P9). */
+static const double MU_LINK_FLOOR[3] = {1.0, 1.0, 0.005};
 
 /* default solver parameters (MJ-DOC XML reference): solref=(0.02,1) solimp=(0.9,0.95,0.001,0.5,2) */
 static const double SOLREF[2] = {0.02, 1.0};
@@ -211,6 +237,7 @@ typedef struct {
     real Iw[6][9];  /* world inertia about com */
     real site[3];
     real sph[NSPH][3];
+    real lpx[NLPX][3];
     int ncube;
     real cR[2][9], cp[2][3];
     const double *mu_cube, *mu_finger_cube;
@@ -256,6 +283,11 @@ static void arm_kinematics(const real *q, kin_t *K) {
         real c[3] = {(real)SPH_POS[s][0], (real)SPH_POS[s][1], (real)SPH_POS[s][2]};
         m3v(t, K->R[SPH_LINK[s] + 1], c);
         v3add(K->sph[s], K->p[SPH_LINK[s] + 1], t);
+    }
+    for (int s = 0; s < NLPX; s++) {
+        real c[3] = {(real)LPX_POS[s][0], (real)LPX_POS[s][1], (real)LPX_POS[s][2]};
+        m3v(t, K->R[LPX_LINK[s] + 1], c);
+        v3add(K->lpx[s], K->p[LPX_LINK[s] + 1], t);
     }
 }
 
@@ -392,11 +424,14 @@ typedef struct {
     real pos[3], frame[9], dist;
     const double *mu; /* [3] tan, tan, torsional */
     const double *solimp;
-    int slot; /* warm-start slot id: 0-3 floor-cube0, 4-7 floor-cube1, 8-11 cube-cube, 12-13 sphere-cube, 14-15 sphere-floor */
+    int slot; /* warm-start slot id: 0-3 floor-cube0, 4-7 floor-cube1, 8-11 cube-cube / rails, 12-13 sphere-cube, 14-15 sphere-floor,
+                 16-17 link-proxy group 0/1 */
+    int dim;  /* rows: 3 (n, t1, t2) or 4 (+ torsion) */
 } contact_t;
 
-#define MAX_CONTACTS (8 + 8 + ORC_MAX_ARM_CONTACTS)
+#define MAX_CONTACTS (8 + 8 + ORC_MAX_ARM_CONTACTS + NLGRP)
 #define MAX_ROWS (12 + 4 * MAX_CONTACTS)
+#define ORC_PGS_CAP 50
 
 /* plane z=0 (geom1, world) vs box (geom2): MJ-DOC mjc_PlaneBox -- vertex i=(+-,+-,+-) by bits 0,1,2;
  * contact where vertex height <= 0... margin 0 => strictly below counts (dist<0); at most 4; pos midway */
@@ -416,13 +451,14 @@ static int collide_plane_box(const kin_t *K, int c, contact_t *out) {
         real nz[3] = {0, 0, 1};
         make_frame(ct->frame, nz);
         ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT; /* P9: cube priority 1 beats floor priority 0 */
+        ct->dim = 4;
     }
     return n;
 }
-/* box c (geom1) vs finger sphere s (geom2) -- (D3) */
-static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
+/* box c (geom1) vs a sphere (centre, radius) carried by arm link `link` (geom2) -- (D3) */
+static int collide_box_sphere_g(const kin_t *K, int c, const real *centre, double radius, int link, contact_t *ct) {
     real d[3], l[3], q[3];
-    v3sub(d, K->sph[s], K->cp[c]);
+    v3sub(d, centre, K->cp[c]);
     m3tv(l, K->cR[c], d);
     int outside = 0;
     for (int k = 0; k < 3; k++) {
@@ -435,7 +471,7 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
         real df[3];
         v3sub(df, l, q);
         real dn = v3norm(df);
-        dist = dn - (real)SPH_RAD[s];
+        dist = dn - (real)radius;
         if (!(dist < 0)) return 0;
         for (int k = 0; k < 3; k++) nl[k] = df[k] / dn;
     } else {
@@ -444,7 +480,7 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
         real sg = l[best] < 0 ? (real)-1 : (real)1;
         v3set(nl, 0, 0, 0); nl[best] = sg;
         q[best] = sg * (real)CUBE_HALF;
-        dist = -(bd + (real)SPH_RAD[s]);
+        dist = -(bd + (real)radius);
     }
     real pl[3] = {q[0] + nl[0] * dist * (real)0.5, q[1] + nl[1] * dist * (real)0.5, q[2] + nl[2] * dist * (real)0.5};
     real nw[3], pw[3];
@@ -452,21 +488,51 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) {
     m3v(pw, K->cR[c], pl);
     v3add(ct->pos, pw, K->cp[c]);
     make_frame(ct->frame, nw);
+    ct->b1 = 6 + c; ct->b2 = link; ct->dist = dist;
+    ct->dim = 4;
+    return 1;
+}
+static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) { /* finger sphere s */
+    if (!collide_box_sphere_g(K, c, K->sph[s], SPH_RAD[s], SPH_LINK[s], ct)) return 0;
     ct->slot = 12 + s;
-    ct->b1 = 6 + c; ct->b2 = SPH_LINK[s]; ct->dist = dist;
     ct->mu = K->mu_finger_cube; ct->solimp = SOLIMP_FINGER_CUBE;
     return 1;
 }
-static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
-    real dist = K->sph[s][2] - (real)SPH_RAD[s];
+static int collide_plane_sphere_g(const real *centre, double radius, int link, contact_t *ct) {
+    real dist = centre[2] - (real)radius;
     if (!(dist < 0)) return 0;
-    v3set(ct->pos, K->sph[s][0], K->sph[s][1], dist * (real)0.5);
+    v3set(ct->pos, centre[0], centre[1], dist * (real)0.5);
     real nz[3] = {0, 0, 1};
     make_frame(ct->frame, nz);
-    ct->slot = 14 + s;
-    ct->b1 = -1; ct->b2 = SPH_LINK[s]; ct->dist = dist;
-    ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
+    ct->b1 = -1; ct->b2 = link; ct->dist = dist;
     return 1;
+}
+static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
+    if (!collide_plane_sphere_g(K->sph[s], SPH_RAD[s], SPH_LINK[s], ct)) return 0;
+    ct->slot = 14 + s;
+    ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
+    ct->dim = 4;
+    return 1;
+}
+/* arm-link proxy group g: the deepest penetration among its members against the floor and (group 1) the cubes */
+static int collide_link_group(const kin_t *K, int g, contact_t *out) {
+    int have = 0;
+    for (int s = 0; s < NLPX; s++) {
+        if (LPX_GROUP[s] != g) continue;
+        contact_t tmp;
+        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
+            tmp.mu = MU_LINK_FLOOR; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 3;
+            if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
+        }
+        if (g == 1)
+            for (int c = 0; c < K->ncube; c++)
+                if (collide_box_sphere_g(K, c, K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
+                    tmp.mu = K->mu_cube; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 4; /* P9: cube priority 1 beats the link geoms */
+                    if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
+                }
+    }
+    if (have) out->slot = 16 + g;
+    return have;
 }
 /* (D7) PushCubeLoop rails (push_cube_loop.xml:44-47): the four wall boxes are restated as their inner faces -- vertical
  * half-spaces that only act below the wall top (z < 0.012).  The pen is wider than the cube in x and in y, so the cube
@@ -512,6 +578,7 @@ static int collide_walls(const kin_t *K, contact_t *out) {
             v3set(ct->pos, P[i][0] - nw[0] * dist * (real)0.5, P[i][1] - nw[1] * dist * (real)0.5, P[i][2]);
             make_frame(ct->frame, nw);
             ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT;
+            ct->dim = 4;
         }
     }
     return n;
@@ -639,6 +706,7 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
         v3copy(ct->pos, spos[s]);
         make_frame(ct->frame, n);
         ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT;
+        ct->dim = 4;
         cnt++;
     }
     return cnt;
@@ -696,10 +764,15 @@ static double g_diag_res;
 /* ------------------------------------------------------------------------------------------------ */
 /* one physics substep == mujoco.mj_step (reach_cube_env.py:276-277) -- MJ-DOC restatement          */
 /* ------------------------------------------------------------------------------------------------ */
-typedef struct { real ee[3]; real cube[2][3]; } lag_t;
+typedef struct {
+    real ee[3]; real cube[2][3];
+    uint32_t active_mask;  /* OR over the substeps of the control step: bit = warm-slot id of an active contact (0..17), 18+j joint-limit of dof j */
+    uint32_t active_count; /* sum over the substeps of the number of active contacts + limits */
+    uint32_t max_sweeps;   /* largest PGS sweep count of a substep (adaptive mode) */
+} lag_t;
 /* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
  * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
-typedef struct { real lim[12]; real slot[16][4]; } warm_t;
+typedef struct { real lim[12]; real slot[18][4]; } warm_t;
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
                     warm_t *warm, int diag) {
@@ -757,7 +830,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     memcpy(a0, tau, sizeof(real) * nv);
     chol_solve(L, nv, a0); /* qacc_smooth */
 
-    /* -- collision (D3, D5) in fixed order: floor-cube(s), cube-cube, sphere-cube, sphere-floor */
+    /* -- collision (D3, D5) in fixed order: floor-cube(s), cube-cube, rails, sphere-cube, sphere-floor, link-proxy groups */
     contact_t con[MAX_CONTACTS];
     int ncon = 0;
     for (int c = 0; c < nc; c++) ncon += collide_plane_box(&K, c, con + ncon);
@@ -775,14 +848,18 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     }
     for (int s = 0; s < NSPH; s++)
         if (collide_plane_sphere(&K, s, con + ncon)) ncon++;
+    if (P->arm_collision)
+        for (int g = 0; g < NLGRP; g++)
+            if (collide_link_group(&K, g, con + ncon)) ncon++;
 
-    /* -- constraint rows: joint limits first, then contacts (4 rows each: n, t1, t2, torsion) */
-    static const int ROWDIM = 4;
+    /* -- constraint rows: joint limits first, then contacts (n, t1, t2 [, torsion]) */
     real J[MAX_ROWS * ORC_NV_MAX], aref[MAX_ROWS], Rr[MAX_ROWS];
     int kind[MAX_ROWS]; /* 0 limit, 1 contact-normal (block start), 2 friction */
+    int blk0[MAX_ROWS], blkdim[MAX_ROWS]; /* first row and row count of the contact a row belongs to */
     real *wptr[MAX_ROWS]; /* where this row's force is kept between substeps */
     const double *rowmu[MAX_ROWS];
     int nr = 0;
+    uint32_t amask = 0;
     memset(J, 0, sizeof J);
     for (int j = 0; j < 6; j++)
         for (int side = 0; side < 2; side++) {
@@ -796,8 +873,9 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             aref[nr] = (real)(-b * (double)vel - k * imp * (double)pos);
             double r = (1 - imp) / imp * g_inv_dof[j];
             Rr[nr] = (real)(r > MJ_MINVAL ? r : MJ_MINVAL);
-            kind[nr] = 0; rowmu[nr] = 0;
+            kind[nr] = 0; rowmu[nr] = 0; blk0[nr] = nr; blkdim[nr] = 1;
             wptr[nr] = &warm->lim[2 * j + side];
+            amask |= 1u << (18 + j);
             nr++;
         }
     for (int ci = 0; ci < ncon; ci++) {
@@ -813,7 +891,8 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         if (Rn < MJ_MINVAL) Rn = MJ_MINVAL;
         double impr = P->impratio > MJ_MINVAL ? P->impratio : MJ_MINVAL;
         double Rf = Rn / impr; /* elliptic cone: friction rows regularised by R/impratio, scaled mu0^2/mu_j^2 */
-        for (int r = 0; r < ROWDIM; r++) {
+        amask |= 1u << ct->slot;
+        for (int r = 0; r < ct->dim; r++) {
             real *Jrow = J + (size_t)(nr + r) * nv;
             const real *fr = ct->frame + 3 * (r < 3 ? r : 0);
             for (int d = 0; d < nv; d++) {
@@ -830,12 +909,15 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             Rr[nr + r] = (real)Rrow;
             kind[nr + r] = r == 0 ? 1 : 2;
             rowmu[nr + r] = ct->mu;
+            blk0[nr + r] = nr; blkdim[nr + r] = ct->dim;
             wptr[nr + r] = &warm->slot[ct->slot][r];
         }
-        nr += ROWDIM;
+        nr += ct->dim;
     }
+    lag->active_mask |= amask;
+    lag->active_count += (uint32_t)__builtin_popcount(amask);
 
-    /* -- dual problem: A = J M^-1 J^T, b = J a0 - aref ; PGS, cold start, fixed iterations (D1, D2) */
+    /* -- dual problem: A = J M^-1 J^T, b = J a0 - aref ; PGS, warm start, fixed or adaptive sweep count (D1, D2) */
     real f[MAX_ROWS];
     real qfc[ORC_NV_MAX];
     memset(qfc, 0, sizeof qfc);
@@ -858,9 +940,15 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             bvec[i] = s - aref[i];
             f[i] = P->warm_start ? *wptr[i] : 0; /* cold start when warm_start == 0 */
         }
+        /* pgs_iters > 0: exactly that many sweeps.  pgs_iters < 0 ("converged" mode): sweep until the largest force change of
+         * a sweep is <= pgs_tol * (1 + largest |force|), at most ORC_PGS_CAP sweeps */
+        const int adaptive = P->pgs_iters < 0;
+        const int max_it = adaptive ? ORC_PGS_CAP : P->pgs_iters;
         double lastchange = 0;
-        for (int it = 0; it < P->pgs_iters; it++) {
+        int sweeps = 0;
+        for (int it = 0; it < max_it; it++) {
             lastchange = 0;
+            double fmaxabs = 0;
             for (int i = 0; i < nr; i++) {
                 real res = bvec[i] + Rr[i] * f[i];
                 for (int j = 0; j < nr; j++) res += A[(size_t)i * nr + j] * f[j];
@@ -869,23 +957,27 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                 if (kind[i] != 2 && nf < 0) nf = 0; /* unilateral rows */
                 f[i] = nf;
                 if (fabs((double)(nf - old)) > lastchange) lastchange = fabs((double)(nf - old));
-                if (kind[i] == 2 && (i + 1 == nr || kind[i + 1] != 2)) {
+                if (kind[i] == 2 && i == blk0[i] + blkdim[i] - 1) {
                     /* last friction row of this contact: project onto the elliptic cone (D2) */
-                    int i0 = i - (ROWDIM - 1);
+                    const int i0 = blk0[i], dm = blkdim[i];
                     const double *mu = rowmu[i];
                     real fn = f[i0], s2 = 0;
-                    for (int r = 1; r < ROWDIM; r++) { real x = f[i0 + r] / (real)mu[r - 1]; s2 += x * x; }
-                    if (fn <= 0) { for (int r = 1; r < ROWDIM; r++) f[i0 + r] = 0; }
+                    for (int r = 1; r < dm; r++) { real x = f[i0 + r] / (real)mu[r - 1]; s2 += x * x; }
+                    if (fn <= 0) { for (int r = 1; r < dm; r++) f[i0 + r] = 0; }
                     else if (s2 > fn * fn) {
                         real sc = fn / (real)sqrt((double)s2);
-                        for (int r = 1; r < ROWDIM; r++) f[i0 + r] *= sc;
+                        for (int r = 1; r < dm; r++) f[i0 + r] *= sc;
                     }
                 }
             }
+            sweeps++;
+            for (int i = 0; i < nr; i++) if (fabs((double)f[i]) > fmaxabs) fmaxabs = fabs((double)f[i]);
+            if (adaptive && lastchange <= P->pgs_tol * (1.0 + fmaxabs)) break;
         }
         for (int i = 0; i < nr; i++)
             for (int d = 0; d < nv; d++) qfc[d] += J[(size_t)i * nv + d] * f[i];
         free(MiJt); free(A);
+        if ((uint32_t)sweeps > lag->max_sweeps) lag->max_sweeps = (uint32_t)sweeps;
         if (diag) { g_diag_res = lastchange; }
     }
     /* slots that are not active in this substep restart from zero */
@@ -942,6 +1034,8 @@ void orc_default_params(orc_params *p, int task) {
     p->compat = 0;
     p->auto_reset = 1;
     p->warm_start = 1;
+    p->arm_collision = 1;
+    p->pgs_tol = 1e-6;
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
 int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }
@@ -1203,6 +1297,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];
     if (io->sim_time) io->sim_time[e] += P->n_substeps * H_STEP; /* data.time advances in mj_step only */
+    if (io->active_mask) { io->active_mask[e] = lag.active_mask; io->active_count[e] = lag.active_count; io->max_sweeps[e] = lag.max_sweeps; }
 
     /* ---- observation, reward, termination: reach:313-333 (+ lift:322-346 push:330-346 stack:326-348) */
     float *obs = io->obs + 18 * e;

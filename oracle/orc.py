@@ -32,6 +32,8 @@ class OrcParams(ctypes.Structure):
         ("compat", ctypes.c_uint32),
         ("auto_reset", ctypes.c_int32),
         ("warm_start", ctypes.c_int32),
+        ("arm_collision", ctypes.c_int32),
+        ("pgs_tol", ctypes.c_double),
     ]
 
 
@@ -53,6 +55,9 @@ class OrcIO(ctypes.Structure):
         ("did_reset", ctypes.c_void_p),
         ("goal", ctypes.c_void_p),
         ("sim_time", ctypes.c_void_p),
+        ("active_mask", ctypes.c_void_p),
+        ("active_count", ctypes.c_void_p),
+        ("max_sweeps", ctypes.c_void_p),
     ]
 
 
@@ -123,10 +128,14 @@ class Oracle:
         self.did_reset = np.zeros(n, np.uint8)
         self.goal = np.zeros(n, np.int32)
         self.sim_time = np.zeros(n)
+        self.active_mask = np.zeros(n, np.uint32)
+        self.active_count = np.zeros(n, np.uint32)
+        self.max_sweeps = np.zeros(n, np.uint32)
         self.io = OrcIO(
             _p(self.qpos), _p(self.qvel), _p(self.ee_lag), _p(self.target), _p(self.elapsed), _p(self.rng),
             _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.reward64), _p(self.terminated),
             _p(self.truncated), _p(self.is_success), _p(self.did_reset), _p(self.goal), _p(self.sim_time),
+            _p(self.active_mask), _p(self.active_count), _p(self.max_sweeps),
         )
 
     def reset(self, seeds=None, mask=None):
