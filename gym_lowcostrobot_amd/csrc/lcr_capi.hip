@@ -12,6 +12,7 @@
 
 #include "../../include/lcr.h"
 #include "lcr_device.h"
+#include "lcr_model_gen.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -225,11 +226,12 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     // stack 0.1 kg, I=1.125e-5 (stack_two_cubes.xml:27,33)
     // push_cube_loop.xml:29-31: 0.05 kg, I=1.125e-5, friction 1.5 / 1.5 (torsional)
     const bool loop = cfg->task == LCR_TASK_PUSH_LOOP;
-    double cm = cfg->task == LCR_TASK_PICK_PLACE ? 10.0 : (loop ? 0.05 : 0.1);
-    double ci = (cfg->task == LCR_TASK_STACK || loop) ? 0.00001125 : 0.00016667;
+    // (numbers from the scene files via tests/golden/model_golden.json -> lcr_model_gen.h)
+    double cm = lcrm::SCENE_CUBE_MASS[cfg->task];
+    double ci = lcrm::SCENE_CUBE_INERTIA[cfg->task];
     {
-        const double mu = loop ? 1.5 : 0.5, mut = loop ? 1.5 : 0.005;   // cube geom friction (tangential, torsional)
-        const double muf = 1.5, muft = loop ? 1.5 : 0.005;               // finger<->cube pair: max of both geoms
+        const double mu = lcrm::SCENE_CUBE_MU[cfg->task], mut = lcrm::SCENE_CUBE_MU_TORS[cfg->task];   // cube geom friction (tangential, torsional)
+        const double muf = mu > 1.5 ? mu : 1.5, muft = mut > 0.005 ? mut : 0.005;   // finger<->cube pair (both priority 1): max of both geoms (finger: follower.xml:15)
         D.rt_cube = (float)(mu * mu / (mut * mut));
         D.inv_mu_c2 = (float)(1.0 / (mu * mu));
         D.inv_mu_ct2 = (float)(1.0 / (mut * mut));

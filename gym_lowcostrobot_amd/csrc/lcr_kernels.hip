@@ -39,9 +39,9 @@ constexpr float KP = 1000.0f;
 constexpr float KV = 10.0f;
 constexpr float FRC = 10.0f;
 constexpr float GRAV = 9.81f;
-constexpr float CH = 0.015f;  // cube half size
-constexpr float JLO[6] = {-3.14f, -3.14f, -3.14f, -3.14f, -3.14f, -2.45f};
-constexpr float JHI[6] = {3.14f, 3.14f, 3.14f, 3.14f, 3.14f, 0.032f};
+constexpr float CH = lcrm::CUBE_HALF;  // cube half size
+constexpr float JLO[6] = {lcrm::JNT_LO[0], lcrm::JNT_LO[1], lcrm::JNT_LO[2], lcrm::JNT_LO[3], lcrm::JNT_LO[4], lcrm::JNT_LO[5]};
+constexpr float JHI[6] = {lcrm::JNT_HI[0], lcrm::JNT_HI[1], lcrm::JNT_HI[2], lcrm::JNT_HI[3], lcrm::JNT_HI[4], lcrm::JNT_HI[5]};
 // soft-constraint parameters (MuJoCo defaults solref=(0.02,1), solimp=(0.9,0.95,0.001,0.5,2); follower.xml:15 fingers)
 // K = 1/(dmax^2 tc^2), B = 2/(dmax tc)
 constexpr float K_DEF = 1.0f / (0.95f * 0.95f * 0.02f * 0.02f), B_DEF = 2.0f / (0.95f * 0.02f);

@@ -95,7 +95,7 @@ static const double SPH_RAD[NSPH] = {0.0065, 0.0065};
 #define NLGRP 2
 static const int LPX_LINK[NLPX] = {2, 2, 3, 4, 5};
 static const double LPX_POS[NLPX][3] = {
-    {-0.0050, 0.0145, 0.0030},  /* elbow end of link_3            (link_3_collision x[-0.111,0.009] y[-0.004,0.033] z[-0.009,0.015]) */
+    {-0.0100, 0.0145, 0.0030},  /* elbow end of link_3            (link_3_collision x[-0.111,0.009] y[-0.004,0.033] z[-0.009,0.015]) */
     {-0.0950, 0.0145, 0.0030},  /* wrist-motor end of link_3      (same hull, x[-0.111,-0.081]) */
     {-0.0320, 0.0206, 0.0000},  /* link_4 motor                   (link_4_collision x[-0.045,-0.018] y[0.003,0.038] z[-0.010,0.010]) */
     {-0.0130, 0.0015, 0.0000},  /* link_5 motor body              (link_5_collision x[-0.026,0] y[-0.018,0.021] z[-0.015,0.015]) */
@@ -1365,6 +1365,33 @@ int orc_max_threads(void) {
 }
 void orc_last_diag(int *n_rows, int *n_contacts, double *pgs_residual) {
     *n_rows = g_diag_rows; *n_contacts = g_diag_contacts; *pgs_residual = g_diag_res;
+}
+
+/* the oracle's own L0 tables, flattened, for the test that compares them with tests/golden/model_golden.json:
+ * per link i (6): pos3, axis3, ipos3, iquat4, mass, diaginertia3, range2 = 19 doubles; then site3, armature, damping, kp, kv,
+ * frcrange, timestep, cube_half; then per task (6): cube mass, cube inertia, mu_tan, mu_tors; then walls (4);
+ * then NSPH x (link, pos3, rad) and NLPX x (link, pos3, rad, group).  Returns the number of doubles written. */
+int orc_model_table(double *out) {
+    int n = 0;
+    for (int i = 0; i < 6; i++) {
+        for (int k = 0; k < 3; k++) out[n++] = LINK_POS[i][k];
+        for (int k = 0; k < 3; k++) out[n++] = LINK_AXIS[i][k];
+        for (int k = 0; k < 3; k++) out[n++] = LINK_IPOS[i][k];
+        for (int k = 0; k < 4; k++) out[n++] = LINK_IQUAT[i][k];
+        out[n++] = LINK_MASS[i];
+        for (int k = 0; k < 3; k++) out[n++] = LINK_DIAGI[i][k];
+        out[n++] = JNT_LO[i]; out[n++] = JNT_HI[i];
+    }
+    for (int k = 0; k < 3; k++) out[n++] = SITE_POS[k];
+    out[n++] = ARMATURE; out[n++] = DAMPING; out[n++] = KP; out[n++] = KV; out[n++] = FRC_LIM; out[n++] = H_STEP; out[n++] = CUBE_HALF;
+    for (int t = 0; t < 6; t++) {
+        task_model T = get_task_model(t);
+        out[n++] = T.cube_mass; out[n++] = T.cube_inertia; out[n++] = T.mu_cube[0]; out[n++] = T.mu_cube[2];
+    }
+    out[n++] = WALL_X; out[n++] = WALL_Y0; out[n++] = WALL_Y1; out[n++] = WALL_TOP;
+    for (int s = 0; s < NSPH; s++) { out[n++] = SPH_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = SPH_POS[s][k]; out[n++] = SPH_RAD[s]; }
+    for (int s = 0; s < NLPX; s++) { out[n++] = LPX_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = LPX_POS[s][k]; out[n++] = LPX_RAD[s]; out[n++] = LPX_GROUP[s]; }
+    return n;
 }
 
 /* ---- model queries ---- */

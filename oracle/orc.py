@@ -199,6 +199,27 @@ def ik(q, target):
     return it, qc, qs, sl
 
 
+def model_table():
+    """the oracle's own L0 constants as a dict (see orc_model_table in lcr_oracle.c)"""
+    buf = np.zeros(256)
+    n = lib().orc_model_table(_p(buf))
+    it = iter(buf[:n])
+    take = lambda k: np.array([next(it) for _ in range(k)])
+    links = []
+    for _ in range(6):
+        links.append({"pos": take(3), "axis": take(3), "ipos": take(3), "iquat": take(4), "mass": take(1)[0], "diaginertia": take(3), "range": take(2)})
+    t = {"links": links, "site": take(3)}
+    for k in ("armature", "damping", "kp", "kv", "frcrange", "timestep", "cube_half"):
+        t[k] = take(1)[0]
+    t["tasks"] = [dict(zip(("cube_mass", "cube_inertia", "mu_tan", "mu_tors"), take(4))) for _ in range(6)]
+    t["walls"] = dict(zip(("x", "y0", "y1", "top"), take(4)))
+    t["spheres"] = [{"link": int(take(1)[0]), "pos": take(3), "rad": take(1)[0]} for _ in range(2)]
+    rest = list(it)
+    t["proxies"] = [{"link": int(rest[6 * i]), "pos": np.array(rest[6 * i + 1:6 * i + 4]), "rad": rest[6 * i + 4], "group": int(rest[6 * i + 5])}
+                    for i in range(len(rest) // 6)]
+    return t
+
+
 def rng_seed(seed):
     r = np.zeros(4, np.uint64)
     lib().orc_rng_seed(ctypes.c_uint64(int(seed)), _p(r))

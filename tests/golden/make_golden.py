@@ -340,5 +340,107 @@ def main():
     print("wrote", dst, {k: len(v) for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# L0: the MJCF numbers themselves (follower.xml + the six scene files) and the extents of the collision / visual meshes.
+# Parsed with ElementTree / a binary-STL reader; the output is DATA (attribute values, bounding boxes), no file is copied.
+# ------------------------------------------------------------------------------------------------------------------
+ASSETS = os.path.join(REF, "gym_lowcostrobot", "assets", "low_cost_robot_6dof")
+SCENES = ["reach_cube", "lift_cube", "push_cube", "pick_place_cube", "stack_two_cubes", "push_cube_loop"]
+
+
+def _nums(txt):
+    return [float(x) for x in txt.split()]
+
+
+def _attrs(el, keep_str=("name", "class", "mesh", "type", "joint", "file", "material", "mode", "integrator", "cone", "childclass",
+                         "body1", "body2", "texture", "builtin", "mark", "angle", "meshdir")):
+    out = {}
+    for k, v in el.attrib.items():
+        if k in keep_str:
+            out[k] = v
+        else:
+            try:
+                n = _nums(v)
+                out[k] = n[0] if len(n) == 1 else n
+            except ValueError:
+                out[k] = v
+    return out
+
+
+def _body_tree(el, parent, bodies):
+    rec = {"name": el.get("name"), "parent": parent, **{k: v for k, v in _attrs(el).items() if k != "name"}}
+    rec["inertial"] = _attrs(el.find("inertial")) if el.find("inertial") is not None else None
+    rec["joints"] = [_attrs(j) for j in el.findall("joint")] + [dict(_attrs(j), type="free") for j in el.findall("freejoint")]
+    rec["geoms"] = [_attrs(g) for g in el.findall("geom")]
+    rec["sites"] = [_attrs(g) for g in el.findall("site")]
+    bodies.append(rec)
+    for ch in el.findall("body"):
+        _body_tree(ch, el.get("name"), bodies)
+
+
+def _defaults(el, prefix, out):
+    cls = el.get("class", prefix)
+    out[cls] = {ch.tag: _attrs(ch) for ch in el if ch.tag != "default"}
+    for ch in el.findall("default"):
+        _defaults(ch, cls, out)
+
+
+def _stl_vertices(path):
+    import struct
+
+    b = open(path, "rb").read()
+    n = struct.unpack("<I", b[80:84])[0]
+    rec = np.frombuffer(b[84:84 + 50 * n], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    return rec["v"].reshape(-1, 3).astype(np.float64)
+
+
+def mk_model():
+    import xml.etree.ElementTree as ET
+
+    out = {"_generated_by": "tests/golden/make_golden.py:mk_model", "_source": "gym_lowcostrobot/assets/low_cost_robot_6dof/*.xml, follower_meshes/*.stl"}
+    root = ET.parse(os.path.join(ASSETS, "follower.xml")).getroot()
+    fol = {"compiler": _attrs(root.find("compiler")), "option": _attrs(root.find("option")), "defaults": {}, "bodies": [],
+           "meshes": {m.get("name"): m.get("file") for m in root.find("asset").findall("mesh")},
+           "excludes": [_attrs(e) for e in root.find("contact").findall("exclude")],
+           "actuators": [dict(_attrs(a), tag=a.tag) for a in root.find("actuator")]}
+    for d in root.find("default").findall("default"):
+        _defaults(d, "main", fol["defaults"])
+    for b in root.find("worldbody").findall("body"):
+        _body_tree(b, "world", fol["bodies"])
+    out["follower"] = fol
+    out["scenes"] = {}
+    for sc in SCENES:
+        r = ET.parse(os.path.join(ASSETS, sc + ".xml")).getroot()
+        wb = r.find("worldbody")
+        rec = {"option": _attrs(r.find("option")), "include_after_option": [c.tag for c in r].index("include") > [c.tag for c in r].index("option"),
+               "world_geoms": [_attrs(g) for g in wb.findall("geom")], "cameras": [_attrs(c) for c in wb.findall("camera")], "bodies": []}
+        for b in wb.findall("body"):
+            _body_tree(b, "world", rec["bodies"])
+        out["scenes"][sc] = rec
+    aabb = {}
+    mdir = os.path.join(ASSETS, "follower_meshes")
+    for name, fn in fol["meshes"].items():
+        v = _stl_vertices(os.path.join(mdir, fn))
+        aabb[name] = {"min": [round(float(x), 6) for x in v.min(0)], "max": [round(float(x), 6) for x in v.max(0)], "n_vertices": int(len(v))}
+    out["mesh_aabb"] = aabb
+    # slab extents of the link hulls along the link's long axis (x): the data the sphere proxies of DESIGN.md D3 are fitted to
+    slabs = {}
+    for name in ("link_3_collision", "link_4_collision", "link_5_collision", "link_6_collision"):
+        v = _stl_vertices(os.path.join(mdir, fol["meshes"][name]))
+        edges = np.linspace(v[:, 0].min(), v[:, 0].max(), 9)
+        rows = []
+        for a, b in zip(edges[:-1], edges[1:]):
+            w = v[(v[:, 0] >= a - 1e-9) & (v[:, 0] <= b + 1e-9)]
+            if len(w):
+                rows.append({"x": [round(float(a), 5), round(float(b), 5)], "y": [round(float(w[:, 1].min()), 5), round(float(w[:, 1].max()), 5)],
+                             "z": [round(float(w[:, 2].min()), 5), round(float(w[:, 2].max()), 5)]})
+        slabs[name] = rows
+    out["mesh_slabs_x"] = slabs
+    return out
+
+
 if __name__ == "__main__":
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "model_golden.json"), "w") as _f:
+        json.dump(mk_model(), _f, indent=1)
+    print("wrote model_golden.json")
     main()

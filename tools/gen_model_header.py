@@ -13,26 +13,49 @@ import os
 
 import numpy as np
 
-# follower.xml:56-98 (body pos / joint axis / inertial pos, quat, mass, diaginertia)
-LINK_POS = [(0.012, 0, 0.0409), (0, -0.0209, 0.0154), (-0.0148, 0.0065, 0.1083),
-            (-0.10048, 5e-05, 0.0026999), (-0.045, 0.013097, 0), (-0.01315, -0.0075, 0.0145)]
-LINK_AXIS = [(0, 0, -1), (0, 1, 0), (0, -1, 0), (0, 1, 0), (1, 0, 0), (0, 0, -1)]
-LINK_IPOS = [(0.011924, -0.00048792, 0.013381), (0.0011747, 0.02097, 0.071547), (-0.05537, 0.014505, 0.0028659),
-             (-0.02652, 0.019195, -9.0614e-06), (-0.019091, 0.0053379, 0.00018011), (-0.02507, 0.0010817, -0.01414)]
-LINK_IQUAT = [(-0.0190903, 0.705417, 0.0178052, 0.708312), (0.998768, 2.01447e-05, 0.0496266, 0.000367169),
-              (8.17663e-05, 0.710999, -4.16983e-05, 0.703193), (0.707361, 0.706812, 0.00580344, 0.00484124),
-              (0.105295, 0.703509, -0.0986543, 0.695885), (0.528148, 0.5474, 0.466496, 0.451436)]
-LINK_MASS = [0.05014, 0.050177, 0.06379, 0.019805, 0.029277, 0.012831]
-LINK_DIAGI = [(1.44921e-05, 1.2371e-05, 7.59138e-06), (3.73065e-05, 3.3772e-05, 7.94901e-06),
-              (2.45081e-05, 2.2231e-05, 7.34061e-06), (2.95813e-06, 2.8759e-06, 1.07787e-06),
-              (8.11303e-06, 7.14908e-06, 3.27429e-06), (3.49922e-06, 2.45768e-06, 1.4645e-06)]
-SITE_POS = (-0.06429, 0.00327, 0.0011)  # follower.xml:91 (on link_5)
-ARMATURE = 0.1  # follower.xml:7
+# ---- inputs: tests/golden/model_golden.json, the MJCF numbers extracted from the reference's follower.xml + scene files by
+# tests/golden/make_golden.py:mk_model (follower.xml:56-98 body pos / joint axis / inertial pos, quat, mass, diaginertia;
+# :91 site; :7 armature; scene files: cube mass / inertia / friction, rails, cameras).  Nothing is typed by hand here.
+import json
+
+_G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "model_golden.json")))
+_B = {b["name"]: b for b in _G["follower"]["bodies"]}
+_LINKS = [_B[f"link_{i}"] for i in range(1, 7)]
+LINK_POS = [tuple(b["pos"]) for b in _LINKS]
+LINK_AXIS = [tuple(b["joints"][0]["axis"]) for b in _LINKS]
+LINK_RANGE = [tuple(b["joints"][0]["range"]) for b in _LINKS]
+LINK_IPOS = [tuple(b["inertial"]["pos"]) for b in _LINKS]
+LINK_IQUAT = [tuple(b["inertial"]["quat"]) for b in _LINKS]
+LINK_MASS = [b["inertial"]["mass"] for b in _LINKS]
+LINK_DIAGI = [tuple(b["inertial"]["diaginertia"]) for b in _LINKS]
+BASE_QUAT = tuple(_B["base_link"]["quat"])  # follower.xml:51
+SITE_POS = tuple(_B["link_5"]["sites"][0]["pos"])  # follower.xml:91 (on link_5)
+ARMATURE = _G["follower"]["defaults"]["follower"]["joint"]["armature"]  # follower.xml:7
+SCENE_OF_TASK = ["reach_cube", "lift_cube", "push_cube", "pick_place_cube", "stack_two_cubes", "push_cube_loop"]  # lcr_task order
+
+
+def scene_cube(task):
+    """(mass, inertia, (mu_tan, mu_tors)) of the (first) cube of a scene; geom friction defaults (1, 0.005, 0.0001) (MJ-DOC)"""
+    b = [x for x in _G["scenes"][SCENE_OF_TASK[task]]["bodies"] if x["joints"] and x["joints"][0].get("type") == "free"][0]
+    fr = b["geoms"][0].get("friction", 1.0)
+    fr = list(fr) if isinstance(fr, list) else [fr]
+    fr = fr + [1.0, 0.005, 0.0001][len(fr):]
+    return b["inertial"]["mass"], b["inertial"]["diaginertia"][0], (fr[0], fr[1]), b["geoms"][0]["size"][0]
+
+
 # finger proxies (deviation D3): one sphere per finger geom, fitted to the tip of the fixed finger of the
 # link_5_collision hull and to the jaw tip of the link_6_collision hull (follower.xml:89,97)
 SPH_LINK = [4, 5]
 SPH_POS = [(-0.0610, 0.0142, 0.0005), (-0.0490, 0.0072, -0.0140)]
 SPH_RAD = [0.0065, 0.0065]
+# arm-link proxies (deviation D3): spheres inscribed in the hulls of link_3 (both ends), link_4 (motor), link_5 (motor body),
+# link_6 (jaw root); extents: model_golden.json "mesh_slabs_x".  Group 0 = forearm (floor only), group 1 = gripper body
+# (floor and cube).  Same table as oracle/lcr_oracle.c LPX_*.
+LPX_LINK = [2, 2, 3, 4, 5]
+LPX_POS = [(-0.0100, 0.0145, 0.0030), (-0.0950, 0.0145, 0.0030), (-0.0320, 0.0206, 0.0000), (-0.0130, 0.0015, 0.0000),
+           (-0.0120, 0.0000, -0.0145)]
+LPX_RAD = [0.0120, 0.0120, 0.0105, 0.0150, 0.0078]
+LPX_GROUP = [0, 0, 0, 1, 1]
 
 
 def quat2mat(q):
@@ -49,7 +72,7 @@ def rot(axis, th):
 
 
 def fk(q):
-    R = quat2mat((-0.707, 0, 0, 0.707))  # follower.xml:51
+    R = quat2mat(BASE_QUAT)  # follower.xml:51
     p = np.zeros(3)
     out = []
     for i in range(6):
@@ -128,13 +151,26 @@ def main():
         for k, ax in enumerate("xyz"):
             L.append(f"constexpr float SPH{s}{ax} = {f(SPH_POS[s][k])};")
         L.append(f"constexpr float SPH{s}r = {f(SPH_RAD[s])};")
-    L.append("// qpos0 inverse weights (MuJoCo body_invweight0[.,0] of link_5/link_6, dof_invweight0)")
-    L.append(f"constexpr float INVW_TRAN_L5 = {f(tran[4])};")
-    L.append(f"constexpr float INVW_ROT_L5 = {f(rotw[4])};")
-    L.append(f"constexpr float INVW_TRAN_L6 = {f(tran[5])};")
-    L.append(f"constexpr float INVW_ROT_L6 = {f(rotw[5])};")
+    for s in range(len(LPX_LINK)):
+        for k, ax in enumerate("xyz"):
+            L.append(f"constexpr float LPX{s}{ax} = {f(LPX_POS[s][k])};")
+        L.append(f"constexpr float LPX{s}r = {f(LPX_RAD[s])};")
+    L.append("// qpos0 inverse weights (MuJoCo body_invweight0[.,0] of the links, dof_invweight0)")
+    for i in range(6):
+        L.append(f"constexpr float INVW_TRAN_L{i + 1} = {f(tran[i])};")
+        L.append(f"constexpr float INVW_ROT_L{i + 1} = {f(rotw[i])};")
     for j in range(6):
         L.append(f"constexpr float INVW_DOF{j + 1} = {f(dof[j])};")
+    L.append("// joint ranges (follower.xml:58-95) == actuator ctrlrange through inheritrange")
+    L.append("constexpr float JNT_LO[6] = {" + ", ".join(f(r[0]) for r in LINK_RANGE) + "};")
+    L.append("constexpr float JNT_HI[6] = {" + ", ".join(f(r[1]) for r in LINK_RANGE) + "};")
+    L.append("// scene constants by lcr_task (reach, lift, push, pick_place, stack, push_loop): cube mass, inertia, friction (double: host side)")
+    cubes = [scene_cube(t) for t in range(6)]
+    L.append("constexpr double SCENE_CUBE_MASS[6] = {" + ", ".join(repr(float(c[0])) for c in cubes) + "};")
+    L.append("constexpr double SCENE_CUBE_INERTIA[6] = {" + ", ".join(repr(float(c[1])) for c in cubes) + "};")
+    L.append("constexpr double SCENE_CUBE_MU[6] = {" + ", ".join(repr(float(c[2][0])) for c in cubes) + "};")
+    L.append("constexpr double SCENE_CUBE_MU_TORS[6] = {" + ", ".join(repr(float(c[2][1])) for c in cubes) + "};")
+    L.append(f"constexpr float CUBE_HALF = {f(cubes[0][3])};")
     L.append("}  // namespace lcrm")
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gym_lowcostrobot_amd", "csrc", "lcr_model_gen.h")
     with open(dst, "w") as fh:
