@@ -11,7 +11,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
@@ -53,8 +53,11 @@ class LcrConfig(ctypes.Structure):
         ("pgs_iters", ctypes.c_int32),
         ("compat", ctypes.c_uint32),
         ("auto_reset", ctypes.c_int32),
-        ("_pad", ctypes.c_int32),
+        ("arm_collision", ctypes.c_int32),
         ("base_seed", ctypes.c_uint64),
+        ("pgs_tol", ctypes.c_double),
+        ("diagnostics", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
     ]
 
 
@@ -83,6 +86,11 @@ class LcrOutView(ctypes.Structure):
         ("terminal_obs", ctypes.c_void_p),
         ("timestamp", ctypes.c_void_p),
         ("current_goal", ctypes.c_void_p),
+        ("active_mask", ctypes.c_void_p),
+        ("active_count", ctypes.c_void_p),
+        ("max_sweeps", ctypes.c_void_p),
+        ("choice", ctypes.c_void_p),
+        ("ctrl", ctypes.c_void_p),
     ]
 
 

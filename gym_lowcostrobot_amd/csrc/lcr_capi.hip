@@ -116,7 +116,10 @@ int lcr_config_default(lcr_config *cfg, int task) {
     cfg->pgs_iters = 4;
     cfg->compat = 0;
     cfg->auto_reset = 1;
+    cfg->arm_collision = 1;
     cfg->base_seed = 0;
+    cfg->pgs_tol = 1e-6;
+    cfg->diagnostics = 0;
     return LCR_OK;
 }
 
@@ -142,7 +145,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     // the kernels index [component][env] arrays with 32-bit products (20 components at most): keep 20 * n_envs < 2^31
     if (cfg->n_envs > (1 << 26)) return fail(LCR_ERR_INVALID, "n_envs %d exceeds 67108864 per handle; shard the batch over several handles", cfg->n_envs);
     if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
-    if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters must be >= 0");
+    if (cfg->pgs_iters < 0 && !(cfg->pgs_tol > 0)) return fail(LCR_ERR_INVALID, "pgs_tol must be positive in converged mode (pgs_iters < 0)");
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
     int k = lcr_action_dim(cfg);
@@ -192,6 +195,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_succ = off; off += al(N);
     size_t o_dres = off; off += al(N);
     size_t o_tobs = off; off += al(sizeof(float) * LCR_OBS_DIM * N);
+    size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
+    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * 64 * N);   // cube<->cube contact records
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
@@ -239,6 +244,9 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.inv_mu_fct2 = (float)(1.0 / (muft * muft));
         D.walls = loop ? 1 : 0;
     }
+    D.arm_collision = cfg->arm_collision ? 1 : 0;
+    D.diag = cfg->diagnostics ? 1 : 0;
+    D.pgs_tol = (float)cfg->pgs_tol;
     D.cube_mass = (float)cm;
     D.cube_minv = (float)(1.0 / cm);
     D.cube_iinv = (float)(1.0 / ci);
@@ -269,6 +277,12 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.is_success = (unsigned char *)(base + o_succ);
     D.did_reset = (unsigned char *)(base + o_dres);
     D.term_obs = (float *)(base + o_tobs);
+    D.active_mask = cfg->diagnostics ? (unsigned *)(base + o_diag) : nullptr;
+    D.active_count = cfg->diagnostics ? (unsigned *)(base + o_diag + al(sizeof(unsigned) * N)) : nullptr;
+    D.max_sweeps = cfg->diagnostics ? (unsigned *)(base + o_diag + 2 * al(sizeof(unsigned) * N)) : nullptr;
+    D.choice = cfg->diagnostics ? (unsigned *)(base + o_diag + 3 * al(sizeof(unsigned) * N)) : nullptr;
+    D.ctrl_out = cfg->diagnostics ? (float *)(base + o_diag + 4 * al(sizeof(unsigned) * N)) : nullptr;
+    D.scratch = cfg->task == LCR_TASK_STACK ? (float *)(base + o_scr) : nullptr;
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
     D.img_bg = s->has_images ? (unsigned char *)(base + o_bg) : nullptr;
@@ -385,6 +399,11 @@ int lcr_get_outputs(lcr_sim *s, lcr_out_view *out) {
     out->terminal_obs = s->dev.term_obs;
     out->timestamp = s->dev.sim_time;
     out->current_goal = s->dev.goal;
+    out->active_mask = s->dev.active_mask;
+    out->active_count = s->dev.active_count;
+    out->max_sweeps = s->dev.max_sweeps;
+    out->choice = s->dev.choice;
+    out->ctrl = s->dev.ctrl_out;
     return LCR_OK;
 }
 

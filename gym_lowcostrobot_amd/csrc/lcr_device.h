@@ -28,6 +28,9 @@ struct LcrDev {
     float rt_fc;         // finger<->cube: mu_tan^2 / mu_tors^2
     float inv_mu_fct2;   // finger<->cube: 1 / mu_tors^2
     int walls;           // PushCubeLoop rails
+    int arm_collision;   // link-proxy spheres collide (D3)
+    int diag;            // write active_mask / active_count / max_sweeps
+    float pgs_tol;       // converged mode (pgs_iters < 0): sweep until max |df| <= pgs_tol (1 + max |f|)
     // reset sampling boxes, fp64 exactly as the reference builds them (reach_cube_env.py:132-139, push:141-148)
     double cube_lo[3], cube_rng[3], tgt_lo[3], tgt_rng[3];
     // state, SoA [component][n]
@@ -43,6 +46,9 @@ struct LcrDev {
     float *reward;
     unsigned char *terminated, *truncated, *is_success, *did_reset;
     float *term_obs;  // [18][n]
+    unsigned *active_mask, *active_count, *max_sweeps, *choice;  // [n] each, diagnostics of the last step (diag != 0)
+    float *ctrl_out;  // [6][n] actuator targets of the last step (diag != 0)
+    float *scratch;   // Stack: cube<->cube contact records [64][n]
     // image observations
     unsigned char *img_front, *img_top;  // [n][240][320][3] or null
     unsigned char *img_bg;               // [2][240][320][3] env-independent background of camera_front / camera_top, or null

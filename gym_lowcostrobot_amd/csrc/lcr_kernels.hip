@@ -246,34 +246,76 @@ struct ArmSlot {
 
 // constraint forces carried from one substep to the next within a control step (zero at its start): warm start of
 // the PGS sweeps, as MuJoCo warm-starts its solver.  Cube<->cube forces (Stack) persist in their LDS records.
+// arm-coupled contact slots: 0,1 finger sphere 0/1 vs cube; 2,3 finger sphere 0/1 vs floor; 4 link-proxy group 0 (forearm) vs
+// floor, 3 rows; 5 link-proxy group 1 (gripper body) vs floor or cube (per lane), 4 rows (torsion only on a cube)
+constexpr int NAS = 6;
+constexpr int as_rows(int s) { return s == 4 ? 3 : 4; }
+constexpr int as_row0(int s) { return s <= 4 ? 4 * s : 19; }
+constexpr int AS_TOTAL_ROWS = 23;
 template <int NC>
 struct Warm {
     float floor[NC][4][4];
-    float arm[4][4];
+    float arm[NAS][4];
     float lim[6];
     float wall[4][4];
     bool cc_prev[4];
 };
 
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
-constexpr int LDS_SLOT = 4 * LDS_ROW;      // four rows
-constexpr int LDS_G_FLOATS = 4 * LDS_SLOT;  // four slots -> 24 KiB per wave
-// Stack only: cube<->cube contact records, 4 slots x 16 floats per lane: pos3 f4 aref4 inv4 Rn  (16 KiB per wave)
+constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 23 rows -> 34.5 KiB per wave (4 waves per CU: 138 of 160 KiB)
+// Stack only: cube<->cube contact records, 4 slots x 16 floats per env: pos3 f4 aref4 inv4 Rn.  They live in a global
+// scratch array [64][N] (coalesced, touched only by waves that have a cube<->cube contact, ~4 % of the wave-substeps):
+// the LDS is taken by the g rows.
 constexpr int CC_REC = 16;
-constexpr int LDS_CC_FLOATS = 4 * CC_REC * 64;
-// The PushCubeLoop kernel (rails: four more contact slots live in registers) parks the per-substep constants of the floor
-// and finger slots (aref[4], inv[4]: written once per substep, read once per PGS sweep) in LDS as 16-B vectors, which cuts
-// its scratch spills (measured 0.795 -> 0.747 ms per 65 536-env step).  [slot 0..7][aref|inv][lane][4] = 16 KiB per wave.
-// For the other one-cube kernels the register allocator's AGPR copies are faster than the LDS round trip (0.261 vs 0.265 ms).
-constexpr int LDS_PARK_FLOATS = 8 * 2 * 64 * 4;
-template <int NC, bool WALLS> struct LdsSize { static constexpr int value = LDS_G_FLOATS + (NC == 2 ? LDS_CC_FLOATS : (WALLS ? LDS_PARK_FLOATS : 0)); };
+template <int NC, bool WALLS> struct LdsSize { static constexpr int value = LDS_G_FLOATS; };
 typedef float float4v __attribute__((ext_vector_type(4)));
+
+// sphere (centre, radius) vs cube box: signed distance, world normal (box -> sphere) and contact point midway between the surfaces
+struct SBHit { float dist; f3 n, pos; int code; };   // code: 7 centre outside the box, else 2 * face axis + (negative side)
+DEV SBHit sphere_box(f3 centre, float rad, f3 cp, const CubeRot &R) {
+    f3 d = centre - cp;
+    f3 l = mk(dot(R.X, d), dot(R.Y, d), dot(R.Z, d));
+    f3 qv = mk(clampf(l.x, -CH, CH), clampf(l.y, -CH, CH), clampf(l.z, -CH, CH));
+    bool outside = (l.x != qv.x) || (l.y != qv.y) || (l.z != qv.z);
+    f3 df = l - qv;
+    float dn2 = dot(df, df);
+    float idn = rsq(fmaxf(dn2, 1e-30f));
+    float dn = dn2 * idn;
+    f3 nl_out = idn * df;
+    // centre inside the box: face of least depth (first minimal index)
+    float dx = CH - fabsf(l.x), dy = CH - fabsf(l.y), dz = CH - fabsf(l.z);
+    int best = 0; float bd = dx;
+    if (dy < bd) { bd = dy; best = 1; }
+    if (dz < bd) { bd = dz; best = 2; }
+    float sg = ((best == 0 ? l.x : (best == 1 ? l.y : l.z)) < 0.f) ? -1.f : 1.f;
+    f3 nl_in = mk(best == 0 ? sg : 0.f, best == 1 ? sg : 0.f, best == 2 ? sg : 0.f);
+    f3 q_in = mk(best == 0 ? sg * CH : l.x, best == 1 ? sg * CH : l.y, best == 2 ? sg * CH : l.z);
+    f3 nl = outside ? nl_out : nl_in;
+    f3 ql = outside ? qv : q_in;
+    float dd = outside ? dn - rad : -(bd + rad);
+    f3 pl = axpy(0.5f * dd, nl, ql);
+    SBHit h;
+    h.code = outside ? 7 : 2 * best + (sg < 0.f ? 1 : 0);
+    h.dist = dd;
+    h.n = axpy(nl.x, R.X, axpy(nl.y, R.Y, nl.z * R.Z));
+    h.pos = axpy(pl.x, R.X, axpy(pl.y, R.Y, axpy(pl.z, R.Z, cp)));
+    return h;
+}
+
+// per-env diagnostics of one control step (written only when LcrDev.diag): which constraint slots were active (bit = slot id:
+// 0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor, 16-17 link-proxy groups, 18+j limit j),
+// the number of (slot, substep) activations, and the largest PGS sweep count of a substep
+struct Diag { unsigned mask, count, sweeps, choice; };
+// choice: wrapping sum over substeps s (weight 2s + 1) and active constraints of (slot + 1)(sel + 1) 2654435761, sel = the discrete choice behind
+// the contact (vertex index, manifold candidate, box face case, proxy member, limit side) -- same formula as the oracle's
+DEV void diag_choice(Diag &DG, bool act, int slot, int sel) { DG.choice += act ? (unsigned)(slot + 1) * (unsigned)(sel + 1) * 2654435761u : 0u; }
 
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool WALLS>
-DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC> &W) {
+template <int NC, bool WALLS, bool ADAPT>
+DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC> &W, Diag &DGtot, int sub_index) {
+    Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
     // ---- position stage -------------------------------------------------------------------------
     CubeRot CR[NC];
@@ -413,6 +455,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 FS[c][s].r = mk(rv[s].x, rv[s].y, rv[s].z - 0.5f * vd[s]);
                 sdist[s] = vd[s];
                 FS[c][s].act = vd[s] < 0.f;
+                if (P.diag) diag_choice(DG, FS[c][s].act, 4 * c + s, s);
             }
         } else {
             int cnt = 0;
@@ -428,6 +471,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     FS[c][s].r.z = take ? rv[i].z - 0.5f * dist : FS[c][s].r.z;  // contact point midway between vertex and plane
                     sdist[s] = take ? dist : sdist[s];
                     FS[c][s].act = FS[c][s].act || take;
+                    if (P.diag) diag_choice(DG, take, 4 * c + s, i);
                 }
                 cnt += pen ? 1 : 0;
             }
@@ -449,11 +493,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
             T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
             T.inv[3] = rcp(iinv + Rt);
-            if constexpr (NC == 1 && WALLS) {
-                float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
-                pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
-                pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
-            }
             // warm start: forces of the previous substep if this slot was active then (inactive slots were zeroed)
 #pragma unroll
             for (int k = 0; k < 4; k++) { T.f[k] = T.act ? W.floor[c][s][k] : 0.f; }
@@ -473,7 +512,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool cc_act[4] = {false, false, false, false};
     bool cc_any = false;
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
-    float *ccl = lds + LDS_G_FLOATS + lane;  // record field k of slot s at ccl[(s*CC_REC + k)*64]
+    float *ccl = (NC == 2 ? P.scratch : lds) + env;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*N] (global scratch, see CC_REC)
+    const size_t CS = (size_t)P.n;
     if constexpr (NC == 2) {
         const f3 dc = S.cp[1] - S.cp[0];
         const f3 ax0[3] = {CR[0].X, CR[0].Y, CR[0].Z}, ax1[3] = {CR[1].X, CR[1].Y, CR[1].Z};
@@ -581,6 +621,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int s2 = 0; s2 < s; s2++) dup = dup || (sidx[s2] == sidx[s]);
                 cc_act[s] = sidx[s] >= 0 && !dup;
                 cnt += cc_act[s] ? 1 : 0;
+                if (P.diag) diag_choice(DG, cc_act[s], 8 + s, sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0.f ? 1 : 0));
             }
         }
         cc_any = __any(cnt > 0) != 0;
@@ -595,7 +636,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 float Rt = Rf * P.rt_cube;
                 f3 vrel = (S.cv[1] + cross(cww[1], r1)) - (S.cv[0] + cross(cww[0], r0));
                 f3 wrel = cww[1] - cww[0];
-                ccl[(s * CC_REC + 0) * 64] = cpos[s].x; ccl[(s * CC_REC + 1) * 64] = cpos[s].y; ccl[(s * CC_REC + 2) * 64] = cpos[s].z;
+                ccl[(size_t)(s * CC_REC + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CC_REC + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CC_REC + 2) * CS] = cpos[s].z;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
@@ -606,18 +647,18 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     else diag = 2.f * iinv;
                     float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                     {   // f: keep the previous substep's force if the slot was active then, and apply it
-                        float fw = (cc_act[s] && W.cc_prev[s]) ? ccl[(s * CC_REC + 3 + r) * 64] : 0.f;
-                        ccl[(s * CC_REC + 3 + r) * 64] = fw;
+                        float fw = (cc_act[s] && W.cc_prev[s]) ? ccl[(size_t)(s * CC_REC + 3 + r) * CS] : 0.f;
+                        ccl[(size_t)(s * CC_REC + 3 + r) * CS] = fw;
                         if (r < 3) {
                             f3 a0 = cross(r0, d), a1 = cross(r1, d);
                             ca[1] = axpy(minv * fw, d, ca[1]); ca[0] = axpy(-minv * fw, d, ca[0]);
                             cal[1] = axpy(iinv * fw, a1, cal[1]); cal[0] = axpy(-iinv * fw, a0, cal[0]);
                         } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
                     }
-                    ccl[(s * CC_REC + 7 + r) * 64] = aref;
-                    ccl[(s * CC_REC + 11 + r) * 64] = rcp(diag + Rr);
+                    ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
+                    ccl[(size_t)(s * CC_REC + 11 + r) * CS] = rcp(diag + Rr);
                 }
-                ccl[(s * CC_REC + 15) * 64] = Rn;
+                ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
             }
         }
     }
@@ -661,6 +702,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 float d1 = 0.f, d2 = 0.f;
                 bool h1 = false, h2 = false;
                 f3 r1 = mk(0.f, 0.f, 0.f), r2 = mk(0.f, 0.f, 0.f);
+                int i1 = 0, i2 = 0;   // vertex indices of the two (diagnostics only)
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const f3 p = vw[i] + S.cp[0];
@@ -668,6 +710,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const bool pen = dist < 0.f && p.z < WALL_TOP;
                     const bool first = pen && (!h1 || dist < d1);
                     const bool second = pen && !first && (!h2 || dist < d2);
+                    if (P.diag) { i2 = first ? i1 : (second ? i : i2); i1 = first ? i : i1; }
                     d2 = first ? d1 : (second ? dist : d2);
                     r2 = first ? r1 : (second ? vw[i] : r2);
                     h2 = first ? h1 : (second ? true : h2);
@@ -684,6 +727,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float dist = c == 0 ? d1 : d2;
                     const f3 rw = c == 0 ? r1 : r2;
                     T.act = c == 0 ? h1 : h2;
+                    if (P.diag) diag_choice(DG, T.act, 8 + 2 * pr + c, (c == 0 ? i1 : i2) + 8 * (2 * pr + (sg > 0.f ? 0 : 1)));
                     f3 r = pr == 0 ? rw : mk(rw.y, rw.z, rw.x);
                     r.x = fmaf(-0.5f * dist, sg, r.x);   // contact point midway between vertex and face
                     T.r = r;
@@ -715,25 +759,30 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
     }
 
-    // ---- collision: finger spheres (one per finger geom) vs cube / floor; rows g = L^-1 J^T go to LDS ----
-    ArmSlot AS[4];
-    bool slot_any[4];
+    // ---- collision: arm-coupled contact slots (NAS): finger spheres vs cube / floor, link-proxy groups (D3); rows g = L^-1 J^T
+    //      go to LDS.  Every slot is skipped wave-uniformly when no lane of the wave touches. ----
+    ArmSlot AS[NAS];
+    bool slot_any[NAS];
+    bool on_cube5 = false;       // slot 5: this lane's contact is against a cube (else the floor)
+    bool last_joint[2] = {false, false};   // slot 4: joint 4 moves the contact (proxy on link_4); slot 5: joint 6 (proxy on link_6)
+    int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 5 refer to (Stack)
+    {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
     const float srad[2] = {SPH0r, SPH1r};
-    int slot_cube[2] = {0, 0};  // which cube each sphere's cube slot refers to
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < NAS; s++) {
         const int sp = s & 1;
-        const bool vs_cube = s < 2;
+        const bool may_cube = s < 2 || s == 5;   // literal after unrolling
         ArmSlot &T = AS[s];
-        f3 pos, n;
-        float dist;
+        f3 pos = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 1.f);
+        float dist = 1.f;
         int cidx = 0;
-        if (vs_cube) {
-            // sphere vs box: closest point on the box in the box frame
+        bool oncube = s < 2;
+        float invw_link = sp == 0 ? INVW_TRAN_L5 : INVW_TRAN_L6;
+        int sel = 0;   // discrete choice behind the contact (diagnostics)
+        if (s < 2) {
+            // sphere vs box; broad phase (wave-uniform): a sphere farther than r + h*sqrt(3) from every cube centre cannot touch
             float bestd = 1e30f;
-            pos = mk(0.f, 0.f, 0.f); n = mk(0.f, 0.f, 1.f);
-            // broad phase (wave-uniform): a sphere farther than r + h*sqrt(3) from every cube centre cannot touch
             bool near_any = false;
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -743,112 +792,143 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             if (__any(near_any))
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                f3 d = sph[sp] - S.cp[c];
-                f3 l = mk(dot(CR[c].X, d), dot(CR[c].Y, d), dot(CR[c].Z, d));
-                f3 qv = mk(clampf(l.x, -CH, CH), clampf(l.y, -CH, CH), clampf(l.z, -CH, CH));
-                bool outside = (l.x != qv.x) || (l.y != qv.y) || (l.z != qv.z);
-                f3 df = l - qv;
-                float dn2 = dot(df, df);
-                float idn = rsq(fmaxf(dn2, 1e-30f));
-                float dn = dn2 * idn;
-                f3 nl_out = idn * df;
-                // centre inside the box: face of least depth (first minimal index)
-                float dx = CH - fabsf(l.x), dy = CH - fabsf(l.y), dz = CH - fabsf(l.z);
-                int best = 0; float bd = dx;
-                if (dy < bd) { bd = dy; best = 1; }
-                if (dz < bd) { bd = dz; best = 2; }
-                float sg = ((best == 0 ? l.x : (best == 1 ? l.y : l.z)) < 0.f) ? -1.f : 1.f;
-                f3 nl_in = mk(best == 0 ? sg : 0.f, best == 1 ? sg : 0.f, best == 2 ? sg : 0.f);
-                f3 q_in = mk(best == 0 ? sg * CH : l.x, best == 1 ? sg * CH : l.y, best == 2 ? sg * CH : l.z);
-                f3 nl = outside ? nl_out : nl_in;
-                f3 ql = outside ? qv : q_in;
-                float dd = outside ? dn - srad[sp] : -(bd + srad[sp]);
-                f3 pl = axpy(0.5f * dd, nl, ql);
-                if (dd < bestd) {  // deepest cube wins (tie: cube 0)
-                    bestd = dd; cidx = c;
-                    n = axpy(nl.x, CR[c].X, axpy(nl.y, CR[c].Y, nl.z * CR[c].Z));
-                    pos = axpy(pl.x, CR[c].X, axpy(pl.y, CR[c].Y, axpy(pl.z, CR[c].Z, S.cp[c])));
-                }
+                const SBHit hit = sphere_box(sph[sp], srad[sp], S.cp[c], CR[c]);
+                if (hit.dist < bestd) { bestd = hit.dist; cidx = c; n = hit.n; pos = hit.pos; sel = 8 * c + hit.code; }  // deepest cube wins (tie: cube 0)
             }
             dist = bestd;
             slot_cube[sp] = cidx;
-        } else {
+        } else if (s < 4) {
             dist = sph[sp].z - srad[sp];
-            n = mk(0.f, 0.f, 1.f);
             pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
+        } else if (s == 4) {
+            // link-proxy group 0 (both ends of link_3, link_4 motor) vs the floor: the deepest member (tie: lower index)
+            const f3 c0 = local_point(F, 2, LPX0x, LPX0y, LPX0z), c1 = local_point(F, 2, LPX1x, LPX1y, LPX1z), c2 = local_point(F, 3, LPX2x, LPX2y, LPX2z);
+            const float d0 = c0.z - LPX0r, d1 = c1.z - LPX1r, d2 = c2.z - LPX2r;
+            f3 c = c0; dist = d0; sel = 64;
+            if (d1 < dist) { dist = d1; c = c1; sel = 128; }
+            const bool l4 = d2 < dist;
+            if (l4) { dist = d2; c = c2; sel = 192; }
+            last_joint[0] = l4;
+            invw_link = l4 ? INVW_TRAN_L4 : INVW_TRAN_L3;
+            pos = mk(c.x, c.y, 0.5f * dist);
+            if (!P.arm_collision) dist = 1.f;
+        } else {
+            // link-proxy group 1 (link_5 motor body, link_6 jaw root) vs the floor and the cube(s): deepest candidate in the
+            // order member 0 floor, member 0 cubes, member 1 floor, member 1 cubes (ties: first)
+            const f3 cm[2] = {local_point(F, 4, LPX3x, LPX3y, LPX3z), local_point(F, 5, LPX4x, LPX4y, LPX4z)};
+            const float rm[2] = {LPX3r, LPX4r};
+            float bestd = 1e30f;
+            bool near_any = false;
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const f3 dd = cm[m] - S.cp[c];
+                    near_any = near_any || dot(dd, dd) < (rm[m] + 1.7321f * CH) * (rm[m] + 1.7321f * CH);
+                }
+            const bool wave_near = __any(near_any) != 0;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const float df = cm[m].z - rm[m];
+                if (df < bestd) { bestd = df; pos = mk(cm[m].x, cm[m].y, 0.5f * df); n = mk(0.f, 0.f, 1.f); oncube = false; last_joint[1] = m == 1; sel = 64 * (m + 4); }
+                if (wave_near)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const SBHit hit = sphere_box(cm[m], rm[m], S.cp[c], CR[c]);
+                    if (hit.dist < bestd) { bestd = hit.dist; pos = hit.pos; n = hit.n; oncube = true; cidx = c; last_joint[1] = m == 1; sel = 64 * (m + 4) + 32 + 8 * c + hit.code; }
+                }
+            }
+            dist = P.arm_collision ? bestd : 1.f;
+            on_cube5 = oncube;
+            slot_cube[2] = cidx;
+            invw_link = last_joint[1] ? INVW_TRAN_L6 : INVW_TRAN_L5;
         }
         T.act = dist < 0.f;
+        if (P.diag) {
+            if (may_cube && (s < 2 || oncube)) sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : 16;   // branch of make_frame
+            diag_choice(DG, T.act, 12 + s, sel);
+        }
         slot_any[s] = __any(T.act) != 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) { T.f[k] = 0.f; T.aref[k] = 0.f; T.inv[k] = 0.f; }
         T.Rn = 1.f; T.n = n; T.t1 = mk(0.f, 1.f, 0.f); T.t2 = mk(-1.f, 0.f, 0.f); T.rc = mk(0.f, 0.f, 0.f);
         if (slot_any[s]) {  // wave-uniform: skip the whole row set-up when no lane of the wave touches
-            if (vs_cube) make_frame(n, T.t1, T.t2);
-            const int nj = sp == 0 ? 5 : 6;  // sphere 0 sits on link_5 (joints 1..5), sphere 1 on link_6
-            const float invw_link = sp == 0 ? INVW_TRAN_L5 : INVW_TRAN_L6;
+            if (may_cube) make_frame(n, T.t1, T.t2);   // (for n = +z this is the floor frame t1 = +y, t2 = -x)
+            // joints that move the contact point: the finger spheres sit on link_5 / link_6, the proxies on link_3..link_6
+            auto joint_on = [&](int j) -> bool {
+                if (s < 4) return j < (sp == 0 ? 5 : 6);
+                if (s == 4) return j < 3 || (j == 3 && last_joint[0]);
+                return j < 5 || last_joint[1];
+            };
             f3 cube_p = mk(0.f, 0.f, 0.f), cube_v = mk(0.f, 0.f, 0.f), cube_w = mk(0.f, 0.f, 0.f);
-            if (vs_cube) {
+            if (may_cube) {
                 if (NC == 2 && cidx == 1) { cube_p = S.cp[NC - 1]; cube_v = S.cv[NC - 1]; cube_w = cww[NC - 1]; }
                 else { cube_p = S.cp[0]; cube_v = S.cv[0]; cube_w = cww[0]; }
                 T.rc = pos - cube_p;
             }
             float imp, Kc, Bc;
-            if (vs_cube) { imp = impedance(dist, D0_FC, DW_FC, 1.0f / W_FC); Kc = K_FC; Bc = B_FC; }
-            else { imp = impedance(dist, D0_FF, DW_FF, 1.0f / W_FF); Kc = K_FF; Bc = B_FF; }
-            float Rn = fmaxf((1.f - imp) * rcp(imp) * (invw_link + (vs_cube ? minv : 0.f)), 1e-15f);
+            if (s < 2) { imp = impedance(dist, D0_FC, DW_FC, 1.0f / W_FC); Kc = K_FC; Bc = B_FC; }
+            else if (s < 4) { imp = impedance(dist, D0_FF, DW_FF, 1.0f / W_FF); Kc = K_FF; Bc = B_FF; }
+            else { imp = impedance(dist, D0_DEF, DW_DEF, 1.0f / W_DEF); Kc = K_DEF; Bc = B_DEF; }   // link geoms: default solref / solimp
+            float Rn = fmaxf((1.f - imp) * rcp(imp) * (invw_link + ((may_cube && oncube) ? minv : 0.f)), 1e-15f);
             float Rf = Rn * P.inv_impratio;
-            float Rt = Rf * (vs_cube ? P.rt_fc : RT_FF);
+            float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
             T.Rn = Rn;
             // point Jacobian columns of the link at the contact point
             f3 jc[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) jc[j] = j < nj ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
+            for (int j = 0; j < 6; j++) {
+                const bool lit = s < 4 ? j < (sp == 0 ? 5 : 6) : (s == 4 ? j < 4 : true);   // columns that can be non-zero at all
+                jc[j] = lit ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
+                if (lit && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < as_rows(s); r++) {
                 const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
                 float g[6];
                 float vel = 0.f;
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
-                    g[j] = r < 3 ? dot(jc[j], d) : (j < nj ? dot(z[j], d) : 0.f);
+                    g[j] = r < 3 ? dot(jc[j], d) : (joint_on(j) ? dot(z[j], d) : 0.f);
                     vel = fmaf(g[j], S.qd[j], vel);
                 }
                 float diagc = 0.f;
-                if (vs_cube) {
+                if (may_cube) {
+                    float velc;
                     if (r < 3) {
                         f3 rxd = cross(T.rc, d);
-                        vel -= dot(d, cube_v) + dot(rxd, cube_w);
+                        velc = dot(d, cube_v) + dot(rxd, cube_w);
                         diagc = minv + iinv * dot(rxd, rxd);
                     } else {
-                        vel -= dot(d, cube_w);
+                        velc = dot(d, cube_w);
                         diagc = iinv;
                     }
+                    if (s == 5) { velc = oncube ? velc : 0.f; diagc = oncube ? diagc : 0.f; }
+                    vel -= velc;
                 }
                 fsub(CL, g);
                 float gg = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; j++) { gg = fmaf(g[j], g[j], gg); lds[s * LDS_SLOT + r * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j]; }
+                for (int j = 0; j < 6; j++) { gg = fmaf(g[j], g[j], gg); lds[(as_row0(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j]; }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 T.inv[r] = rcp(gg + diagc + Rr);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
-                const float fw = T.act ? W.arm[s][r] : 0.f;
+                const bool row_on = T.act && (s != 5 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
+                const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
 #pragma unroll
                 for (int j = 0; j < 6; j++) y[j] = fmaf(g[j], fw, y[j]);
-                if (vs_cube) {
-                    f3 dl = r < 3 ? (-minv * fw) * d : mk(0.f, 0.f, 0.f);
-                    f3 da = r < 3 ? (-iinv * fw) * cross(T.rc, d) : (-iinv * fw) * d;
+                if (may_cube) {
+                    const float fc = (s == 5 && !oncube) ? 0.f : fw;
+                    f3 dl = r < 3 ? (-minv * fc) * d : mk(0.f, 0.f, 0.f);
+                    f3 da = r < 3 ? (-iinv * fc) * cross(T.rc, d) : (-iinv * fc) * d;
                     if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
                     else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
                 }
             }
-            if constexpr (NC == 1 && WALLS) {
-                float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)((4 + s) * 2) * 64 + lane;
-                pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
-                pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
-            }
         }
+    }
     }
 
     // ---- joint limits (rare): rows +-e_j ---------------------------------------------------------
@@ -858,6 +938,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         lim_act[j] = (S.q[j] < JLO[j]) || (S.q[j] > JHI[j]);
+        if (P.diag) diag_choice(DG, lim_act[j], 18 + j, S.q[j] < JLO[j] ? 0 : 1);
         flim[j] = lim_act[j] ? W.lim[j] : 0.f;
         any_lim = any_lim || lim_act[j];
     }
@@ -873,10 +954,21 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], flim[j], y[k]);
         }
     }
-    const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3];
+    const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3] || slot_any[4] || slot_any[5];
 
-    // ---- projected Gauss-Seidel on the dual, matrix-free, cold start, fixed sweeps -----------------
-    for (int it = 0; it < P.pgs_iters; it++) {
+    // ---- projected Gauss-Seidel on the dual, matrix-free, warm-started.  Fixed sweep count (pgs_iters > 0), or ADAPT
+    //      (pgs_iters < 0): sweep until the largest force change of a sweep is <= pgs_tol (1 + largest |force|) in EVERY lane
+    //      of the wave, at most 50 sweeps ----
+    const int max_it = ADAPT ? 50 : P.pgs_iters;
+    int sweeps_done = 0;
+    for (int it = 0; it < max_it; it++) {
+        float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep
+        auto track = [&](float d0, float d1, float d2, float d3, float f0, float f1, float f2, float f3_) {
+            if (ADAPT) {
+                chg = fmaxf(fmaxf(chg, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+                fmx = fmaxf(fmaxf(fmx, fmaxf(fabsf(f0), fabsf(f1))), fmaxf(fabsf(f2), fabsf(f3_)));
+            }
+        };
         if (wave_lim) {
 #pragma unroll
             for (int j = 0; j < 6; j++) {
@@ -897,6 +989,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 float nf = fmaxf(flim[j] - res * rcp(gg + Rl), 0.f);
                 float dl = lim_act[j] ? nf - flim[j] : 0.f;
                 flim[j] += dl;
+                track(dl, 0.f, 0.f, 0.f, flim[j], 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], dl, y[k]);
             }
@@ -916,12 +1009,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
                 float aref0 = T.aref[0], aref1 = T.aref[1], aref2 = T.aref[2], aref3 = T.aref[3];
                 float inv0 = T.inv[0], inv1 = T.inv[1], inv2 = T.inv[2], inv3 = T.inv[3];
-                if constexpr (NC == 1 && WALLS) {
-                    const float4v *pk = reinterpret_cast<const float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
-                    const float4v a4 = pk[0], i4 = pk[64];
-                    aref0 = a4.x; aref1 = a4.y; aref2 = a4.z; aref3 = a4.w;
-                    inv0 = i4.x; inv1 = i4.y; inv2 = i4.z; inv3 = i4.w;
-                }
                 const float u0 = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - aref0 + T.Rn * T.f[0];
                 const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - aref1 + Rf * T.f[1];
                 const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - aref2 + Rf * T.f[2];
@@ -939,6 +1026,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
                 const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                 T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
                 // a += M^-1 J^T delta
                 ca[c].z = fmaf(minv, d0, ca[c].z);
                 ca[c].y = fmaf(minv, d1, ca[c].y);
@@ -955,17 +1043,17 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const bool act = cc_act[s];
-                    const f3 pos = mk(ccl[(s * CC_REC + 0) * 64], ccl[(s * CC_REC + 1) * 64], ccl[(s * CC_REC + 2) * 64]);
+                    const f3 pos = mk(ccl[(size_t)(s * CC_REC + 0) * CS], ccl[(size_t)(s * CC_REC + 1) * CS], ccl[(size_t)(s * CC_REC + 2) * CS]);
                     const f3 r0 = pos - S.cp[0], r1 = pos - S.cp[1];
-                    const float Rn = ccl[(s * CC_REC + 15) * 64];
+                    const float Rn = ccl[(size_t)(s * CC_REC + 15) * CS];
                     const float Rf = Rn * P.inv_impratio;
                     const float Rt = Rf * P.rt_cube;
                     float f[4], aref[4], inv[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        f[r] = ccl[(s * CC_REC + 3 + r) * 64];
-                        aref[r] = ccl[(s * CC_REC + 7 + r) * 64];
-                        inv[r] = ccl[(s * CC_REC + 11 + r) * 64];
+                        f[r] = ccl[(size_t)(s * CC_REC + 3 + r) * CS];
+                        aref[r] = ccl[(size_t)(s * CC_REC + 7 + r) * CS];
+                        inv[r] = ccl[(size_t)(s * CC_REC + 11 + r) * CS];
                     }
                     // relative acceleration of the contact point (cube 1 minus cube 0) and relative angular acceleration
                     const f3 A = (ca[1] + cross(cal[1], r1)) - (ca[0] + cross(cal[0], r0));
@@ -989,8 +1077,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
                     const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
                     const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
-                    ccl[(s * CC_REC + 3) * 64] = fn; ccl[(s * CC_REC + 4) * 64] = f[1] + e1;
-                    ccl[(s * CC_REC + 5) * 64] = f[2] + e2; ccl[(s * CC_REC + 6) * 64] = f[3] + e3;
+                    track(d0, d1a, d2a, d3a, fn, f[1] + e1, f[2] + e2, f[3] + e3);
+                    ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
+                    ccl[(size_t)(s * CC_REC + 5) * CS] = f[2] + e2; ccl[(size_t)(s * CC_REC + 6) * CS] = f[3] + e3;
                     // a += M^-1 J^T delta: the force change F acts at the contact point on cube 1 and, negated, on cube 0
                     const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
                     const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
@@ -1029,6 +1118,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
                     const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                     T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                    track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
                     const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
                     const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
                     const float ab = iinv * sg * (r.z * d0 - r.x * d2);
@@ -1038,34 +1128,31 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
         }
-        // finger spheres
+        // arm-coupled slots: finger spheres, link-proxy groups
         if (wave_arm) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < NAS; s++) {
                 if (!slot_any[s]) continue;
                 ArmSlot &T = AS[s];
-                const bool vs_cube = s < 2;
-                const int sp = s & 1;
+                const bool may_cube = s < 2 || s == 5;
+                const bool oncube = s < 2 || (s == 5 && on_cube5);
+                const int nrow = as_rows(s);
                 const float Rf = T.Rn * P.inv_impratio;
-                const float Rt = Rf * (vs_cube ? P.rt_fc : RT_FF);
+                const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
                 // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
                 float2v g[4][3];
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int r = 0; r < nrow; r++)
 #pragma unroll
-                    for (int k = 0; k < 3; k++) g[r][k] = *reinterpret_cast<const float2v *>(&lds[s * LDS_SLOT + r * LDS_ROW + k * 128 + lane * 2]);
+                    for (int k = 0; k < 3; k++) g[r][k] = *reinterpret_cast<const float2v *>(&lds[(as_row0(s) + r) * LDS_ROW + k * 128 + lane * 2]);
                 float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
-                float arefv[4] = {T.aref[0], T.aref[1], T.aref[2], T.aref[3]}, invv[4] = {T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
-                if constexpr (NC == 1 && WALLS) {
-                    const float4v *pk = reinterpret_cast<const float4v *>(lds + LDS_G_FLOATS) + (size_t)((4 + s) * 2) * 64 + lane;
-                    const float4v a4 = pk[0], i4 = pk[64];
-                    arefv[0] = a4.x; arefv[1] = a4.y; arefv[2] = a4.z; arefv[3] = a4.w;
-                    invv[0] = i4.x; invv[1] = i4.y; invv[2] = i4.z; invv[3] = i4.w;
-                }
+                const float arefv[4] = {T.aref[0], T.aref[1], T.aref[2], T.aref[3]}, invv[4] = {T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
                 // pick the cube this slot talks to (wave-divergent only for Stack)
                 f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
-                const bool second = vs_cube && NC == 2 && slot_cube[sp] == 1;
-                if (vs_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+                const bool second = may_cube && NC == 2 && slot_cube[s == 5 ? 2 : (s & 1)] == 1;
+                if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+                // cube-side inverse inertia of this lane's contact (zero when slot 5 touches the floor: the cube terms vanish)
+                const float minv_e = (s == 5 && !oncube) ? 0.f : minv, iinv_e = (s == 5 && !oncube) ? 0.f : iinv;
                 // The cube's share of the four row residuals is tracked as SCALARS: v_r = d_r . (acceleration of the contact
                 // point of the cube), wn = n . (angular acceleration).  A force change dlt on row j moves them by closed-form
                 // couplings, because (rc x d_i).(rc x d_j) = |rc|^2 delta_ij - (rc.d_i)(rc.d_j) for the orthonormal frame:
@@ -1073,54 +1160,64 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // and the summed force is applied to the cube once at the end of the slot.
                 float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f;
                 float f_in[4] = {T.f[0], T.f[1], T.f[2], T.f[3]};
-                if (vs_cube) {
+                if (may_cube) {
                     const f3 Ac = a_lin + cross(a_ang, T.rc);
                     vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
                     pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
                     wn = dot(T.n, a_ang);
-                    kq = fmaf(iinv, dot(T.rc, T.rc), minv);
+                    kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
+                    if (s == 5) {   // floor lanes: no cube share in the residuals
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
+                        wn = oncube ? wn : 0.f;
+                    }
                 }
                 // effect of a force change dlt on row j on the tracked scalars
                 auto couple = [&](int j, float dlt) {
                     if (j < 3) {
-                        const float c = iinv * pq[j] * dlt;
+                        const float c = iinv_e * pq[j] * dlt;
 #pragma unroll
                         for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
                         vq[j] = fmaf(-kq, dlt, vq[j]);
                         // n.(rc x t1) = -rc.t2, n.(rc x t2) = rc.t1, n.(rc x n) = 0
-                        if (j == 1) wn = fmaf(iinv * dlt, pq[2], wn);
-                        if (j == 2) wn = fmaf(-iinv * dlt, pq[1], wn);
+                        if (j == 1) wn = fmaf(iinv_e * dlt, pq[2], wn);
+                        if (j == 2) wn = fmaf(-iinv_e * dlt, pq[1], wn);
                     } else {   // torsion: angular acceleration changes by -iinv dlt n; contact point by (-iinv dlt n) x rc
-                        wn = fmaf(-iinv, dlt, wn);
-                        vq[1] = fmaf(iinv * dlt, pq[2], vq[1]);    // t1.(n x rc) = -p_2
-                        vq[2] = fmaf(-iinv * dlt, pq[1], vq[2]);   // t2.(n x rc) =  p_1
+                        wn = fmaf(-iinv_e, dlt, wn);
+                        vq[1] = fmaf(iinv_e * dlt, pq[2], vq[1]);    // t1.(n x rc) = -p_2
+                        vq[2] = fmaf(-iinv_e * dlt, pq[1], vq[2]);   // t2.(n x rc) =  p_1
                     }
                 };
+                float dtr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < nrow; r++) {
                     const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
                     const float gy = acc.x + acc.y;
-                    const float jc_a = vs_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                    const float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
                     const float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
                     float res = gy + jc_a - arefv[r] + Rr * T.f[r];
                     float nf = T.f[r] - res * invv[r];
                     if (r == 0) nf = fmaxf(nf, 0.f);
-                    float dlt = T.act ? nf - T.f[r] : 0.f;
+                    const bool row_on = T.act && (s != 5 || r < 3 || oncube);
+                    float dlt = row_on ? nf - T.f[r] : 0.f;
                     T.f[r] += dlt;
+                    dtr[r] = dlt;
                     {
                         const float2v d2 = {dlt, dlt};
 #pragma unroll
                         for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
                     }
-                    if (vs_cube) couple(r, dlt);
+                    if (may_cube) couple(r, dlt);
                 }
-                // cone projection
+                // cone projection (finger geoms: mu 1.5; a link proxy on the floor: mu 1; on a cube: the cube's friction)
                 {
                     float fn = T.f[0];
-                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * (1.f / (MU_FINGER * MU_FINGER)) + T.f[3] * T.f[3] * (vs_cube ? P.inv_mu_fct2 : 1.f / (MU_TORS * MU_TORS));
+                    const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (s == 4 ? 1.f : (oncube ? P.inv_mu_c2 : 1.f));
+                    const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
+                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow == 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
                     float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
 #pragma unroll
-                    for (int r = 1; r < 4; r++) {
+                    for (int r = 1; r < nrow; r++) {
                         float dlt = T.f[r] * sc - T.f[r];
                         T.f[r] += dlt;
                         const float2v d2 = {dlt, dlt};
@@ -1129,21 +1226,26 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         // (the tracked scalars are not needed any more: the next slot starts from the updated accelerations)
                     }
                 }
+                track(dtr[0], dtr[1], dtr[2], dtr[3], T.f[0], T.f[1], T.f[2], T.f[3]);
                 f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
-                if (vs_cube) {
+                if (may_cube) {
                     const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
-                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the finger; the cube gets -Fd at rc
-                    dl_lin = (-minv) * Fd;
-                    dl_ang = (-iinv) * axpy(e3, T.n, cross(T.rc, Fd));
+                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
+                    dl_lin = (-minv_e) * Fd;
+                    dl_ang = (-iinv_e) * axpy(e3, T.n, cross(T.rc, Fd));
                 }
                 y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
-                if (vs_cube) {
+                if (may_cube) {
                     if (NC == 2) {
                         if (second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }
                         else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
                     } else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
                 }
             }
+        }
+        sweeps_done = it + 1;
+        if (ADAPT) {
+            if (__all(chg <= P.pgs_tol * (1.f + fmx))) break;
         }
     }
 
@@ -1155,10 +1257,31 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
             for (int k = 0; k < 4; k++) W.floor[c][s][k] = FS[c][s].f[k];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < NAS; s++)
 #pragma unroll
         for (int k = 0; k < 4; k++) W.arm[s][k] = AS[s].f[k];
-        W.cc_prev[s] = cc_act[s];
+#pragma unroll
+    for (int s = 0; s < 4; s++) W.cc_prev[s] = cc_act[s];
+    if (P.diag) {   // wave-uniform
+        unsigned m = 0u;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) m |= FS[c][s].act ? (1u << (4 * c + s)) : 0u;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
+            if (WALLS) m |= WS[s].act ? (1u << (8 + s)) : 0u;
+        }
+        m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u;
+        m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;
+        m |= AS[4].act ? (1u << 16) : 0u; m |= AS[5].act ? (1u << 17) : 0u;
+#pragma unroll
+        for (int j = 0; j < 6; j++) m |= lim_act[j] ? (1u << (18 + j)) : 0u;
+        DGtot.mask |= m;
+        DGtot.count += (unsigned)__popc(m);
+        DGtot.sweeps = max(DGtot.sweeps, (unsigned)(m ? sweeps_done : 0));
+        DGtot.choice += DG.choice * (unsigned)(2 * sub_index + 1);   // odd weight: the same choice in another substep hashes differently
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = flim[j];
@@ -1283,7 +1406,7 @@ DEV void write_obs18(const LcrDev &P, float *dst, int e, const EnvState<NC> &S, 
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool WALLS>
+template <int NC, bool EE, bool WALLS, bool ADAPT>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
     __shared__ float lds[LdsSize<NC, WALLS>::value];
     const int lane = threadIdx.x;
@@ -1305,6 +1428,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     for (int i = 0; i < 6; i++) act[i] = i < P.k ? clampf(action[(size_t)i * N + e], -1.f, 1.f) : 0.f;  // np.clip reach:234
     float ctrl[6];
     f3 lag_ee = mk(0.f, 0.f, 0.f);
+    int ik_iters = 0;   // executed iterations of the reference's IK loop (diagnostics)
     if (EE) {
         f3 eel = mk(P.ee_lag[e], P.ee_lag[N + e], P.ee_lag[2 * N + e]);
         f3 tgt = mk(eel.x + act[0] * 0.05f, eel.y + act[1] * 0.05f, fmaxf(eel.z + act[2] * 0.05f, 0.f));  // reach:241-242
@@ -1314,6 +1438,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         for (int j = 0; j < 6; j++) { qk[j] = S.q[j]; qstate[j] = S.q[j]; }
         bool done = false;
         for (int it = 0; it < 10; it++) {
+            ik_iters += done ? 0 : 1;
             ArmFrames F;
             arm_frames(qk, F);
             f3 site = site_pos(F);
@@ -1379,18 +1504,25 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
             for (int k = 0; k < 4; k++) W.floor[c][s][k] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < NAS; s++)
 #pragma unroll
         for (int k = 0; k < 4; k++) W.arm[s][k] = 0.f;
-        W.cc_prev[s] = false;
-    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) W.cc_prev[s] = false;
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; s++)
 #pragma unroll
         for (int k = 0; k < 4; k++) W.wall[s][k] = 0.f;
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS>(P, S, ctrl, lds, lane, lag_ee, lag_cube, W);
+    Diag DG = {0u, 0u, 0u, 0u};
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    if (P.diag && valid) {
+        P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
+        P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
+#pragma unroll
+        for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];   // data.ctrl as apply_action left it (reach_cube_env.py:273)
+    }
 
     // ---- reward / success / termination (reach:313-348 and per-task deltas), lagged kinematics (P8) ----
     f3 a3, b3;
@@ -1546,16 +1678,20 @@ static int check_launch() {
     return err == hipSuccess ? 0 : (int)err;
 }
 
-int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
+template <bool ADAPT>
+static void launch_step_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
     const bool stack = P.task == 4;
-    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+}
+int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
+    if (P.pgs_iters < 0) launch_step_t<true>(P, action_dev, ee_mode, (hipStream_t)stream);   // converged mode
+    else launch_step_t<false>(P, action_dev, ee_mode, (hipStream_t)stream);
     return check_launch();
 }
 

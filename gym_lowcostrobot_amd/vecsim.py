@@ -68,6 +68,9 @@ class VecSim:
         compat=0,
         auto_reset=True,
         base_seed=0,
+        arm_collision=True,
+        pgs_tol=1e-6,
+        diagnostics=False,
     ):
         self.L = _capi.load()
         if action_mode not in ACTION_MODES:
@@ -98,6 +101,9 @@ class VecSim:
         cfg.compat = int(compat)
         cfg.auto_reset = int(bool(auto_reset))
         cfg.base_seed = int(base_seed)
+        cfg.arm_collision = int(bool(arm_collision))
+        cfg.pgs_tol = float(pgs_tol)
+        cfg.diagnostics = int(bool(diagnostics))
         self.cfg = cfg
         self.n = int(n_envs)
         self.device = int(device)
@@ -129,6 +135,11 @@ class VecSim:
         self.terminal_obs = DeviceArray(self, out.terminal_obs, (18, N), np.float32)
         self.timestamp = DeviceArray(self, out.timestamp, (N,), np.float64)
         self.current_goal = DeviceArray(self, out.current_goal, (N,), np.int32)
+        self.active_mask = DeviceArray(self, out.active_mask, (N,), np.uint32) if out.active_mask else None
+        self.active_count = DeviceArray(self, out.active_count, (N,), np.uint32) if out.active_count else None
+        self.max_sweeps = DeviceArray(self, out.max_sweeps, (N,), np.uint32) if out.max_sweeps else None
+        self.choice = DeviceArray(self, out.choice, (N,), np.uint32) if out.choice else None
+        self.ctrl = DeviceArray(self, out.ctrl, (6, N), np.float32) if out.ctrl else None
 
     # ---- lifecycle ----
     def close(self):

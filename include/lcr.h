@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LCR_ABI_VERSION 1
+#define LCR_ABI_VERSION 2
 
 typedef enum lcr_status {
     LCR_OK = 0,
@@ -78,11 +78,16 @@ typedef struct lcr_config {
     double impratio;           /* 100, follower.xml:3 */
     int32_t n_substeps;        /* 20 */
     int32_t max_episode_steps; /* 50, gymnasium TimeLimit configured at __init__.py:12-42; <=0 disables */
-    int32_t pgs_iters;         /* warm-started PGS sweeps per substep, 4 */
+    int32_t pgs_iters;         /* warm-started PGS sweeps per substep, 4; < 0: "converged" mode -- sweep until the largest force
+                                  change of a sweep is <= pgs_tol (1 + largest |force|) in every env of the wave, at most 50 sweeps */
     uint32_t compat;
     int32_t auto_reset;        /* 1: SB3 VecEnv semantics fused in the step kernel */
-    int32_t _pad;
+    int32_t arm_collision;     /* 1 (default): the arm links collide with the floor / cube through sphere proxies (follower.xml:10,13:
+                                  every arm geom collides in the reference); 0: finger tips only */
     uint64_t base_seed;        /* envs never explicitly seeded use SeedSequence(base_seed + global env id) */
+    double pgs_tol;            /* 1e-6; used when pgs_iters < 0 */
+    int32_t diagnostics;       /* 1: lcr_out_view.active_mask / active_count / max_sweeps are written by every step */
+    int32_t _pad;
 } lcr_config;
 
 typedef struct lcr_sim lcr_sim;
@@ -113,6 +118,15 @@ typedef struct lcr_out_view {
     const float *terminal_obs;  /* [18][N] arm_qpos6, arm_qvel6, cube_pos3, aux3 -- valid where did_reset */
     const double *timestamp;    /* [N]  accumulated simulation time = info["timestamp"] of PushCubeLoop-v0 (push_cube_loop_env.py:328) */
     const int32_t *current_goal;/* [N]  PushCubeLoop-v0 goal side (0|1), persists across resets (push_cube_loop_env.py:136,341) */
+    /* solver diagnostics of the last step, valid when lcr_config.diagnostics != 0 (else NULL): bit s of active_mask = constraint
+     * slot s was active in some substep (0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor,
+     * 16-17 arm-link proxy groups, 18+j joint limit j); active_count = number of (slot, substep) activations;
+     * max_sweeps = most PGS sweeps of a substep; choice = wrapping sum over substeps s (weight 2s+1) and active constraints of
+     * (slot + 1)(sel + 1) 2654435761 with sel the discrete choice behind the contact (vertex index, manifold candidate, box
+     * face, proxy member, limit side) + 0x9E3779B1 x executed IK iterations: two runs that agree in these four words went
+     * through the same sequence of discrete decisions */
+    const uint32_t *active_mask, *active_count, *max_sweeps, *choice; /* [N] each */
+    const float *ctrl;          /* [6][N] actuator targets data.ctrl as apply_action left them (reach_cube_env.py:273); diagnostics only */
 } lcr_out_view;
 
 int lcr_abi_version(void);

@@ -427,6 +427,7 @@ typedef struct {
     int slot; /* warm-start slot id: 0-3 floor-cube0, 4-7 floor-cube1, 8-11 cube-cube / rails, 12-13 sphere-cube, 14-15 sphere-floor,
                  16-17 link-proxy group 0/1 */
     int dim;  /* rows: 3 (n, t1, t2) or 4 (+ torsion) */
+    int sel;  /* discrete choice behind this contact (which vertex / candidate / face / member): diagnostics, see lag_t.choice */
 } contact_t;
 
 #define MAX_CONTACTS (8 + 8 + ORC_MAX_ARM_CONTACTS + NLGRP)
@@ -452,6 +453,7 @@ static int collide_plane_box(const kin_t *K, int c, contact_t *out) {
         make_frame(ct->frame, nz);
         ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT; /* P9: cube priority 1 beats floor priority 0 */
         ct->dim = 4;
+        ct->sel = i;
     }
     return n;
 }
@@ -467,6 +469,7 @@ static int collide_box_sphere_g(const kin_t *K, int c, const real *centre, doubl
         if (l[k] < (real)-CUBE_HALF) { q[k] = (real)-CUBE_HALF; outside = 1; }
     }
     real nl[3], dist;
+    int selcode = 7;
     if (outside) {
         real df[3];
         v3sub(df, l, q);
@@ -480,6 +483,7 @@ static int collide_box_sphere_g(const kin_t *K, int c, const real *centre, doubl
         real sg = l[best] < 0 ? (real)-1 : (real)1;
         v3set(nl, 0, 0, 0); nl[best] = sg;
         q[best] = sg * (real)CUBE_HALF;
+        selcode = 2 * best + (sg < 0 ? 1 : 0);
         dist = -(bd + (real)radius);
     }
     real pl[3] = {q[0] + nl[0] * dist * (real)0.5, q[1] + nl[1] * dist * (real)0.5, q[2] + nl[2] * dist * (real)0.5};
@@ -490,6 +494,7 @@ static int collide_box_sphere_g(const kin_t *K, int c, const real *centre, doubl
     make_frame(ct->frame, nw);
     ct->b1 = 6 + c; ct->b2 = link; ct->dist = dist;
     ct->dim = 4;
+    ct->sel = 8 * c + selcode + 16 * ((ct->frame[1] < (real)0.5 && ct->frame[1] > (real)-0.5) ? 0 : 1); /* cube, face case, frame branch */
     return 1;
 }
 static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) { /* finger sphere s */
@@ -505,6 +510,7 @@ static int collide_plane_sphere_g(const real *centre, double radius, int link, c
     real nz[3] = {0, 0, 1};
     make_frame(ct->frame, nz);
     ct->b1 = -1; ct->b2 = link; ct->dist = dist;
+    ct->sel = 0;
     return 1;
 }
 static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
@@ -522,12 +528,14 @@ static int collide_link_group(const kin_t *K, int g, contact_t *out) {
         contact_t tmp;
         if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
             tmp.mu = MU_LINK_FLOOR; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 3;
+            tmp.sel = 64 * (s + 1);
             if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
         }
         if (g == 1)
             for (int c = 0; c < K->ncube; c++)
                 if (collide_box_sphere_g(K, c, K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
                     tmp.mu = K->mu_cube; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 4; /* P9: cube priority 1 beats the link geoms */
+                    tmp.sel += 64 * (s + 1) + 32;
                     if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
                 }
     }
@@ -579,6 +587,7 @@ static int collide_walls(const kin_t *K, contact_t *out) {
             make_frame(ct->frame, nw);
             ct->mu = K->mu_cube; ct->solimp = SOLIMP_DEFAULT;
             ct->dim = 4;
+            ct->sel = i + 8 * w;
         }
     }
     return n;
@@ -707,6 +716,7 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
         make_frame(ct->frame, n);
         ct->mu = MU_CUBE; ct->solimp = SOLIMP_DEFAULT;
         ct->dim = 4;
+        ct->sel = sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0 ? 1 : 0);
         cnt++;
     }
     return cnt;
@@ -769,13 +779,16 @@ typedef struct {
     uint32_t active_mask;  /* OR over the substeps of the control step: bit = warm-slot id of an active contact (0..17), 18+j joint-limit of dof j */
     uint32_t active_count; /* sum over the substeps of the number of active contacts + limits */
     uint32_t max_sweeps;   /* largest PGS sweep count of a substep (adaptive mode) */
+    uint32_t choice;       /* wrapping sum over substeps s (weight 2s+1) and active constraints of (slot+1)(sel+1) 2654435761: the discrete choices
+                              behind the contacts (which vertex, manifold candidate, box face, proxy member, limit side), plus the
+                              number of IK iterations x 0x9E3779B1 */
 } lag_t;
 /* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
  * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
 typedef struct { real lim[12]; real slot[18][4]; } warm_t;
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
-                    warm_t *warm, int diag) {
+                    warm_t *warm, int diag, int sub_index) {
     const int nc = T->ncube, nv = 6 + 6 * nc;
     const real h = (real)H_STEP;
     kin_t K;
@@ -859,7 +872,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     real *wptr[MAX_ROWS]; /* where this row's force is kept between substeps */
     const double *rowmu[MAX_ROWS];
     int nr = 0;
-    uint32_t amask = 0;
+    uint32_t amask = 0, choice = 0;
     memset(J, 0, sizeof J);
     for (int j = 0; j < 6; j++)
         for (int side = 0; side < 2; side++) {
@@ -876,6 +889,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             kind[nr] = 0; rowmu[nr] = 0; blk0[nr] = nr; blkdim[nr] = 1;
             wptr[nr] = &warm->lim[2 * j + side];
             amask |= 1u << (18 + j);
+            choice += (uint32_t)(18 + j + 1) * (uint32_t)(side + 1) * 2654435761u;
             nr++;
         }
     for (int ci = 0; ci < ncon; ci++) {
@@ -892,6 +906,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         double impr = P->impratio > MJ_MINVAL ? P->impratio : MJ_MINVAL;
         double Rf = Rn / impr; /* elliptic cone: friction rows regularised by R/impratio, scaled mu0^2/mu_j^2 */
         amask |= 1u << ct->slot;
+        choice += (uint32_t)(ct->slot + 1) * (uint32_t)(ct->sel + 1) * 2654435761u;
         for (int r = 0; r < ct->dim; r++) {
             real *Jrow = J + (size_t)(nr + r) * nv;
             const real *fr = ct->frame + 3 * (r < 3 ? r : 0);
@@ -916,6 +931,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     }
     lag->active_mask |= amask;
     lag->active_count += (uint32_t)__builtin_popcount(amask);
+    lag->choice += choice * (uint32_t)(2 * sub_index + 1); /* odd weight: the same choice in another substep hashes differently */
 
     /* -- dual problem: A = J M^-1 J^T, b = J a0 - aref ; PGS, warm start, fixed or adaptive sweep count (D1, D2) */
     real f[MAX_ROWS];
@@ -1267,6 +1283,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     float *target = io->target + 3 * e;
     const int nq = orc_nq(P->task), nv = orc_nv(P->task), k = orc_action_dim(P);
     real qpos[ORC_NQ_MAX], qvel[ORC_NV_MAX], ctrl[6];
+    int ik_iters = 0;
     for (int i = 0; i < nq; i++) qpos[i] = (real)qpos64[i];
     for (int i = 0; i < nv; i++) qvel[i] = (real)qvel64[i];
 
@@ -1276,7 +1293,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
         double t64[3], g64;
         orc_ee_glue(P, ee_lag, 0.0, action, t64, &g64); /* target only; the gripper needs the post-IK qpos[5] */
         for (int i = 0; i < 3; i++) tgt[i] = (real)t64[i];
-        ik_solve(qpos, tgt, qc, sl);
+        ik_iters = ik_solve(qpos, tgt, qc, sl);
         for (int j = 0; j < 6; j++) ctrl[j] = qc[j];
         orc_ee_glue(P, ee_lag, (double)qpos[5], action, t64, &g64);
         ctrl[5] = (real)g64;
@@ -1292,12 +1309,15 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     warm_t warm;
     memset(&lag, 0, sizeof lag);
     memset(&warm, 0, sizeof warm);
-    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, &warm, e == 0 && s == P->n_substeps - 1);
+    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, &warm, e == 0 && s == P->n_substeps - 1, s);
     for (int i = 0; i < nq; i++) qpos64[i] = (double)qpos[i];
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];
     if (io->sim_time) io->sim_time[e] += P->n_substeps * H_STEP; /* data.time advances in mj_step only */
-    if (io->active_mask) { io->active_mask[e] = lag.active_mask; io->active_count[e] = lag.active_count; io->max_sweeps[e] = lag.max_sweeps; }
+    if (io->active_mask) {
+        io->active_mask[e] = lag.active_mask; io->active_count[e] = lag.active_count; io->max_sweeps[e] = lag.max_sweeps;
+        io->choice[e] = lag.choice + (uint32_t)ik_iters * 0x9E3779B1u;
+    }
 
     /* ---- observation, reward, termination: reach:313-333 (+ lift:322-346 push:330-346 stack:326-348) */
     float *obs = io->obs + 18 * e;
@@ -1402,6 +1422,13 @@ void orc_fk(const double *q6, double *link_pos, double *site, double *spheres) {
     for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) link_pos[3 * i + k] = (double)K.p[i + 1][k];
     for (int k = 0; k < 3; k++) site[k] = (double)K.site[k];
     if (spheres) for (int s = 0; s < NSPH; s++) for (int k = 0; k < 3; k++) spheres[3 * s + k] = (double)K.sph[s][k];
+}
+int orc_proxies(const double *q6, double *centres /*[NLPX][3]*/, double *radii /*[NLPX]*/) {
+    real q[6]; kin_t K;
+    for (int j = 0; j < 6; j++) q[j] = (real)q6[j];
+    arm_kinematics(q, &K);
+    for (int s = 0; s < NLPX; s++) { for (int k = 0; k < 3; k++) centres[3 * s + k] = (double)K.lpx[s][k]; radii[s] = LPX_RAD[s]; }
+    return NLPX;
 }
 void orc_mass_matrix(const double *q6, int with_armature, double *M) {
     real q[6], Mr[36]; kin_t K;

@@ -58,6 +58,7 @@ class OrcIO(ctypes.Structure):
         ("active_mask", ctypes.c_void_p),
         ("active_count", ctypes.c_void_p),
         ("max_sweeps", ctypes.c_void_p),
+        ("choice", ctypes.c_void_p),
     ]
 
 
@@ -131,11 +132,12 @@ class Oracle:
         self.active_mask = np.zeros(n, np.uint32)
         self.active_count = np.zeros(n, np.uint32)
         self.max_sweeps = np.zeros(n, np.uint32)
+        self.choice = np.zeros(n, np.uint32)
         self.io = OrcIO(
             _p(self.qpos), _p(self.qvel), _p(self.ee_lag), _p(self.target), _p(self.elapsed), _p(self.rng),
             _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.reward64), _p(self.terminated),
             _p(self.truncated), _p(self.is_success), _p(self.did_reset), _p(self.goal), _p(self.sim_time),
-            _p(self.active_mask), _p(self.active_count), _p(self.max_sweeps),
+            _p(self.active_mask), _p(self.active_count), _p(self.max_sweeps), _p(self.choice),
         )
 
     def reset(self, seeds=None, mask=None):
@@ -161,6 +163,14 @@ def fk(q):
     lp, site, sph = np.zeros((6, 3)), np.zeros(3), np.zeros((2, 3))
     lib().orc_fk(_p(q), _p(lp), _p(site), _p(sph))
     return lp, site, sph
+
+
+def proxies(q):
+    """world centres and radii of the arm-link proxy spheres (D3)"""
+    q = np.ascontiguousarray(q, np.float64)
+    c, r = np.zeros((8, 3)), np.zeros(8)
+    n = lib().orc_proxies(_p(q), _p(c), _p(r))
+    return c[:n], r[:n]
 
 
 def mass_matrix(q, armature=True):

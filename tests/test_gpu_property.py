@@ -35,13 +35,8 @@ def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps,
     np.testing.assert_array_equal(st0["qpos"][:, : sim.nq].astype(np.float32), o.qpos[:, : sim.nq].astype(np.float32))
     np.testing.assert_array_equal(st0["rng"], o.rng)
     for t in range(3):
-        util.sync_oracle_to_f32(o); util.push_state(sim, o)
         a = rng.uniform(-1.3, 1.3, (n, sim.action_dim)).astype(np.float32)
-        o.step(a, threads=0); sim.step(a)
-        st1 = util.pull_state(sim)
-        dq = np.abs(st1["qpos"] - o.qpos[:, : sim.nq]).max(axis=1)
-        dv = np.abs(st1["qvel"] - o.qvel[:, : sim.nv]).max(axis=1)
-        ok = (dq <= 3e-5) & (dv <= 5e-3)
+        dq, dv, ok, st1 = util.parity_step(sim, o, a, 3e-5, 5e-3, max_dq=5e-2, max_dv=5.0, where=(task, mode, n_substeps, pgs_iters, t))
         assert ok.mean() >= min(0.97, 1 - 1.5 / n) or ok.sum() >= n - 1, (t, ok.mean(), np.sort(dq)[-3:], np.sort(dv)[-3:])
         out = sim.outputs()
         same = out["terminated"] == o.terminated.astype(bool)

@@ -470,3 +470,53 @@ def test_flop_census_build_is_the_same_algorithm():
     b.L.orc_count_get(out)
     flops = sum(list(out)[:5]) / (4 * 5)
     assert 1e5 < flops < 5e6, flops
+
+
+# ---------------------------------------------------------------- arm-link proxies (D3) and the converged solver mode
+def test_link_proxies_keep_the_arm_above_the_floor():
+    """random joint-mode policy: with arm_collision on, no link proxy sinks below the floor by more than the soft-contact
+    depth; with it off (round-1 model: finger tips only) wrist-side links go centimetres below"""
+    n = 256
+    worst = {}
+    for on in (1, 0):
+        o = orc.Oracle("reach", n, arm_collision=on)
+        o.reset(seeds=np.arange(n))
+        rng = np.random.default_rng(0)
+        low = 0.0
+        for step in range(60):
+            o.step(rng.uniform(-1, 1, (n, 5)).astype(np.float32), threads=0)
+            if step % 3 == 2:
+                for e in range(0, n, 2):
+                    c, r = orc.proxies(o.qpos[e, :6])
+                    low = min(low, float((c[:, 2] - r).min()))
+        worst[on] = low
+    # soft contact with the default solref time constant of 0.02 s: an impact at v penetrates ~ v * 0.02 / e transiently
+    # (1.5 m/s -> 11 mm); the proxies turn a 6 cm dive into that
+    assert worst[1] > -0.015, worst
+    assert worst[0] < -0.04, worst           # without the proxies the wrist dives centimetres into the floor
+
+
+def test_converged_mode_reaches_the_tolerance():
+    """pgs_iters = -1 against 300 fixed sweeps from identical states: the typical env-step agrees to 1e-6; the few stiff contact
+    sets that PGS cannot resolve within the 50-sweep cap stay within millimetres (and are still far better than 4 sweeps)"""
+    n = 64
+    errs = {}
+    for name, kw in (("adaptive", dict(pgs_iters=-1, pgs_tol=1e-8)), ("four", dict(pgs_iters=4))):
+        o = orc.Oracle("push", n, **kw)
+        ref = orc.Oracle("push", n, pgs_iters=300)
+        for s in (o, ref):
+            s.reset(seeds=np.arange(n))
+        rng = np.random.default_rng(1)
+        e = []
+        for _ in range(10):
+            a = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+            for k in ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng"):
+                getattr(ref, k)[:] = getattr(o, k)
+            o.step(a, threads=0); ref.step(a, threads=0)
+            e.append(np.abs(o.qpos - ref.qpos).max(axis=1))
+        errs[name] = np.concatenate(e)
+        if name == "adaptive":
+            assert 4 < o.max_sweeps.max() <= 50
+    ad, four = errs["adaptive"], errs["four"]
+    assert np.median(ad) < 1e-6 and np.percentile(ad, 99) < 5e-6 and ad.max() < 5e-3, (np.median(ad), np.percentile(ad, 99), ad.max())
+    assert np.median(ad) < 0.05 * np.median(four) and np.percentile(ad, 99) < 0.05 * np.percentile(four, 99)

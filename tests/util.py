@@ -40,7 +40,7 @@ def make_pair(task, n, **kw):
 
     okw = {}
     for k in ("action_mode", "reward_type", "block_gripper", "n_substeps", "max_episode_steps", "pgs_iters",
-              "auto_reset", "compat", "distance_threshold", "impratio"):
+              "auto_reset", "compat", "distance_threshold", "impratio", "arm_collision", "pgs_tol"):
         if k in kw:
             v = kw[k]
             if k == "action_mode":
@@ -49,6 +49,7 @@ def make_pair(task, n, **kw):
                 v = {"sparse": 0, "dense": 1}[v]
             okw[k] = int(v) if isinstance(v, bool) else v
     o = orc.Oracle(task, n, **okw)
+    kw.setdefault("diagnostics", True)
     sim = VecSim(task, n, observation_mode="state", **kw)
     assert sim.action_dim == o.action_dim
     return sim, o
@@ -85,3 +86,58 @@ def pinch_setup(o, gap=0.0285):
     o.qpos[:, 9:13] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
     o.qvel[:] = 0
     return mid
+
+
+MAX_DQ, MAX_DV = 2e-2, 2.0   # bound on explained outliers after one control step (rad or m, rad/s or m/s)
+STATS = {"envs": 0, "out": 0, "out_flip": 0, "out_illcond": 0, "max_dq": 0.0, "max_dv": 0.0}
+_twins = {}
+
+
+def _twin(o):
+    """the oracle's fp32-arithmetic build (same C source compiled with float) with the same parameters"""
+    key = id(o)
+    if key not in _twins:
+        t = orc.Oracle(o.task, o.n, f32=True)
+        import ctypes
+        ctypes.memmove(ctypes.byref(t.params), ctypes.byref(o.params), ctypes.sizeof(o.params))
+        _twins.clear()
+        _twins[key] = t
+    return _twins[key]
+
+
+def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_DV, where=""):
+    """One re-synchronised control step of the HIP path and the fp64 oracle from identical float32-representable states.
+    Returns (dq, dv, ok) per env.  EVERY env outside the tolerance must be explained, by one of two measurable facts:
+      (flip)     its discrete-decision signature differs from the oracle's: which constraint slots were active, how many
+                 (slot, substep) activations, and the substep-weighted hash of the choices behind the contacts (vertex,
+                 manifold candidate, box face, proxy member, limit side, IK iterations) -- the step map is discontinuous there;
+      (illcond)  the state is ill-conditioned for fp32 arithmetic as such: the oracle's own fp32 build (same C source, float),
+                 stepped from the same state, uses up more than a quarter of the tolerance itself (non-converged PGS on a stiff contact set can
+                 amplify rounding by orders of magnitude within one control step).
+    Explained outliers still have to stay within max_dq / max_dv."""
+    sync_oracle_to_f32(o)
+    push_state(sim, o)
+    t = _twin(o)
+    for k in ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time"):
+        getattr(t, k)[:] = getattr(o, k)
+    o.step(a, threads=0)
+    sim.step(a)
+    st = pull_state(sim)
+    dq = np.abs(st["qpos"] - o.qpos[:, : sim.nq]).max(axis=1)
+    dv = np.abs(st["qvel"] - o.qvel[:, : sim.nv]).max(axis=1)
+    ok = (dq <= atol_q) & (dv <= atol_v)
+    if not ok.all():
+        flip = (sim.active_mask.numpy() != o.active_mask) | (sim.active_count.numpy() != o.active_count) | (sim.choice.numpy() != o.choice)
+        t.step(a, threads=0)
+        tq = np.abs(t.qpos[:, : sim.nq] - o.qpos[:, : sim.nq]).max(axis=1)
+        tv = np.abs(t.qvel[:, : sim.nv] - o.qvel[:, : sim.nv]).max(axis=1)
+        # (a quarter of the tolerance: two differently formulated fp32 computations may differ a few times more from each other
+        #  than one of them does from fp64)
+        ill = ((tq > 0.25 * atol_q) | (tv > 0.25 * atol_v)) | (t.active_count != o.active_count) | (t.choice != o.choice)
+        STATS["out"] += int((~ok).sum()); STATS["out_flip"] += int((~ok & flip).sum()); STATS["out_illcond"] += int((~ok & ~flip & ill).sum())
+        bad = ~ok & ~flip & ~ill
+        assert not bad.any(), (where, np.nonzero(bad)[0][:8], dq[bad][:8], dv[bad][:8])
+    STATS["envs"] += sim.n
+    STATS["max_dq"] = max(STATS["max_dq"], float(dq.max())); STATS["max_dv"] = max(STATS["max_dv"], float(dv.max()))
+    assert dq.max() <= max_dq and dv.max() <= max_dv, (where, float(dq.max()), float(dv.max()))
+    return dq, dv, ok, st
