@@ -245,7 +245,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.walls = loop ? 1 : 0;
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;
-    D.diag = cfg->diagnostics ? 1 : 0;
+    D.diag = cfg->diagnostics;   // 2: max_sweeps carries the wave's cycle count instead (profiling aid)
     D.pgs_tol = (float)cfg->pgs_tol;
     D.cube_mass = (float)cm;
     D.cube_minv = (float)(1.0 / cm);

@@ -246,12 +246,12 @@ struct ArmSlot {
 
 // constraint forces carried from one substep to the next within a control step (zero at its start): warm start of
 // the PGS sweeps, as MuJoCo warm-starts its solver.  Cube<->cube forces (Stack) persist in their LDS records.
-// arm-coupled contact slots: 0,1 finger sphere 0/1 vs cube; 2,3 finger sphere 0/1 vs floor; 4 link-proxy group 0 (forearm) vs
-// floor, 3 rows; 5 link-proxy group 1 (gripper body) vs floor or cube (per lane), 4 rows (torsion only on a cube)
-constexpr int NAS = 6;
-constexpr int as_rows(int s) { return s == 4 ? 3 : 4; }
-constexpr int as_row0(int s) { return s <= 4 ? 4 * s : 19; }
-constexpr int AS_TOTAL_ROWS = 23;
+// arm-coupled contact slots: 0,1 finger sphere 0/1 vs cube; 2,3 finger sphere 0/1 vs floor; 4 the arm-link proxies (D3): one
+// contact, vs floor or (gripper body) cube per lane, 4 rows (the torsion row only on a cube: link<->floor is condim 3)
+constexpr int NAS = 5;
+constexpr int as_rows(int) { return 4; }
+constexpr int as_row0(int s) { return 4 * s; }
+constexpr int AS_TOTAL_ROWS = 20;
 template <int NC>
 struct Warm {
     float floor[NC][4][4];
@@ -262,7 +262,7 @@ struct Warm {
 };
 
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
-constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 23 rows -> 34.5 KiB per wave (4 waves per CU: 138 of 160 KiB)
+constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 20 rows -> 30 KiB per wave (4 waves per CU: 120 of 160 KiB)
 // Stack only: cube<->cube contact records, 4 slots x 16 floats per env: pos3 f4 aref4 inv4 Rn.  They live in a global
 // scratch array [64][N] (coalesced, touched only by waves that have a cube<->cube contact, ~4 % of the wave-substeps):
 // the LDS is taken by the g rows.
@@ -303,7 +303,7 @@ DEV SBHit sphere_box(f3 centre, float rad, f3 cp, const CubeRot &R) {
 }
 
 // per-env diagnostics of one control step (written only when LcrDev.diag): which constraint slots were active (bit = slot id:
-// 0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor, 16-17 link-proxy groups, 18+j limit j),
+// 0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor, 16 arm-link proxies, 18+j limit j),
 // the number of (slot, substep) activations, and the largest PGS sweep count of a substep
 struct Diag { unsigned mask, count, sweeps, choice; };
 // choice: wrapping sum over substeps s (weight 2s + 1) and active constraints of (slot + 1)(sel + 1) 2654435761, sel = the discrete choice behind
@@ -763,16 +763,17 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     //      go to LDS.  Every slot is skipped wave-uniformly when no lane of the wave touches. ----
     ArmSlot AS[NAS];
     bool slot_any[NAS];
-    bool on_cube5 = false;       // slot 5: this lane's contact is against a cube (else the floor)
-    bool last_joint[2] = {false, false};   // slot 4: joint 4 moves the contact (proxy on link_4); slot 5: joint 6 (proxy on link_6)
-    int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 5 refer to (Stack)
+    bool on_cube5 = false;       // slot 4: this lane's contact is against a cube (else the floor)
+    int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
+    int link_bi = 0;             // slot 4: which proxy
+    int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
     const float srad[2] = {SPH0r, SPH1r};
 #pragma unroll
     for (int s = 0; s < NAS; s++) {
         const int sp = s & 1;
-        const bool may_cube = s < 2 || s == 5;   // literal after unrolling
+        const bool may_cube = s < 2 || s == 4;   // literal after unrolling
         ArmSlot &T = AS[s];
         f3 pos = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 1.f);
         float dist = 1.f;
@@ -800,48 +801,46 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         } else if (s < 4) {
             dist = sph[sp].z - srad[sp];
             pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
-        } else if (s == 4) {
-            // link-proxy group 0 (both ends of link_3, link_4 motor) vs the floor: the deepest member (tie: lower index)
-            const f3 c0 = local_point(F, 2, LPX0x, LPX0y, LPX0z), c1 = local_point(F, 2, LPX1x, LPX1y, LPX1z), c2 = local_point(F, 3, LPX2x, LPX2y, LPX2z);
-            const float d0 = c0.z - LPX0r, d1 = c1.z - LPX1r, d2 = c2.z - LPX2r;
-            f3 c = c0; dist = d0; sel = 64;
-            if (d1 < dist) { dist = d1; c = c1; sel = 128; }
-            const bool l4 = d2 < dist;
-            if (l4) { dist = d2; c = c2; sel = 192; }
-            last_joint[0] = l4;
-            invw_link = l4 ? INVW_TRAN_L4 : INVW_TRAN_L3;
-            pos = mk(c.x, c.y, 0.5f * dist);
-            if (!P.arm_collision) dist = 1.f;
-        } else {
-            // link-proxy group 1 (link_5 motor body, link_6 jaw root) vs the floor and the cube(s): deepest candidate in the
-            // order member 0 floor, member 0 cubes, member 1 floor, member 1 cubes (ties: first)
-            const f3 cm[2] = {local_point(F, 4, LPX3x, LPX3y, LPX3z), local_point(F, 5, LPX4x, LPX4y, LPX4z)};
-            const float rm[2] = {LPX3r, LPX4r};
-            float bestd = 1e30f;
+        } else if (P.arm_collision) {
+            // arm-link proxies (D3): both ends of link_3, link_4 motor, link_5 motor body, link_6 jaw root.  One contact: the
+            // deepest candidate in the order proxy 0 floor, proxy 1 floor, proxy 2 floor, proxy 3 floor, proxy 3 cubes, proxy 4
+            // floor, proxy 4 cubes (ties: first).  Floor candidates need only the height of the proxy centre.
+            const int plink[5] = {2, 2, 3, 4, 5};
+            const float px[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, py[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, pz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};
+            const float pr[5] = {LPX0r, LPX1r, LPX2r, LPX3r, LPX4r};
+            // wave-uniform broad phase for the gripper body vs the cubes: both proxies lie within 27 mm of the link_5 / link_6 origins
             bool near_any = false;
 #pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const f3 dd = cm[m] - S.cp[c];
-                    near_any = near_any || dot(dd, dd) < (rm[m] + 1.7321f * CH) * (rm[m] + 1.7321f * CH);
-                }
+            for (int c = 0; c < NC; c++) {
+                const f3 dd = F.p[4] - S.cp[c];
+                near_any = near_any || dot(dd, dd) < (0.0350f + 1.7321f * CH) * (0.0350f + 1.7321f * CH);
+            }
             const bool wave_near = __any(near_any) != 0;
+            float bestd = 1e30f;
+            int bi = 0;
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const float df = cm[m].z - rm[m];
-                if (df < bestd) { bestd = df; pos = mk(cm[m].x, cm[m].y, 0.5f * df); n = mk(0.f, 0.f, 1.f); oncube = false; last_joint[1] = m == 1; sel = 64 * (m + 4); }
-                if (wave_near)
+            for (int i = 0; i < 5; i++) {
+                const int L = plink[i];
+                const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
+                const float df = cz - pr[i];
+                if (df < bestd) { bestd = df; bi = i; oncube = false; }
+                if (i >= 3 && wave_near) {
+                    const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const SBHit hit = sphere_box(cm[m], rm[m], S.cp[c], CR[c]);
-                    if (hit.dist < bestd) { bestd = hit.dist; pos = hit.pos; n = hit.n; oncube = true; cidx = c; last_joint[1] = m == 1; sel = 64 * (m + 4) + 32 + 8 * c + hit.code; }
+                    for (int c = 0; c < NC; c++) {
+                        const SBHit hit = sphere_box(ci, pr[i], S.cp[c], CR[c]);
+                        if (hit.dist < bestd) { bestd = hit.dist; bi = i; pos = hit.pos; n = hit.n; oncube = true; cidx = c; sel = 32 + 8 * c + hit.code; }
+                    }
                 }
             }
-            dist = P.arm_collision ? bestd : 1.f;
+            link_bi = bi;
+            if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
+            sel += 64 * (bi + 1);
+            dist = bestd;
             on_cube5 = oncube;
             slot_cube[2] = cidx;
-            invw_link = last_joint[1] ? INVW_TRAN_L6 : INVW_TRAN_L5;
+            link_nj = bi < 2 ? 3 : bi + 2;                       // proxies 0, 1 on link_3 (3 joints); 2 on link_4; 3 on link_5; 4 on link_6
+            invw_link = bi < 2 ? INVW_TRAN_L3 : (bi == 2 ? INVW_TRAN_L4 : (bi == 3 ? INVW_TRAN_L5 : INVW_TRAN_L6));
         }
         T.act = dist < 0.f;
         if (P.diag) {
@@ -853,12 +852,26 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         for (int k = 0; k < 4; k++) { T.f[k] = 0.f; T.aref[k] = 0.f; T.inv[k] = 0.f; }
         T.Rn = 1.f; T.n = n; T.t1 = mk(0.f, 1.f, 0.f); T.t2 = mk(-1.f, 0.f, 0.f); T.rc = mk(0.f, 0.f, 0.f);
         if (slot_any[s]) {  // wave-uniform: skip the whole row set-up when no lane of the wave touches
+            if (s == 4) {
+                // floor contact of proxy link_bi: its horizontal position is needed only now (masked sum: a select chain over
+                // five computed points would be turned into a scratch array by the compiler)
+                const float qx[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, qy[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, qz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};
+                const int ql[5] = {2, 2, 3, 4, 5};
+                f2v cb = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const float m = link_bi == i ? 1.f : 0.f;
+                    const int L = ql[i];
+                    const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
+                    cb = f2v{m, m} * ci + cb;
+                }
+                if (!oncube) pos = mk(cb.x, cb.y, 0.5f * dist);
+            }
             if (may_cube) make_frame(n, T.t1, T.t2);   // (for n = +z this is the floor frame t1 = +y, t2 = -x)
             // joints that move the contact point: the finger spheres sit on link_5 / link_6, the proxies on link_3..link_6
             auto joint_on = [&](int j) -> bool {
                 if (s < 4) return j < (sp == 0 ? 5 : 6);
-                if (s == 4) return j < 3 || (j == 3 && last_joint[0]);
-                return j < 5 || last_joint[1];
+                return j < link_nj;
             };
             f3 cube_p = mk(0.f, 0.f, 0.f), cube_v = mk(0.f, 0.f, 0.f), cube_w = mk(0.f, 0.f, 0.f);
             if (may_cube) {
@@ -878,9 +891,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             f3 jc[6];
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                const bool lit = s < 4 ? j < (sp == 0 ? 5 : 6) : (s == 4 ? j < 4 : true);   // columns that can be non-zero at all
+                const bool lit = s < 4 ? j < (sp == 0 ? 5 : 6) : true;   // columns that can be non-zero at all
                 jc[j] = lit ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
-                if (lit && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
+                if (s == 4 && j >= 3 && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int r = 0; r < as_rows(s); r++) {
@@ -903,7 +916,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         velc = dot(d, cube_w);
                         diagc = iinv;
                     }
-                    if (s == 5) { velc = oncube ? velc : 0.f; diagc = oncube ? diagc : 0.f; }
+                    if (s == 4) { velc = oncube ? velc : 0.f; diagc = oncube ? diagc : 0.f; }
                     vel -= velc;
                 }
                 fsub(CL, g);
@@ -914,13 +927,13 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 T.inv[r] = rcp(gg + diagc + Rr);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
-                const bool row_on = T.act && (s != 5 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
+                const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
                 const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
 #pragma unroll
                 for (int j = 0; j < 6; j++) y[j] = fmaf(g[j], fw, y[j]);
                 if (may_cube) {
-                    const float fc = (s == 5 && !oncube) ? 0.f : fw;
+                    const float fc = (s == 4 && !oncube) ? 0.f : fw;
                     f3 dl = r < 3 ? (-minv * fc) * d : mk(0.f, 0.f, 0.f);
                     f3 da = r < 3 ? (-iinv * fc) * cross(T.rc, d) : (-iinv * fc) * d;
                     if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
@@ -954,13 +967,19 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], flim[j], y[k]);
         }
     }
-    const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3] || slot_any[4] || slot_any[5];
+    const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3] || slot_any[4];
 
     // ---- projected Gauss-Seidel on the dual, matrix-free, warm-started.  Fixed sweep count (pgs_iters > 0), or ADAPT
     //      (pgs_iters < 0): sweep until the largest force change of a sweep is <= pgs_tol (1 + largest |force|) in EVERY lane
     //      of the wave, at most 50 sweeps ----
     const int max_it = ADAPT ? 50 : P.pgs_iters;
     int sweeps_done = 0;
+    // Quiescent floor rows: when nothing else in this wave acts on a cube (no finger / proxy / cube<->cube / rail contact in any
+    // lane) the floor<->cube rows only talk to themselves.  Once a sweep changes none of their forces by more than 2e-6 of the
+    // largest normal force (warm-started resting or airborne cubes: the update is at the rounding level of fp32), the remaining
+    // sweeps of this substep would repeat that no-op and are skipped for the whole wave.
+    const bool cube_coupled = slot_any[0] || slot_any[1] || (slot_any[4] && __any(on_cube5)) || cc_any || wall_any;
+    bool floor_quiet = false;
     for (int it = 0; it < max_it; it++) {
         float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep
         auto track = [&](float d0, float d1, float d2, float d3, float f0, float f1, float f2, float f3_) {
@@ -995,6 +1014,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
         }
         // floor <-> cube
+        if (!floor_quiet) {
+        float fl_chg = 0.f, fl_max = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
 #pragma unroll
@@ -1027,6 +1048,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                 T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
                 track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
+                fl_chg = fmaxf(fmaxf(fl_chg, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+                fl_max = fmaxf(fl_max, fn);
                 // a += M^-1 J^T delta
                 ca[c].z = fmaf(minv, d0, ca[c].z);
                 ca[c].y = fmaf(minv, d1, ca[c].y);
@@ -1035,6 +1058,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 cal[c].y = fmaf(iinv, -r.x * d0 - r.z * d2, cal[c].y);
                 cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
             }
+        }
+        if (!cube_coupled) floor_quiet = __all(fl_chg <= 2e-6f * fl_max) != 0;
         }
         // cube <-> cube (Stack): block form of the four rows of each contact.  With an orthonormal frame the couplings between
         // the rows need only the projections of the two lever arms on the frame: (r x d_i).(r x d_j) = -(r.d_i)(r.d_j), i != j.
@@ -1134,8 +1159,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int s = 0; s < NAS; s++) {
                 if (!slot_any[s]) continue;
                 ArmSlot &T = AS[s];
-                const bool may_cube = s < 2 || s == 5;
-                const bool oncube = s < 2 || (s == 5 && on_cube5);
+                const bool may_cube = s < 2 || s == 4;
+                const bool oncube = s < 2 || (s == 4 && on_cube5);
                 const int nrow = as_rows(s);
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
@@ -1149,10 +1174,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float arefv[4] = {T.aref[0], T.aref[1], T.aref[2], T.aref[3]}, invv[4] = {T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
                 // pick the cube this slot talks to (wave-divergent only for Stack)
                 f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
-                const bool second = may_cube && NC == 2 && slot_cube[s == 5 ? 2 : (s & 1)] == 1;
+                const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
                 if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
                 // cube-side inverse inertia of this lane's contact (zero when slot 5 touches the floor: the cube terms vanish)
-                const float minv_e = (s == 5 && !oncube) ? 0.f : minv, iinv_e = (s == 5 && !oncube) ? 0.f : iinv;
+                const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
                 // The cube's share of the four row residuals is tracked as SCALARS: v_r = d_r . (acceleration of the contact
                 // point of the cube), wn = n . (angular acceleration).  A force change dlt on row j moves them by closed-form
                 // couplings, because (rc x d_i).(rc x d_j) = |rc|^2 delta_ij - (rc.d_i)(rc.d_j) for the orthonormal frame:
@@ -1166,7 +1191,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
                     wn = dot(T.n, a_ang);
                     kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
-                    if (s == 5) {   // floor lanes: no cube share in the residuals
+                    if (s == 4) {   // floor lanes: no cube share in the residuals
 #pragma unroll
                         for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
                         wn = oncube ? wn : 0.f;
@@ -1198,7 +1223,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     float res = gy + jc_a - arefv[r] + Rr * T.f[r];
                     float nf = T.f[r] - res * invv[r];
                     if (r == 0) nf = fmaxf(nf, 0.f);
-                    const bool row_on = T.act && (s != 5 || r < 3 || oncube);
+                    const bool row_on = T.act && (s != 4 || r < 3 || oncube);
                     float dlt = row_on ? nf - T.f[r] : 0.f;
                     T.f[r] += dlt;
                     dtr[r] = dlt;
@@ -1212,7 +1237,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // cone projection (finger geoms: mu 1.5; a link proxy on the floor: mu 1; on a cube: the cube's friction)
                 {
                     float fn = T.f[0];
-                    const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (s == 4 ? 1.f : (oncube ? P.inv_mu_c2 : 1.f));
+                    const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
                     const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
                     float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow == 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
                     float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
@@ -1275,7 +1300,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
         m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u;
         m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;
-        m |= AS[4].act ? (1u << 16) : 0u; m |= AS[5].act ? (1u << 17) : 0u;
+        m |= AS[4].act ? (1u << 16) : 0u;
 #pragma unroll
         for (int j = 0; j < 6; j++) m |= lim_act[j] ? (1u << (18 + j)) : 0u;
         DGtot.mask |= m;
@@ -1415,6 +1440,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     const int e = valid ? e_raw : P.n - 1;  // tail lanes shadow the last env, their stores are masked
     const int N = P.n;
 
+    const long long t_begin = P.diag == 2 ? clock64() : 0;
     EnvState<NC> S;
     load_state<NC>(P, e, S);
     f3 target = mk(0.f, 0.f, 0.f);
@@ -1520,6 +1546,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
+        if (P.diag == 2) P.max_sweeps[e] = (unsigned)(clock64() - t_begin);   // profiling aid: cycles of this wave up to here
 #pragma unroll
         for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];   // data.ctrl as apply_action left it (reach_cube_env.py:273)
     }

@@ -120,7 +120,7 @@ typedef struct lcr_out_view {
     const int32_t *current_goal;/* [N]  PushCubeLoop-v0 goal side (0|1), persists across resets (push_cube_loop_env.py:136,341) */
     /* solver diagnostics of the last step, valid when lcr_config.diagnostics != 0 (else NULL): bit s of active_mask = constraint
      * slot s was active in some substep (0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor,
-     * 16-17 arm-link proxy groups, 18+j joint limit j); active_count = number of (slot, substep) activations;
+     * 16 arm-link proxies, 18+j joint limit j); active_count = number of (slot, substep) activations;
      * max_sweeps = most PGS sweeps of a substep; choice = wrapping sum over substeps s (weight 2s+1) and active constraints of
      * (slot + 1)(sel + 1) 2654435761 with sel the discrete choice behind the contact (vertex index, manifold candidate, box
      * face, proxy member, limit side) + 0x9E3779B1 x executed IK iterations: two runs that agree in these four words went

@@ -86,13 +86,14 @@ static const double SPH_RAD[NSPH] = {0.0065, 0.0065};
  * contype=conaffinity=1, :13 collision hulls; geoms :70-98) are restated as spheres inscribed in the motor / bracket
  * volumes of their hulls (mesh extents: tests/golden/model_golden.json "mesh_aabb").  link_1 / link_2 / base cannot
  * reach the floor inside the joint-mode target box (reach_cube_env.py:249-250) and carry no proxy.
- * Proxies are grouped; each GROUP yields at most ONE contact per substep -- the deepest penetration of its members
- * (ties: lower index) -- the way MuJoCo's convex collider yields one point per geom pair.
- *   group 0 "forearm" (both ends of link_3, link_4 motor): vs floor only
- *   group 1 "gripper body" (link_5 motor body, link_6 jaw root): vs floor and vs the cube(s)
- * {link index 0..5, centre in link frame, radius, group} */
+ * Together the proxies yield at most ONE contact per substep -- the deepest penetration among all candidates (ties: the first
+ * in the order proxy 0 floor, proxy 0 cubes, proxy 1 floor, ...) -- the way MuJoCo's convex collider yields one point per
+ * geom pair; every proxy is tested against the floor, the gripper-body proxies (link_5 motor body, link_6 jaw root) also
+ * against the cube(s).  (Measured under a random policy: a proxy touches in 3 % of the env-steps, two links at once in
+ * < 0.1 %; the one that is not served keeps its warm start for the next substep in which it is the deepest.)
+ * {link index 0..5, centre in link frame, radius, collides with cubes} */
 #define NLPX 5
-#define NLGRP 2
+#define NLGRP 1
 static const int LPX_LINK[NLPX] = {2, 2, 3, 4, 5};
 static const double LPX_POS[NLPX][3] = {
     {-0.0100, 0.0145, 0.0030},  /* elbow end of link_3            (link_3_collision x[-0.111,0.009] y[-0.004,0.033] z[-0.009,0.015]) */
@@ -104,7 +105,8 @@ static const double LPX_POS[NLPX][3] = {
 /* (against a plane a set of spheres acts like its convex hull, so the two ends of a link stand for the whole link; the
  * fixed finger between the link_5 body and the finger-tip sphere needs no proxy of its own, and the grasp gap stays free) */
 static const double LPX_RAD[NLPX] = {0.0120, 0.0120, 0.0105, 0.0150, 0.0078};
-static const int LPX_GROUP[NLPX] = {0, 0, 0, 1, 1};
+static const int LPX_GROUP[NLPX] = {0, 0, 0, 0, 0};
+static const int LPX_CUBE[NLPX] = {0, 0, 0, 1, 1};
 /* link geoms: MuJoCo geom defaults friction (1, 0.005, 0.0001), condim 3, priority 0.  vs floor (priority 0, friction 0.1):
  * max rule -> mu 1, condim 3, default solref/solimp.  vs cube (priority 1): the cube's condim 4, friction, solimp win (P9). */
 static const double MU_LINK_FLOOR[3] = {1.0, 1.0, 0.005};
@@ -425,7 +427,7 @@ typedef struct {
     const double *mu; /* [3] tan, tan, torsional */
     const double *solimp;
     int slot; /* warm-start slot id: 0-3 floor-cube0, 4-7 floor-cube1, 8-11 cube-cube / rails, 12-13 sphere-cube, 14-15 sphere-floor,
-                 16-17 link-proxy group 0/1 */
+                 16 arm-link proxies */
     int dim;  /* rows: 3 (n, t1, t2) or 4 (+ torsion) */
     int sel;  /* discrete choice behind this contact (which vertex / candidate / face / member): diagnostics, see lag_t.choice */
 } contact_t;
@@ -520,7 +522,7 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     ct->dim = 4;
     return 1;
 }
-/* arm-link proxy group g: the deepest penetration among its members against the floor and (group 1) the cubes */
+/* arm-link proxies (group g = 0): the deepest penetration among them against the floor and (gripper body) the cubes */
 static int collide_link_group(const kin_t *K, int g, contact_t *out) {
     int have = 0;
     for (int s = 0; s < NLPX; s++) {
@@ -531,7 +533,7 @@ static int collide_link_group(const kin_t *K, int g, contact_t *out) {
             tmp.sel = 64 * (s + 1);
             if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
         }
-        if (g == 1)
+        if (LPX_CUBE[s])
             for (int c = 0; c < K->ncube; c++)
                 if (collide_box_sphere_g(K, c, K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
                     tmp.mu = K->mu_cube; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 4; /* P9: cube priority 1 beats the link geoms */
@@ -1410,7 +1412,7 @@ int orc_model_table(double *out) {
     }
     out[n++] = WALL_X; out[n++] = WALL_Y0; out[n++] = WALL_Y1; out[n++] = WALL_TOP;
     for (int s = 0; s < NSPH; s++) { out[n++] = SPH_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = SPH_POS[s][k]; out[n++] = SPH_RAD[s]; }
-    for (int s = 0; s < NLPX; s++) { out[n++] = LPX_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = LPX_POS[s][k]; out[n++] = LPX_RAD[s]; out[n++] = LPX_GROUP[s]; }
+    for (int s = 0; s < NLPX; s++) { out[n++] = LPX_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = LPX_POS[s][k]; out[n++] = LPX_RAD[s]; out[n++] = LPX_CUBE[s]; }
     return n;
 }
 

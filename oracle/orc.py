@@ -225,7 +225,7 @@ def model_table():
     t["walls"] = dict(zip(("x", "y0", "y1", "top"), take(4)))
     t["spheres"] = [{"link": int(take(1)[0]), "pos": take(3), "rad": take(1)[0]} for _ in range(2)]
     rest = list(it)
-    t["proxies"] = [{"link": int(rest[6 * i]), "pos": np.array(rest[6 * i + 1:6 * i + 4]), "rad": rest[6 * i + 4], "group": int(rest[6 * i + 5])}
+    t["proxies"] = [{"link": int(rest[6 * i]), "pos": np.array(rest[6 * i + 1:6 * i + 4]), "rad": rest[6 * i + 4], "cube": int(rest[6 * i + 5])}
                     for i in range(len(rest) // 6)]
     return t
 

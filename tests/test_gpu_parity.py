@@ -512,9 +512,9 @@ def _states_with_slots(task, bits, n_want, seed, n_try=24000, cube_near_gripper=
     return q0[idx], v0[idx]
 
 
-@pytest.mark.parametrize("task,bit,near", [("reach", 16, False), ("reach", 17, False), ("push", 17, True), ("stack", 16, False)])
+@pytest.mark.parametrize("task,bit,near", [("reach", 16, False), ("push", 16, True), ("lift", 16, True), ("stack", 16, False)])
 def test_link_proxy_contacts(hip_lib, task, bit, near):
-    """arm-link proxy groups (D3): forearm (slot 16) / gripper body (slot 17) on the floor, gripper body against the cube"""
+    """arm-link proxies (D3, slot 16): forearm / gripper body on the floor, gripper body against the cube"""
     qpos, qvel = _states_with_slots(task, [bit], 256, seed=50 + bit, cube_near_gripper=near)
     n = len(qpos)
     sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0)
@@ -524,7 +524,7 @@ def test_link_proxy_contacts(hip_lib, task, bit, near):
     seen = 0
     for t in range(5):
         a = (0.3 * rng.uniform(-1, 1, (n, sim.action_dim))).astype(np.float32)
-        # selected states press up to four arm contacts (both finger tips + both proxy groups: 14 rows on 6 dofs) on the floor at
+        # selected states press up to three arm contacts (both finger tips + a link proxy: 11 rows on 6 dofs) on the floor at
         # once; 4 PGS sweeps leave such sets far from converged and the rounding of the two formulations differs more: 4e-5
         dq, dv, ok, st = util.parity_step(sim, o, a, 4e-5, 4e-3, where=("link", task, bit, t))
         assert ok.mean() >= 0.97, (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])

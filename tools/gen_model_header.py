@@ -49,13 +49,13 @@ SPH_LINK = [4, 5]
 SPH_POS = [(-0.0610, 0.0142, 0.0005), (-0.0490, 0.0072, -0.0140)]
 SPH_RAD = [0.0065, 0.0065]
 # arm-link proxies (deviation D3): spheres inscribed in the hulls of link_3 (both ends), link_4 (motor), link_5 (motor body),
-# link_6 (jaw root); extents: model_golden.json "mesh_slabs_x".  Group 0 = forearm (floor only), group 1 = gripper body
-# (floor and cube).  Same table as oracle/lcr_oracle.c LPX_*.
+# link_6 (jaw root); extents: model_golden.json "mesh_slabs_x".  All collide with the floor, the gripper-body ones (LPX_CUBE)
+# also with the cube(s); together they yield one contact.  Same table as oracle/lcr_oracle.c LPX_*.
 LPX_LINK = [2, 2, 3, 4, 5]
 LPX_POS = [(-0.0100, 0.0145, 0.0030), (-0.0950, 0.0145, 0.0030), (-0.0320, 0.0206, 0.0000), (-0.0130, 0.0015, 0.0000),
            (-0.0120, 0.0000, -0.0145)]
 LPX_RAD = [0.0120, 0.0120, 0.0105, 0.0150, 0.0078]
-LPX_GROUP = [0, 0, 0, 1, 1]
+LPX_CUBE = [0, 0, 0, 1, 1]
 
 
 def quat2mat(q):
