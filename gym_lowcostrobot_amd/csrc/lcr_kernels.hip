@@ -267,7 +267,11 @@ constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 20 rows -> 30 KiB per 
 // scratch array [64][N] (coalesced, touched only by waves that have a cube<->cube contact, ~4 % of the wave-substeps):
 // the LDS is taken by the g rows.
 constexpr int CC_REC = 16;
-template <int NC, bool WALLS> struct LdsSize { static constexpr int value = LDS_G_FLOATS; };
+// The per-substep constants of the floor<->cube slots of cube 0 (aref[4], inv[4]: written once per substep, read once per PGS
+// sweep) are parked in LDS as 16-B vectors instead of occupying 32 registers across the whole solver loop:
+// [slot 0..3][aref|inv][lane][4] = 8 KiB per wave (30 + 8 = 38 of the 40 KiB a wave may use at four waves per CU).
+constexpr int LDS_PARK_FLOATS = 4 * 2 * 64 * 4;
+template <int NC, bool WALLS> struct LdsSize { static constexpr int value = LDS_G_FLOATS + LDS_PARK_FLOATS; };
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 // sphere (centre, radius) vs cube box: signed distance, world normal (box -> sphere) and contact point midway between the surfaces
@@ -493,6 +497,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
             T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
             T.inv[3] = rcp(iinv + Rt);
+            if (c == 0) {
+                float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
+                pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
+                pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
+            }
             // warm start: forces of the previous substep if this slot was active then (inactive slots were zeroed)
 #pragma unroll
             for (int k = 0; k < 4; k++) { T.f[k] = T.act ? W.floor[c][s][k] : 0.f; }
@@ -1030,6 +1039,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
                 float aref0 = T.aref[0], aref1 = T.aref[1], aref2 = T.aref[2], aref3 = T.aref[3];
                 float inv0 = T.inv[0], inv1 = T.inv[1], inv2 = T.inv[2], inv3 = T.inv[3];
+                if (c == 0) {
+                    const float4v *pk = reinterpret_cast<const float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
+                    const float4v a4 = pk[0], i4 = pk[64];
+                    aref0 = a4.x; aref1 = a4.y; aref2 = a4.z; aref3 = a4.w;
+                    inv0 = i4.x; inv1 = i4.y; inv2 = i4.z; inv3 = i4.w;
+                }
                 const float u0 = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - aref0 + T.Rn * T.f[0];
                 const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - aref1 + Rf * T.f[1];
                 const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - aref2 + Rf * T.f[2];
