@@ -35,6 +35,27 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
+# BASELINE.json configs[1..4] at their per-GPU size: --config N selects (workload, envs per GPU, observation mode)
+CONFIGS = {
+    2: ("ReachCube-v0", 65536, "state"),
+    3: ("PushCube-v0", 65536, "state"),
+    4: ("PickPlaceCube-v0", 32768, "state"),     # 131 072 envs over 4 GPUs, ee-IK action mode
+    5: ("StackTwoCubes-v0", 32768, "both"),      # 262 144 envs over 8 GPUs, state + two ray-cast 240x320x3 frames
+}
+
+
+def kernel_sha16():
+    """hash of the HIP sources: committed PMC-derived figures (traffic, VALU counts) are echoed only while it still matches"""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gym_lowcostrobot_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
 
 
 def cpu_baseline(task, action_mode, budget_s=12.0):
@@ -84,6 +105,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="ReachCube-v0", choices=sorted(WORKLOADS))
+    ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS), help="BASELINE.json configs[N-1] at its per-GPU size (overrides --workload / --envs-per-gpu / --obs)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions in total (the first is the contract's K steps; the rest give the median SURVEY.md 8(d) asks for)")
+    ap.add_argument("--arm-collision", type=int, default=1, help="0: round-1 contact model (finger tips only), for like-for-like comparison")
     ap.add_argument("--pgs-iters", type=int, default=4)
     ap.add_argument("--obs", default="state", choices=["state", "both"], help="both: also ray-cast the two 240x320x3 observation frames per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,6 +115,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for a single rank (tests the N>1 code path on one GPU)")
     ap.add_argument("--calibrate", type=int, default=0, help="after timing, launch the known-byte-count copy kernel this many times (PMC calibration)")
     args = ap.parse_args()
+    if args.config:
+        args.workload, args.envs_per_gpu, args.obs = CONFIGS[args.config]
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # launched directly instead of through torchrun: start one rank per GPU ourselves (same command line the driver uses)
@@ -139,7 +165,7 @@ def main():
         alg_bytes += 2 * 240 * 320 * 3  # write-once frames
     n = args.envs_per_gpu
     sim = VecSim(task, n, device=local_rank, env_id_offset=sharding.shard_offset(n, rank), observation_mode=args.obs, action_mode=action_mode,
-                 pgs_iters=args.pgs_iters, base_seed=0)
+                 pgs_iters=args.pgs_iters, base_seed=0, arm_collision=args.arm_collision)
     stream = torch.cuda.current_stream()
     sim.set_stream(stream.cuda_stream)
 
@@ -163,6 +189,13 @@ def main():
 
     dt, _ = sharding.timed_region(run, args.steps, dist=dist, device_sync=torch.cuda.synchronize, tensor_device="cuda" if backend == "nccl" else "cpu")
     ev_ms = ev["ms"]
+    # further regions of the same K steps (HIP events on the launch stream, this rank only): median of `repeats`
+    rep_ms = [ev_ms / args.steps]
+    for r in range(max(args.repeats, 1) - 1):
+        sim.timer_begin()
+        for i in range(args.steps):
+            sim.step_device(bufs[(args.warmup + i + 7 * (r + 1)) % ring].ptr)
+        rep_ms.append(sim.timer_end() / args.steps)
 
     calib_bytes = 0
     for _ in range(args.calibrate):
@@ -179,12 +212,18 @@ def main():
     if rank == 0:
         kern_ms = ev_ms / args.steps
         achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # measured HBM bytes per launch: rocprofv3 PMC passes cannot run inside this process, so the figure comes from the
+        # committed summary of the same command (profiles/traffic.json) -- and only while the kernel sources are unchanged
+        sha = kernel_sha16()
+        wl_key = f"{args.workload}|{n}|{args.obs}"
+        traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
                 with open(prof) as f:
-                    traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+                    rec = json.load(f).get(wl_key, {})
+                if rec.get("kernel_sha16") == sha:
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), f"profiles/traffic.json[{wl_key}] ({rec.get('round')})"
             except Exception:
                 traffic = None
         out = {
@@ -206,7 +245,11 @@ def main():
                 "envs_per_gpu": n,
                 "global_envs": n * world,
                 "parallelism": f"env-sharded x{world}, no collective",
+                "arm_collision": bool(args.arm_collision),
+                "kernel_sha16": sha,
             },
+            "repeats": {"ms_per_step": rep_ms, "median_ms_per_step": float(np.median(rep_ms)),
+                        "median_value": n * world / (float(np.median(rep_ms)) * 1e-3)},
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -214,6 +257,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "lcr_step_kernel" if args.obs == "state" else "lcr_step_kernel + lcr_render_obs_kernel",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_env_step": alg_bytes,
@@ -231,13 +275,13 @@ def main():
             with open(pm) as f:
                 pj = json.load(f)
             pmc = pj["step_kernel_pmc_per_launch"]
-            if pj.get("workload") == args.workload and args.obs == "state":
+            if pj.get("workload") == args.workload and args.obs == "state" and pj.get("kernel_sha16") == sha and n == 65536:
                 out["valu"] = {
                     "source": os.path.basename(pm),
                     "valu_insts_per_wave_per_launch": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
                     "valu_busy_frac_of_wave_cycles": pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"],
                     "wait_frac_of_wave_cycles": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
-                    "note": "one wave per SIMD at 65 536 envs; plain fp32 VALU issues ~1 instruction per 4 cycles per SIMD",
+                    "note": "one wave per SIMD at 65 536 envs; a single wave issues one VALU instruction per ~5.2 cycles (tools/ubench/valu_issue.hip)",
                 }
                 # flops: executed by the kernel (measured VALU instructions x flop weight of its instruction
                 # mix) and, for reference, the census of the CPU oracle's dense formulation (tools/count_flops.py)
