@@ -31,15 +31,16 @@ class Policy(nn.Module):
         return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--task", default="reach")
     ap.add_argument("--reward-type", default="dense")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     dev = torch.device("cuda", 0)
+    history = []
     torch.manual_seed(0)
     sim = VecSim(args.task, args.envs, observation_mode="state", reward_type=args.reward_type, base_seed=0)
     sim.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -90,9 +91,11 @@ def main():
             loss_v = 0.5 * (pol.v(O[mb]).squeeze(-1) - RET[mb]).pow(2).mean()
             opt.zero_grad(); (loss_pi + loss_v).backward(); opt.step()
         mean_r = torch.stack(R).mean().item()
+        history.append({"mean_reward": mean_r, "successes": int(succ), "loss": float((loss_pi + loss_v).item())})
         print(f"iter {it:3d}  mean reward/step {mean_r:+.4f}  successes {int(succ):6d}  "
               f"env-steps/s incl. learning {N * args.horizon * (it + 1) / (time.time() - t_start):.3e}", flush=True)
     sim.close()
+    return history
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ LCR_OK, LCR_ERR_INVALID, LCR_ERR_NO_DEVICE, LCR_ERR_HIP, LCR_ERR_OOM, LCR_ERR_UN
 SYMBOLS = [
     "lcr_abi_version", "lcr_last_error", "lcr_config_default", "lcr_action_dim", "lcr_nq", "lcr_nv",
     "lcr_create", "lcr_destroy", "lcr_set_stream", "lcr_sync", "lcr_reset", "lcr_step", "lcr_step_host",
-    "lcr_get_obs", "lcr_get_outputs", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
+    "lcr_get_obs", "lcr_get_outputs", "lcr_fetch_host", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
     "lcr_memcpy_h2d", "lcr_memcpy_d2h", "lcr_timer_begin", "lcr_timer_end", "lcr_fill_random_actions",
     "lcr_calibrate_copy", "lcr_render",
 ]
@@ -94,6 +94,23 @@ class LcrOutView(ctypes.Structure):
     ]
 
 
+class LcrHostView(ctypes.Structure):
+    _fields_ = [
+        ("n_envs", ctypes.c_int32),
+        ("any_reset", ctypes.c_int32),
+        ("arm_qpos", ctypes.c_void_p),
+        ("arm_qvel", ctypes.c_void_p),
+        ("cube_pos", ctypes.c_void_p),
+        ("aux_pos", ctypes.c_void_p),
+        ("reward", ctypes.c_void_p),
+        ("terminated", ctypes.c_void_p),
+        ("truncated", ctypes.c_void_p),
+        ("is_success", ctypes.c_void_p),
+        ("did_reset", ctypes.c_void_p),
+        ("terminal_obs", ctypes.c_void_p),
+    ]
+
+
 class LcrError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"lcr error {code}: {msg}")
@@ -140,6 +157,7 @@ def load():
     L.lcr_step_host.argtypes = [vp, vp]
     L.lcr_get_obs.argtypes = [vp, ctypes.POINTER(LcrObsView)]
     L.lcr_get_outputs.argtypes = [vp, ctypes.POINTER(LcrOutView)]
+    L.lcr_fetch_host.argtypes = [vp, ctypes.POINTER(LcrHostView)]
     L.lcr_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lcr_set_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lcr_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]

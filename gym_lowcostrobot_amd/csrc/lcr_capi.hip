@@ -82,6 +82,9 @@ struct lcr_sim {
     LcrCam cam_front, cam_top, cam_vizu;
     unsigned char *render_dev;  // scratch frame for lcr_render
     size_t render_bytes;
+    // lcr_fetch_host: pinned host mirror of the arena range [qpos .. did_reset] (+ terminal observations)
+    size_t fetch_bytes, tobs_off, tobs_bytes;
+    char *host_mirror;
 };
 
 extern "C" {
@@ -185,16 +188,20 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_qvel = off; off += al(sizeof(float) * s->nv * N);
     size_t o_ee = off; off += al(sizeof(float) * 3 * N);
     size_t o_tgt = off; off += al(sizeof(float) * 3 * N);
-    size_t o_el = off; off += al(sizeof(int) * N);
-    size_t o_rng = off; off += al(sizeof(unsigned long long) * 4 * N);
-    size_t o_goal = off; off += al(sizeof(int) * N);
-    size_t o_time = off; off += al(sizeof(double) * N);
+    // step outputs follow the observable state directly: [qpos .. did_reset] is ONE contiguous range, fetched by lcr_fetch_host
+    // with a single device-to-host copy (the terminal observations behind it only when some env was reset)
     size_t o_rew = off; off += al(sizeof(float) * N);
     size_t o_term = off; off += al(N);
     size_t o_trunc = off; off += al(N);
     size_t o_succ = off; off += al(N);
     size_t o_dres = off; off += al(N);
+    size_t o_fetch_end = off;
     size_t o_tobs = off; off += al(sizeof(float) * LCR_OBS_DIM * N);
+    size_t o_tobs_end = off;
+    size_t o_el = off; off += al(sizeof(int) * N);
+    size_t o_rng = off; off += al(sizeof(unsigned long long) * 4 * N);
+    size_t o_goal = off; off += al(sizeof(int) * N);
+    size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
     size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * 64 * N);   // cube<->cube contact records
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
@@ -205,6 +212,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_bg = off;
     if (s->has_images) { o_img0 = off; off += al(img_bytes * N); o_img1 = off; off += al(img_bytes * N); o_bg = off; off += al(2 * img_bytes); }
     s->arena_bytes = off;
+    s->fetch_bytes = o_fetch_end;
+    s->tobs_off = o_tobs;
+    s->tobs_bytes = o_tobs_end - o_tobs;
+    s->host_mirror = nullptr;
     e = hipMalloc(&s->arena, off);
     if (e != hipSuccess) { delete s; return fail(LCR_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", off, hipGetErrorString(e)); }
     e = hipMemset(s->arena, 0, off);
@@ -316,6 +327,7 @@ void lcr_destroy(lcr_sim *s) {
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     if (s->render_dev) (void)hipFree(s->render_dev);
+    if (s->host_mirror) (void)hipHostFree(s->host_mirror);
     (void)hipFree(s->arena);
     delete s;
 }
@@ -404,6 +416,40 @@ int lcr_get_outputs(lcr_sim *s, lcr_out_view *out) {
     out->max_sweeps = s->dev.max_sweeps;
     out->choice = s->dev.choice;
     out->ctrl = s->dev.ctrl_out;
+    return LCR_OK;
+}
+
+int lcr_fetch_host(lcr_sim *s, lcr_host_view *out) {
+    SIMCHK(s);
+    if (!out) return fail(LCR_ERR_INVALID, "out is NULL");
+    const size_t N = (size_t)s->dev.n;
+    if (!s->host_mirror) {
+        hipError_t e = hipHostMalloc((void **)&s->host_mirror, s->tobs_off + s->tobs_bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { s->host_mirror = nullptr; return fail(LCR_ERR_OOM, "hipHostMalloc(%zu) failed: %s", s->tobs_off + s->tobs_bytes, hipGetErrorString(e)); }
+    }
+    HIPCHK(hipMemcpyAsync(s->host_mirror, s->arena, s->fetch_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const char *hb = s->host_mirror, *db = (const char *)s->arena;
+    auto H = [&](const void *dev) { return hb + ((const char *)dev - db); };
+    const unsigned char *dres = (const unsigned char *)H(s->dev.did_reset);
+    int any = 0;
+    for (size_t i = 0; i < N; i++) any |= dres[i];
+    if (any) {
+        HIPCHK(hipMemcpyAsync(s->host_mirror + s->tobs_off, (const char *)s->arena + s->tobs_off, s->tobs_bytes, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    out->n_envs = s->dev.n;
+    out->any_reset = any;
+    out->arm_qpos = (const float *)H(s->dev.qpos);
+    out->arm_qvel = (const float *)H(s->dev.qvel);
+    out->cube_pos = (const float *)H(s->dev.qpos + 6 * N);
+    out->aux_pos = s->dev.has_target ? (const float *)H(s->dev.target) : (s->cfg.task == LCR_TASK_STACK ? (const float *)H(s->dev.qpos + 13 * N) : nullptr);
+    out->reward = (const float *)H(s->dev.reward);
+    out->terminated = (const unsigned char *)H(s->dev.terminated);
+    out->truncated = (const unsigned char *)H(s->dev.truncated);
+    out->is_success = (const unsigned char *)H(s->dev.is_success);
+    out->did_reset = dres;
+    out->terminal_obs = (const float *)H(s->dev.term_obs);
     return LCR_OK;
 }
 

@@ -1,9 +1,12 @@
-"""Vectorised consumers: an SB3-style VecEnv over one VecSim (reference call pattern:
-examples/gym_manipulation_sb3.py:26-39 make_vec_env / DummyVecEnv).
+"""Vectorised consumers: an SB3-style VecEnv and a gymnasium.vector-style env over one VecSim (reference call pattern:
+examples/gym_manipulation_sb3.py:26-39 make_vec_env / DummyVecEnv; rl_zoo3 with observation_mode "both", README.md:122).
 
-DummyVecEnv semantics reproduced in the fused kernel: an env that terminates or hits the TimeLimit is reset
-inside the same step; the returned observation is the reset observation, the last observation of the
-episode is in infos[i]["terminal_observation"], and infos[i]["TimeLimit.truncated"] / ["is_success"] are set.
+DummyVecEnv semantics reproduced in the fused kernel: an env that terminates or hits the TimeLimit is reset inside the same
+step; the returned observation is the reset observation, the last observation of the episode is in
+infos[i]["terminal_observation"], and infos[i]["TimeLimit.truncated"] / ["is_success"] are set.
+
+Host cost per step is O(1) python + one packed device-to-host copy (VecSim.fetch_host, 132 B/env) + work proportional to the
+number of envs that finished an episode in this step; there is no per-env python loop.
 """
 import numpy as np
 
@@ -16,30 +19,80 @@ except Exception:
     _SB3VecEnv = object
 
 
+def _obs_spaces(sim, observation_mode):
+    """observation space of the reference env for this task / mode (reach_cube_env.py:105-115, push:111, stack:115-116)"""
+    subs = {
+        "arm_qpos": sp.Box(-np.pi, np.pi, shape=(6,), dtype=np.float32),
+        "arm_qvel": sp.Box(-10.0, 10.0, shape=(6,), dtype=np.float32),
+    }
+    if sim.task_name in ("push", "pick_place"):
+        subs["target_pos"] = sp.Box(-10.0, 10.0, shape=(3,), dtype=np.float32)     # always present (push_cube_env.py:297)
+    if observation_mode in ("image", "both"):
+        subs["image_front"] = sp.Box(0, 255, shape=(240, 320, 3), dtype=np.uint8)
+        subs["image_top"] = sp.Box(0, 255, shape=(240, 320, 3), dtype=np.uint8)
+    if observation_mode in ("state", "both"):
+        subs[sim.cube_name] = sp.Box(-10.0, 10.0, shape=(3,), dtype=np.float32)
+        if sim.task_name == "stack":
+            subs["cube_blue_pos"] = sp.Box(-10.0, 10.0, shape=(3,), dtype=np.float32)
+    return subs
+
+
+class _InfoList(list):
+    """infos of one step: a real list (SB3 indexes and iterates it) whose entries for envs that did NOT finish an episode all
+    refer to ONE shared dict per step -- building 65 536 dicts per step would dominate the step time."""
+
+
 class LowCostRobotVecEnv(_SB3VecEnv):
     def __init__(self, task, num_envs, seed=0, device=0, env_id_offset=0, **kw):
         kw.setdefault("observation_mode", "state")
+        self.observation_mode = kw["observation_mode"]
         self.sim = VecSim(task, num_envs, device=device, env_id_offset=env_id_offset, base_seed=seed, auto_reset=True, **kw)
         self.num_envs = int(num_envs)
         self.task = task
         self.action_space = sp.Box(-1.0, 1.0, shape=(self.sim.action_dim,), dtype=np.float32)
-        subs = {
-            "arm_qpos": sp.Box(-np.pi, np.pi, shape=(6,), dtype=np.float32),
-            "arm_qvel": sp.Box(-10.0, 10.0, shape=(6,), dtype=np.float32),
-            self.sim.cube_name: sp.Box(-10.0, 10.0, shape=(3,), dtype=np.float32),
-        }
-        if self.sim.aux_name:
-            subs[self.sim.aux_name] = sp.Box(-10.0, 10.0, shape=(3,), dtype=np.float32)
+        subs = _obs_spaces(self.sim, self.observation_mode)
         self.observation_space = sp.Dict(subs)
         self._keys = list(subs)
         self._actions = None
+        self._last = None
         if _SB3VecEnv is not object:
             super().__init__(self.num_envs, self.observation_space, self.action_space)
 
-    def _obs(self):
-        o = self.sim.observations()
-        return {k: o[k] for k in self._keys}
+    # ---- observations ----
+    def _obs_from(self, h):
+        sim = self.sim
+        o = {"arm_qpos": h["arm_qpos"], "arm_qvel": h["arm_qvel"]}
+        if sim.task_name in ("push", "pick_place"):
+            o["target_pos"] = h["aux_pos"]
+        if self.observation_mode in ("state", "both"):
+            o[sim.cube_name] = h["cube_pos"]
+            if sim.task_name == "stack":
+                o["cube_blue_pos"] = h["aux_pos"]
+        if self.observation_mode in ("image", "both"):
+            o["image_front"] = sim.image_front.numpy()
+            o["image_top"] = sim.image_top.numpy()
+        # copies: the pinned mirror is overwritten by the next fetch (SB3 keeps observations in its rollout buffer)
+        return {k: np.ascontiguousarray(o[k]) for k in self._keys}
 
+    def _obs(self):
+        return self._obs_from(self.sim.fetch_host())
+
+    def _terminal(self, tobs_rows):
+        """terminal observation dicts for the rows of `tobs_rows` (k, 18): arm_qpos6, arm_qvel6, cube3, aux3"""
+        sim = self.sim
+        out = []
+        for t in tobs_rows:
+            d = {"arm_qpos": t[0:6].copy(), "arm_qvel": t[6:12].copy()}
+            if sim.task_name in ("push", "pick_place"):
+                d["target_pos"] = t[15:18].copy()
+            if self.observation_mode in ("state", "both"):
+                d[sim.cube_name] = t[12:15].copy()
+                if sim.task_name == "stack":
+                    d["cube_blue_pos"] = t[15:18].copy()
+            out.append(d)
+        return out
+
+    # ---- SB3 VecEnv API ----
     def seed(self, seed=None):
         self._seed = seed
         return [None if seed is None else seed + i for i in range(self.num_envs)]
@@ -58,24 +111,26 @@ class LowCostRobotVecEnv(_SB3VecEnv):
 
     def step_wait(self):
         self.sim.step(self._actions)
-        out = self.sim.outputs()
-        obs = self._obs()
-        dones = out["terminated"] | out["truncated"]
-        infos = [{} for _ in range(self.num_envs)]
-        tobs = None
-        if out["did_reset"].any():
-            tobs = self.sim.terminal_obs.numpy().T  # (N, 18): arm_qpos6, arm_qvel6, cube3, aux3
-        for i in range(self.num_envs):
-            if self.task != "lift":
-                infos[i]["is_success"] = bool(out["is_success"][i])
-            infos[i]["TimeLimit.truncated"] = bool(out["truncated"][i] and not out["terminated"][i])
-            if out["did_reset"][i]:
-                t = tobs[i]
-                d = {"arm_qpos": t[0:6].copy(), "arm_qvel": t[6:12].copy(), self.sim.cube_name: t[12:15].copy()}
-                if self.sim.aux_name:
-                    d[self.sim.aux_name] = t[15:18].copy()
-                infos[i]["terminal_observation"] = d
-        return obs, out["reward"].copy(), dones, infos
+        h = self.sim.fetch_host()
+        obs = self._obs_from(h)
+        term, trunc, dres = h["terminated"], h["truncated"], h["did_reset"]
+        dones = term | trunc
+        lift = self.task == "lift"
+        shared = {"TimeLimit.truncated": False} if lift else {"is_success": False, "TimeLimit.truncated": False}
+        infos = _InfoList([shared]) * self.num_envs
+        idx = np.nonzero(dones | dres)[0]
+        if idx.size:
+            tl = trunc[idx] & ~term[idx]
+            succ = h["is_success"][idx]
+            tobs = self._terminal(h["terminal_obs"][idx]) if h["terminal_obs"] is not None else [None] * idx.size
+            for j, i in enumerate(idx):
+                d = {"TimeLimit.truncated": bool(tl[j])}
+                if not lift:
+                    d["is_success"] = bool(succ[j])
+                if dres[i]:
+                    d["terminal_observation"] = tobs[j]
+                infos[i] = d
+        return obs, h["reward"].copy(), dones, infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -84,7 +139,6 @@ class LowCostRobotVecEnv(_SB3VecEnv):
     def close(self):
         self.sim.close()
 
-    # SB3 VecEnv abstract API
     def get_attr(self, attr_name, indices=None):
         return [getattr(self, attr_name, None)] * self.num_envs
 
@@ -106,11 +160,10 @@ class LowCostRobotVectorEnv:
 
     Autoreset happens in the SAME step (fused in the kernel): the returned observation of a finished env is its reset
     observation, `infos["final_obs"]` holds the terminal observations and `infos["_final_obs"]` the mask, as with
-    gymnasium's AutoresetMode.SAME_STEP.  Arrays are batched numpy arrays, observations a dict of (N, .) float32.
+    gymnasium's AutoresetMode.SAME_STEP.  Arrays are batched numpy arrays, observations a dict of (N, .) arrays.
     """
 
     def __init__(self, task, num_envs, seed=0, device=0, env_id_offset=0, **kw):
-        kw.setdefault("observation_mode", "state")
         self._v = LowCostRobotVecEnv(task, num_envs, seed=seed, device=device, env_id_offset=env_id_offset, **kw)
         self.num_envs = self._v.num_envs
         self.single_action_space = self._v.action_space
@@ -128,21 +181,25 @@ class LowCostRobotVectorEnv:
         return self._v._obs(), {}
 
     def step(self, actions):
-        sim = self._v.sim
+        v, sim = self._v, self._v.sim
         sim.step(np.asarray(actions, np.float32))
-        out = sim.outputs()
-        obs = self._v._obs()
+        h = sim.fetch_host()
+        obs = v._obs_from(h)
         infos = {}
         if self.task != "lift":
-            infos["is_success"] = out["is_success"]
-        if out["did_reset"].any():
-            t = sim.terminal_obs.numpy().T
-            fin = {"arm_qpos": t[:, 0:6], "arm_qvel": t[:, 6:12], sim.cube_name: t[:, 12:15]}
-            if sim.aux_name:
-                fin[sim.aux_name] = t[:, 15:18]
+            infos["is_success"] = h["is_success"].copy()
+        if h["terminal_obs"] is not None:
+            t = h["terminal_obs"]
+            fin = {"arm_qpos": t[:, 0:6].copy(), "arm_qvel": t[:, 6:12].copy()}
+            if sim.task_name in ("push", "pick_place"):
+                fin["target_pos"] = t[:, 15:18].copy()
+            if v.observation_mode in ("state", "both"):
+                fin[sim.cube_name] = t[:, 12:15].copy()
+                if sim.task_name == "stack":
+                    fin["cube_blue_pos"] = t[:, 15:18].copy()
             infos["final_obs"] = fin
-            infos["_final_obs"] = out["did_reset"]
-        return obs, out["reward"].copy(), out["terminated"], out["truncated"], infos
+            infos["_final_obs"] = h["did_reset"].copy()
+        return obs, h["reward"].copy(), h["terminated"].copy(), h["truncated"].copy(), infos
 
     def close(self):
         self._v.close()

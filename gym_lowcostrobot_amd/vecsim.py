@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from ._capi import ACTION_MODES, OBS_MODES, REWARD_TYPES, TASKS, LcrConfig, LcrObsView, LcrOutView, check
+from ._capi import ACTION_MODES, OBS_MODES, REWARD_TYPES, TASKS, LcrConfig, LcrHostView, LcrObsView, LcrOutView, check
 
 
 def _vp(a):
@@ -237,6 +237,32 @@ class VecSim:
             obs["image_front"] = self.image_front.numpy()
             obs["image_top"] = self.image_top.numpy()
         return obs
+
+    def fetch_host(self):
+        """State observations, rewards and flags of all envs after ONE device-to-host copy into pinned memory (lcr_fetch_host).
+        Returns a dict of numpy VIEWS (no further copy) valid until the next call: observations as (N, .) float32 (strided),
+        reward (N,) float32, terminated / truncated / is_success / did_reset (N,) bool, terminal_obs (N, 18) or None."""
+        hv = LcrHostView()
+        check(self.L.lcr_fetch_host(self.handle, ctypes.byref(hv)))
+        N = self.n
+
+        def view(ptr, rows, dt):
+            if not ptr:
+                return None
+            cnt = rows * N
+            buf = (ctypes.c_char * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
+            a = np.frombuffer(buf, dt, cnt)
+            return a.reshape(rows, N).T if rows > 1 else a
+
+        out = {
+            "arm_qpos": view(hv.arm_qpos, 6, np.float32), "arm_qvel": view(hv.arm_qvel, 6, np.float32),
+            "cube_pos": view(hv.cube_pos, 3, np.float32), "aux_pos": view(hv.aux_pos, 3, np.float32),
+            "reward": view(hv.reward, 1, np.float32),
+            "terminated": view(hv.terminated, 1, np.bool_), "truncated": view(hv.truncated, 1, np.bool_),
+            "is_success": view(hv.is_success, 1, np.bool_), "did_reset": view(hv.did_reset, 1, np.bool_),
+            "terminal_obs": view(hv.terminal_obs, 18, np.float32) if hv.any_reset else None,
+        }
+        return out
 
     def outputs(self):
         return {

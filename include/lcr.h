@@ -129,6 +129,20 @@ typedef struct lcr_out_view {
     const float *ctrl;          /* [6][N] actuator targets data.ctrl as apply_action left them (reach_cube_env.py:273); diagnostics only */
 } lcr_out_view;
 
+/* Host-side mirror of everything a host vector env needs after a step (lcr_fetch_host): pointers into a pinned buffer owned
+ * by the handle, SoA [component][N] like the device views, valid until the next lcr_fetch_host / lcr_destroy. */
+typedef struct lcr_host_view {
+    int32_t n_envs;
+    int32_t any_reset;          /* 1 if some env was auto-reset in the last step (terminal_obs is then current) */
+    const float *arm_qpos;      /* [6][N] */
+    const float *arm_qvel;      /* [6][N] */
+    const float *cube_pos;      /* [3][N] */
+    const float *aux_pos;       /* [3][N] or NULL */
+    const float *reward;        /* [N] */
+    const uint8_t *terminated, *truncated, *is_success, *did_reset; /* [N] each */
+    const float *terminal_obs;  /* [18][N], copied only when any_reset */
+} lcr_host_view;
+
 int lcr_abi_version(void);
 const char *lcr_last_error(void);
 
@@ -161,6 +175,10 @@ int lcr_step(lcr_sim *sim, const float *action_dev);
 int lcr_step_host(lcr_sim *sim, const float *action_host);
 
 int lcr_get_obs(lcr_sim *sim, lcr_obs_view *out);
+/* == what DummyVecEnv.step_wait hands to SB3 (examples/gym_manipulation_sb3.py:34-39): state observations + rewards + flags of
+ * all envs in ONE device-to-host copy into pinned memory (132 B/env), plus the terminal observations (72 B/env) only when some
+ * env was reset.  Synchronises the handle's stream. */
+int lcr_fetch_host(lcr_sim *sim, lcr_host_view *out);
 int lcr_get_outputs(lcr_sim *sim, lcr_out_view *out);
 
 /* Full simulator state (replaces poking env.data.qpos / env.data.qvel, e.g. examples/dynamixel_gym_leader.py:96-98;
