@@ -27,7 +27,7 @@ SYMBOLS = [
     "lcr_create", "lcr_destroy", "lcr_set_stream", "lcr_sync", "lcr_reset", "lcr_step", "lcr_step_host",
     "lcr_get_obs", "lcr_get_outputs", "lcr_fetch_host", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
     "lcr_memcpy_h2d", "lcr_memcpy_d2h", "lcr_timer_begin", "lcr_timer_end", "lcr_fill_random_actions",
-    "lcr_calibrate_copy", "lcr_render",
+    "lcr_calibrate_copy", "lcr_render", "lcr_render_state",
 ]
 
 
@@ -84,6 +84,7 @@ class LcrOutView(ctypes.Structure):
         ("is_success", ctypes.c_void_p),
         ("did_reset", ctypes.c_void_p),
         ("terminal_obs", ctypes.c_void_p),
+        ("terminal_quat", ctypes.c_void_p),
         ("timestamp", ctypes.c_void_p),
         ("current_goal", ctypes.c_void_p),
         ("active_mask", ctypes.c_void_p),
@@ -169,6 +170,7 @@ def load():
     L.lcr_fill_random_actions.argtypes = [vp, vp, u64, u64]
     L.lcr_calibrate_copy.argtypes = [vp, vp, ctypes.c_size_t]
     L.lcr_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.lcr_render_state.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("lcr_last_error", "lcr_destroy"):

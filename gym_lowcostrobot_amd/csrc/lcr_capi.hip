@@ -197,6 +197,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_dres = off; off += al(N);
     size_t o_fetch_end = off;
     size_t o_tobs = off; off += al(sizeof(float) * LCR_OBS_DIM * N);
+    size_t o_tquat = off; off += al(sizeof(float) * 8 * N);
     size_t o_tobs_end = off;
     size_t o_el = off; off += al(sizeof(int) * N);
     size_t o_rng = off; off += al(sizeof(unsigned long long) * 4 * N);
@@ -288,6 +289,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.is_success = (unsigned char *)(base + o_succ);
     D.did_reset = (unsigned char *)(base + o_dres);
     D.term_obs = (float *)(base + o_tobs);
+    D.term_quat = (float *)(base + o_tquat);
     D.active_mask = cfg->diagnostics ? (unsigned *)(base + o_diag) : nullptr;
     D.active_count = cfg->diagnostics ? (unsigned *)(base + o_diag + al(sizeof(unsigned) * N)) : nullptr;
     D.max_sweeps = cfg->diagnostics ? (unsigned *)(base + o_diag + 2 * al(sizeof(unsigned) * N)) : nullptr;
@@ -409,6 +411,7 @@ int lcr_get_outputs(lcr_sim *s, lcr_out_view *out) {
     out->is_success = s->dev.is_success;
     out->did_reset = s->dev.did_reset;
     out->terminal_obs = s->dev.term_obs;
+    out->terminal_quat = s->dev.term_quat;
     out->timestamp = s->dev.sim_time;
     out->current_goal = s->dev.goal;
     out->active_mask = s->dev.active_mask;
@@ -562,6 +565,38 @@ int lcr_render(lcr_sim *s, int env, int camera, int width, int height, uint8_t *
         s->render_bytes = bytes;
     }
     int rc = lcr_launch_render_single(s->dev, cam, env, width, height, s->render_dev, s->stream);
+    if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(rgb_host, s->render_dev, bytes, hipMemcpyDeviceToHost));
+    return LCR_OK;
+}
+
+int lcr_render_state(lcr_sim *s, int camera, int width, int height, const double *qpos_host, const float *target_host, uint8_t *rgb_host) {
+    SIMCHK(s);
+    if (!rgb_host || !qpos_host) return fail(LCR_ERR_INVALID, "NULL argument");
+    if (camera < 0 || camera > 2) return fail(LCR_ERR_INVALID, "camera must be 0 (front), 1 (top) or 2 (vizu)");
+    if (width <= 0 || height <= 0 || (size_t)width * height > ((size_t)1 << 26)) return fail(LCR_ERR_INVALID, "bad frame size");
+    LcrCam cam = camera == 0 ? s->cam_front : (camera == 1 ? s->cam_top : s->cam_vizu);
+    cam.s = (float)(2.0 * std::tan(0.5 * 45.0 * M_PI / 180.0) / height);
+    const size_t bytes = (size_t)width * height * 3, frame = (bytes + 255) & ~(size_t)255, need = frame + 256;
+    if (need > s->render_bytes) {
+        if (s->render_dev) (void)hipFree(s->render_dev);
+        s->render_dev = nullptr; s->render_bytes = 0;
+        hipError_t e = hipMalloc((void **)&s->render_dev, need);
+        if (e != hipSuccess) return fail(LCR_ERR_OOM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        s->render_bytes = need;
+    }
+    // a one-env view of the handle whose state arrays are the caller's pose, staged behind the frame
+    float st[32];
+    for (int i = 0; i < s->nq; i++) st[i] = (float)qpos_host[i];
+    for (int i = 0; i < 3; i++) st[s->nq + i] = target_host ? target_host[i] : 0.f;
+    float *stage = (float *)(s->render_dev + frame);
+    HIPCHK(hipMemcpyAsync(stage, st, sizeof(float) * (s->nq + 3), hipMemcpyHostToDevice, s->stream));
+    LcrDev P1 = s->dev;
+    P1.n = 1;
+    P1.qpos = stage;
+    P1.target = stage + s->nq;
+    int rc = lcr_launch_render_single(P1, cam, 0, width, height, s->render_dev, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(rgb_host, s->render_dev, bytes, hipMemcpyDeviceToHost));

@@ -46,6 +46,7 @@ struct LcrDev {
     float *reward;
     unsigned char *terminated, *truncated, *is_success, *did_reset;
     float *term_obs;  // [18][n]
+    float *term_quat; // [8][n]  cube quaternion(s) of the terminal state (valid where did_reset)
     unsigned *active_mask, *active_count, *max_sweeps, *choice;  // [n] each, diagnostics of the last step (diag != 0)
     float *ctrl_out;  // [6][n] actuator targets of the last step (diag != 0)
     float *scratch;   // Stack: cube<->cube contact records [64][n]

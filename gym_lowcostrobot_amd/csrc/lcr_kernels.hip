@@ -1625,7 +1625,13 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         P.did_reset[e] = do_reset;
     }
     if (do_reset) {  // SB3 VecEnv semantics: keep the terminal observation, then reset in place
-        if (valid) write_obs18<NC>(P, P.term_obs, e, S, target);
+        if (valid) {
+            write_obs18<NC>(P, P.term_obs, e, S, target);
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) P.term_quat[(size_t)(4 * c + k) * N + e] = S.cq[c][k];   // completes the terminal pose (frames of recordings)
+        }
         Pcg g = load_rng(P, e);
         reset_env<NC>(P, S, g, target, lag_ee, goal);
         if (diverged) {

@@ -122,29 +122,44 @@ class VecRecorder:
         self.files = []
 
     def after_step(self, actions):
-        """actions: (N, k) host array that was just applied"""
-        obs = self.sim.observations()
-        out = self.sim.outputs()
-        tobs = self.sim.terminal_obs.numpy().T if out["did_reset"].any() else None
-        for e in self.which:
-            o = {"arm_qpos": obs["arm_qpos"][e], "arm_qvel": obs["arm_qvel"][e]}
-            if out["did_reset"][e]:  # the kernel already reset this env: its last observation is the terminal one
-                o = {"arm_qpos": tobs[e, 0:6].copy(), "arm_qvel": tobs[e, 6:12].copy()}
-            elif "image_front" in obs:
-                o["image_front"], o["image_top"] = obs["image_front"][e], obs["image_top"][e]
+        """actions: (N, k) host array that was just applied.  Only the recorded envs' data crosses PCIe: one packed copy of the
+        state outputs (132 B/env) and one 230 400-B copy per recorded env and camera."""
+        sim = self.sim
+        h = sim.fetch_host()
+        has_img = sim.image_front is not None
+        if has_img:
+            front = sim.read_rows(sim.image_front, self.which)
+            top = sim.read_rows(sim.image_top, self.which)
+        tq = None
+        for j, e in enumerate(self.which):
+            if h["did_reset"][e]:
+                # the kernel already reset this env: its last observation is the terminal one, and its last frame is ray-cast
+                # from the terminal pose (terminal_obs + terminal_quat) -- the frame buffers show the reset state
+                t = h["terminal_obs"][e]
+                o = {"arm_qpos": t[0:6].copy(), "arm_qvel": t[6:12].copy()}
+                if has_img:
+                    if tq is None:
+                        tq = sim.terminal_quat.numpy()
+                    qpos = np.zeros(sim.nq)
+                    qpos[0:6] = t[0:6]; qpos[6:9] = t[12:15]; qpos[9:13] = tq[0:4, e]
+                    if sim.task_name == "stack":
+                        qpos[13:16] = t[15:18]; qpos[16:20] = tq[4:8, e]
+                    tgt = t[15:18] if sim.task_name in ("push", "pick_place") else None
+                    o["image_front"] = sim.render_state(qpos, tgt, "camera_front")
+                    o["image_top"] = sim.render_state(qpos, tgt, "camera_top")
+            else:
+                o = {"arm_qpos": h["arm_qpos"][e].copy(), "arm_qvel": h["arm_qvel"][e].copy()}
+                if has_img:
+                    o["image_front"], o["image_top"] = front[j], top[j]
             self._obs[e].append(o)
             self._act[e].append(np.asarray(actions[e], np.float32))
-            if out["did_reset"][e]:
+            if h["did_reset"][e]:
                 self._flush(e)
 
     def _flush(self, e):
         if self._obs[e]:
-            keep = [o for o in self._obs[e]]
-            if any("image_front" in o for o in keep) and not all("image_front" in o for o in keep):
-                for o in keep:  # terminal frames of auto-reset envs have no image: drop the image datasets consistently
-                    o.pop("image_front", None); o.pop("image_top", None)
             path = os.path.join(self.folder, f"{self.name_prefix}-env{e}-episode-{self.episode_id[e]}.hdf5")
-            self.files.append(write_episode(path, keep, self._act[e]))
+            self.files.append(write_episode(path, self._obs[e], self._act[e]))
             self.episode_id[e] += 1
         self._obs[e], self._act[e] = [], []
 

@@ -133,6 +133,7 @@ class VecSim:
         self.is_success = DeviceArray(self, out.is_success, (N,), np.uint8)
         self.did_reset = DeviceArray(self, out.did_reset, (N,), np.uint8)
         self.terminal_obs = DeviceArray(self, out.terminal_obs, (18, N), np.float32)
+        self.terminal_quat = DeviceArray(self, out.terminal_quat, (8, N), np.float32)
         self.timestamp = DeviceArray(self, out.timestamp, (N,), np.float64)
         self.current_goal = DeviceArray(self, out.current_goal, (N,), np.int32)
         self.active_mask = DeviceArray(self, out.active_mask, (N,), np.uint32) if out.active_mask else None
@@ -201,6 +202,28 @@ class VecSim:
         cam = {"camera_front": 0, "camera_top": 1, "camera_vizu": 2}[camera]
         out = np.empty((height, width, 3), np.uint8)
         check(self.L.lcr_render(self.handle, int(env), cam, int(width), int(height), _vp(out)))
+        return out
+
+    def render_state(self, qpos, target=None, camera="camera_front", width=320, height=240):
+        """ray-cast an arbitrary pose (qpos of length nq as env.data.qpos; target_pos or None) without touching the sim state"""
+        cam = {"camera_front": 0, "camera_top": 1, "camera_vizu": 2}[camera]
+        q = np.ascontiguousarray(qpos, np.float64)
+        if q.shape != (self.nq,):
+            raise ValueError(f"qpos must have shape ({self.nq},)")
+        t = None if target is None else np.ascontiguousarray(target, np.float32)
+        out = np.empty((height, width, 3), np.uint8)
+        check(self.L.lcr_render_state(self.handle, cam, int(width), int(height), _vp(q), _vp(t), _vp(out)))
+        return out
+
+    def read_rows(self, arr, rows):
+        """host copies of selected leading-axis rows of a device array (e.g. the frames of a few recorded envs): one small
+        device-to-host copy per row instead of the whole array"""
+        rows = list(rows)
+        row_shape = arr.shape[1:]
+        nb = int(np.prod(row_shape)) * arr.dtype.itemsize
+        out = np.empty((len(rows),) + row_shape, arr.dtype)
+        for i, r in enumerate(rows):
+            check(self.L.lcr_memcpy_d2h(self.handle, _vp(out[i]), ctypes.c_void_p(arr.ptr + int(r) * nb), nb))
         return out
 
     def calibrate_copy(self, n_floats):

@@ -116,6 +116,7 @@ typedef struct lcr_out_view {
     const uint8_t *is_success;  /* [N]  info["is_success"] (lift: always 0, reference returns info={}) */
     const uint8_t *did_reset;   /* [N]  1 where the env was auto-reset at the end of this step */
     const float *terminal_obs;  /* [18][N] arm_qpos6, arm_qvel6, cube_pos3, aux3 -- valid where did_reset */
+    const float *terminal_quat; /* [8][N]  cube quaternion(s) of the terminal state (with terminal_obs: the full terminal pose) */
     const double *timestamp;    /* [N]  accumulated simulation time = info["timestamp"] of PushCubeLoop-v0 (push_cube_loop_env.py:328) */
     const int32_t *current_goal;/* [N]  PushCubeLoop-v0 goal side (0|1), persists across resets (push_cube_loop_env.py:136,341) */
     /* solver diagnostics of the last step, valid when lcr_config.diagnostics != 0 (else NULL): bit s of active_mask = constraint
@@ -208,6 +209,9 @@ int lcr_fill_random_actions(lcr_sim *sim, float *action_dev, uint64_t seed, uint
  * the observation cameras: ray-cast env `env` from camera 0 (camera_front), 1 (camera_top) or 2 (camera_vizu) at
  * width x height into rgb_host[height][width][3].  Synchronous. */
 int lcr_render(lcr_sim *sim, int env, int camera, int width, int height, uint8_t *rgb_host);
+/* The same for an arbitrary pose given by the caller (qpos_host[nq] as env.data.qpos, target_host[3] or NULL): e.g. the last
+ * frame of an episode whose env the step kernel has already reset (terminal_obs + terminal_quat).  Does not touch the sim state. */
+int lcr_render_state(lcr_sim *sim, int camera, int width, int height, const double *qpos_host, const float *target_host, uint8_t *rgb_host);
 
 /* Measurement support: copy n_floats floats from the start of the state arena to dst_dev with one dword load and
  * one dword store per lane (the step kernel's access pattern): a launch with a KNOWN byte count (4*n read, 4*n

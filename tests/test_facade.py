@@ -173,7 +173,7 @@ def test_vector_env_same_step_autoreset(hip_lib):
 def test_vec_recorder_writes_reference_layout(hip_lib, tmp_path):
     from gym_lowcostrobot_amd import VecSim, recorder
 
-    sim = VecSim("reach", 16, observation_mode="both", max_episode_steps=4)
+    sim = VecSim("push", 16, observation_mode="both", max_episode_steps=4)
     rec = recorder.VecRecorder(sim, str(tmp_path), which=(0, 5))
     rng = np.random.default_rng(0)
     for t in range(9):
@@ -183,7 +183,37 @@ def test_vec_recorder_writes_reference_layout(hip_lib, tmp_path):
     rec.close()
     assert len(rec.files) == 6                                     # two episodes of 4 steps + one partial, for two envs
     ep = recorder.load_episode(sorted(rec.files)[0])
-    assert ep["observations/qpos"].shape == (4, 6) and ep["action"].shape == (4, 5)
+    # dataset names / shapes / dtypes of record_hdf5.py:52-61 -- every COMPLETED episode keeps its image datasets, the last
+    # frame being ray-cast from the terminal pose (the frame buffers already show the reset state by then)
+    assert set(ep) == set(recorder.DATASETS)
+    assert ep["observations/qpos"].shape == (4, 6) and ep["observations/qpos"].dtype == np.float32
+    assert ep["observations/qvel"].shape == (4, 6) and ep["action"].shape == (4, 5) and ep["action"].dtype == np.float32
+    for cam in ("front", "top"):
+        im = ep[f"observations/images/{cam}"]
+        assert im.shape == (4, 240, 320, 3) and im.dtype == np.uint8 and im[-1].std() > 5
+    # the terminal frame belongs to the episode: it shows the arm where the terminal qpos puts it, not at the reset pose q = 0
+    terminal, reset_like = ep["observations/images/top"][-1].astype(int), sim.render_state(np.r_[np.zeros(6), 0.3, 0.3, 0.015, 1, 0, 0, 0], None, "camera_top").astype(int)
+    assert np.abs(ep["observations/qpos"][-1]).max() > 0.05
+    assert (np.abs(terminal - reset_like).max(-1) > 30).mean() > 0.002
+    sim.close()
+    if recorder.h5py is None:
+        print("[recorder] h5py is not installed in this image: episodes were written as .npz with the HDF5 dataset names")
+
+
+@pytest.mark.gpu
+def test_render_state_matches_render_of_the_same_pose(hip_lib):
+    from gym_lowcostrobot_amd import VecSim
+
+    sim = VecSim("stack", 4, observation_mode="state", auto_reset=False)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        sim.step(rng.uniform(-1, 1, (4, 6)).astype(np.float32))
+    st = sim.get_state()
+    for e in (0, 3):
+        for cam in ("camera_front", "camera_top"):
+            a = sim.render(e, cam, 320, 240)
+            b = sim.render_state(st["qpos"][:, e], None, cam, 320, 240)
+            np.testing.assert_array_equal(a, b)
     sim.close()
 
 
