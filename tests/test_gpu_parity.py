@@ -553,6 +553,47 @@ def test_converged_solver_mode(hip_lib, task):
     sim.close()
 
 
+@pytest.mark.parametrize("task", ["push", "stack", "pick_place", "reach"])
+def test_image_observations_vs_cpu_raycaster(hip_lib, task):
+    """image observations against oracle/render_oracle.py (numpy fp64, per pixel, no culling / tiles / cached background):
+    8 random states x 2 cameras, >= 99.9 % of the pixels within +-2 levels (silhouette edges and checker boundaries may fall on
+    the other side of a pixel centre in fp32); the 640x640 render() frame likewise"""
+    from gym_lowcostrobot_amd import VecSim
+    from oracle import render_oracle
+
+    n = 8
+    rng = np.random.default_rng(17)
+    sim = VecSim(task, n, observation_mode="both", auto_reset=False)
+    st = sim.get_state()
+    qpos = st["qpos"].copy()
+    q, _ = util.random_arm_state(rng, n)
+    qpos[:6] = q.T
+    ncube = 2 if task == "stack" else 1
+    for c in range(ncube):
+        qpos[6 + 7 * c] = rng.uniform(-0.15, 0.15, n); qpos[7 + 7 * c] = rng.uniform(0.0, 0.3, n); qpos[8 + 7 * c] = rng.uniform(0.015, 0.08, n)
+        quat = rng.normal(size=(4, n)); quat /= np.linalg.norm(quat, axis=0)
+        qpos[9 + 7 * c: 13 + 7 * c] = quat
+    target = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(0.0, 0.3, n), rng.uniform(0, 0.1, n)]).astype(np.float32)
+    qpos = qpos.astype(np.float32).astype(np.float64)
+    sim.set_state(qpos=qpos, target=target)
+    sim.reset(mask=np.zeros(n, np.uint8))            # no env reset, but re-renders the frames from the new state
+    obs = sim.observations()
+    worst = 0.0
+    for e in range(n):
+        for cam, key in (("camera_front", "image_front"), ("camera_top", "image_top")):
+            ref = render_oracle.render(task, qpos[:, e], target[:, e], cam).astype(int)
+            d = np.abs(obs[key][e].astype(int) - ref).max(-1)
+            frac = (d <= 2).mean()
+            worst = max(worst, 1 - frac)
+            assert frac >= 0.999, (task, e, cam, frac, np.argwhere(d > 2)[:5])
+            assert ref.std() > 5
+    ref = render_oracle.render(task, qpos[:, 0], target[:, 0], "camera_vizu", 640, 640).astype(int)
+    d = np.abs(sim.render(0, "camera_vizu", 640, 640).astype(int) - ref).max(-1)
+    assert (d <= 2).mean() >= 0.999, (d <= 2).mean()
+    print(f"[image parity] {task}: worst fraction of pixels beyond +-2 levels {worst:.5f}")
+    sim.close()
+
+
 def test_zz_outlier_census(hip_lib):
     """(runs last in this file) every out-of-tolerance env seen by the parity loops above differed from the oracle in its
     active set; print the census"""

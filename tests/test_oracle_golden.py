@@ -520,3 +520,32 @@ def test_converged_mode_reaches_the_tolerance():
     ad, four = errs["adaptive"], errs["four"]
     assert np.median(ad) < 1e-6 and np.percentile(ad, 99) < 5e-6 and ad.max() < 5e-3, (np.median(ad), np.percentile(ad, 99), ad.max())
     assert np.median(ad) < 0.05 * np.median(four) and np.percentile(ad, 99) < 0.05 * np.percentile(four, 99)
+
+
+def test_render_oracle_places_the_scene_by_the_pinhole_model():
+    """oracle/render_oracle.py: camera poses parsed from the scene files (model_golden.json), fovy 45 deg: a cube centre and a
+    point inside the forearm project to pixels of the cube's / the arm's colour; floor is a bluish checker, sky above the horizon"""
+    from oracle import render_oracle as ro
+    q = np.r_[0.3, -0.4, 0.5, 0.2, 0.1, -0.3, 0.08, 0.2, 0.015, 1, 0, 0, 0]
+    for cam in ("camera_front", "camera_top"):
+        pos, X, Y, Z = ro.camera("reach", cam)
+        assert abs(X @ Y) < 1e-12 and abs(np.linalg.norm(X) - 1) < 1e-12 and np.allclose(np.cross(X, Y), Z)
+        im = ro.render("reach", q, None, cam).astype(int)
+        s = 2 * np.tan(np.radians(22.5)) / 240
+        def pix(p):
+            d = np.asarray(p) - pos
+            depth = -(d @ Z)
+            return int(round(160 + (d @ X) / (depth * s) - 0.5)), int(round(120 - (d @ Y) / (depth * s) - 0.5))
+        u, v = pix(q[6:9])
+        assert im[v, u, 0] > 60 and im[v, u, 1] < 20 and im[v, u, 2] < 20, (cam, im[v, u])          # red cube (reach_cube.xml:26 rgba 0.5 0 0)
+        lp, _, _ = orc.fk(q[:6])
+        u, v = pix(0.5 * (lp[2] + lp[3]))
+        assert im[v, u].min() > 70 and im[v, u].max() - im[v, u].min() < 12, (cam, im[v, u])     # light grey arm
+    top = ro.render("reach", q, None, "camera_top").astype(int)
+    assert top[5, 5, 2] > top[5, 5, 1] > top[5, 5, 0]                                              # bluish floor
+    front = ro.render("reach", q, None, "camera_front").astype(int)
+    assert front[2, 160, 2] > front[2, 160, 0] and front[2, 160].tolist() != front[230, 160].tolist()   # sky row vs floor row
+    # the translucent target marker of PushCube blends over the floor (alpha 0.3, push_cube.xml:35)
+    a = ro.render("push", q, [0.0, 0.1, 0.005], "camera_top").astype(int)
+    b = ro.render("push", q, [0.1, 0.25, 0.005], "camera_top").astype(int)
+    assert (np.abs(a - b).max(-1) > 10).mean() > 0.005
