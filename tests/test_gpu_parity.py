@@ -293,14 +293,17 @@ def test_joint_limit_rows(hip_lib):
     sim.close()
 
 
-def test_full_size_properties(hip_lib):
-    """BASELINE.json sizes: 65 536 envs -- finite state, episodes cycle through TimeLimit, success flags consistent"""
+@pytest.mark.parametrize("task,mode,n,obs", [("reach", "joint", 65536, "state"), ("push", "joint", 65536, "state"),
+                                             ("pick_place", "ee", 32768, "state"), ("stack", "joint", 32768, "both")])
+def test_full_size_properties(hip_lib, task, mode, n, obs):
+    """BASELINE.json configs 2-5 at their per-GPU size: finite state, episodes cycle through TimeLimit, flags consistent,
+    quaternions normalised, joint limits hold, frames non-constant (config 5)"""
     from gym_lowcostrobot_amd import VecSim
-    n = 65536
-    sim = VecSim("reach", n, observation_mode="state", base_seed=3)
+    sim = VecSim(task, n, action_mode=mode, observation_mode=obs, base_seed=3)
     act = sim.alloc_actions()
     resets = np.zeros(n, np.int64)
-    for t in range(60):
+    steps = 60 if obs == "state" else 12
+    for t in range(steps):
         sim.fill_random_actions(act, 1, t)
         sim.step_device(act.ptr)
         out = sim.outputs()
@@ -312,11 +315,22 @@ def test_full_size_properties(hip_lib):
         assert np.array_equal(r == 0, out["is_success"])
     st = sim.get_state()
     assert np.isfinite(st["qpos"]).all() and np.isfinite(st["qvel"]).all()
-    assert resets.min() >= 1 and (st["elapsed"] < 50).all()                      # every env hit the 50-step TimeLimit once
+    if steps >= 50:
+        assert resets.min() >= 1                                                 # every env hit the 50-step TimeLimit once
+    assert (st["elapsed"] < 50).all()
     assert np.abs(st["qpos"][:6]).max() <= 3.2                                   # joint limits hold under a random policy
-    qn = np.linalg.norm(st["qpos"][9:13], axis=0)
-    np.testing.assert_allclose(qn, 1.0, atol=1e-5)                               # cube quaternions stay normalised
-    assert (st["qpos"][8] > -0.02).all()                                         # no cube fell through the floor
+    for c in range(2 if task == "stack" else 1):
+        qn = np.linalg.norm(st["qpos"][9 + 7 * c: 13 + 7 * c], axis=0)
+        np.testing.assert_allclose(qn, 1.0, atol=1e-5)                           # cube quaternions stay normalised
+        assert (st["qpos"][8 + 7 * c] > -0.02).all()                             # no cube fell through the floor
+    if task == "pick_place":
+        assert np.abs(st["ee_lag"]).max() < 1.0 and (st["target"][2] >= 0).all()
+    if obs == "both":                                                            # frames of a few envs across the batch
+        rows = [0, 1, n // 2, n - 1]
+        for arr in (sim.image_front, sim.image_top):
+            fr = sim.read_rows(arr, rows)
+            assert fr.shape == (4, 240, 320, 3) and all(f.std() > 5 for f in fr)
+            assert not np.array_equal(fr[0], fr[1])                              # different envs, different cubes
     sim.close()
 
 
