@@ -204,7 +204,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_goal = off; off += al(sizeof(int) * N);
     size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
-    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * 64 * N);   // cube<->cube contact records
+    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * 24 * N);   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);

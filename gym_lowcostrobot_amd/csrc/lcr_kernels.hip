@@ -263,15 +263,17 @@ struct Warm {
 
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
 constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 20 rows -> 30 KiB per wave (4 waves per CU: 120 of 160 KiB)
-// Stack only: cube<->cube contact records, 4 slots x 16 floats per env: pos3 f4 aref4 inv4 Rn.  They live in a global
-// scratch array [64][N] (coalesced, touched only by waves that have a cube<->cube contact, ~4 % of the wave-substeps):
-// the LDS is taken by the g rows.
+// Stack only: cube<->cube contact records, 4 slots x 16 floats per lane: pos3 f4 aref4 inv4 Rn (LDS, see LdsSize)
 constexpr int CC_REC = 16;
 // The per-substep constants of the floor<->cube slots of cube 0 (aref[4], inv[4]: written once per substep, read once per PGS
 // sweep) are parked in LDS as 16-B vectors instead of occupying 32 registers across the whole solver loop:
 // [slot 0..3][aref|inv][lane][4] = 8 KiB per wave (30 + 8 = 38 of the 40 KiB a wave may use at four waves per CU).
 constexpr int LDS_PARK_FLOATS = 4 * 2 * 64 * 4;
-template <int NC, bool WALLS> struct LdsSize { static constexpr int value = LDS_G_FLOATS + LDS_PARK_FLOATS; };
+// Stack (two cubes): the 40 KiB hold the 16 g rows of the four finger slots (24 KiB) and the four cube<->cube contact records
+// (16 floats per lane each, 16 KiB: they are read and written by every sweep of the waves that determine the launch time);
+// the four g rows of its arm-link proxy slot live in a coalesced global scratch array instead ([12][N] float2, L1/L2 resident).
+constexpr int LDS_CC_FLOATS = 4 * CC_REC * 64;
+template <int NC, bool WALLS> struct LdsSize { static constexpr int value = NC == 2 ? 16 * LDS_ROW + LDS_CC_FLOATS : LDS_G_FLOATS + LDS_PARK_FLOATS; };
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 // sphere (centre, radius) vs cube box: signed distance, world normal (box -> sphere) and contact point midway between the surfaces
@@ -497,7 +499,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
             T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
             T.inv[3] = rcp(iinv + Rt);
-            if (c == 0) {
+            if (c == 0 && NC == 1) {
                 float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                 pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
                 pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
@@ -521,8 +523,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool cc_act[4] = {false, false, false, false};
     bool cc_any = false;
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
-    float *ccl = (NC == 2 ? P.scratch : lds) + env;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*N] (global scratch, see CC_REC)
-    const size_t CS = (size_t)P.n;
+    float *ccl = lds + 16 * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
+    const size_t CS = 64;
     if constexpr (NC == 2) {
         const f3 dc = S.cp[1] - S.cp[0];
         const f3 ax0[3] = {CR[0].X, CR[0].Y, CR[0].Z}, ax1[3] = {CR[1].X, CR[1].Y, CR[1].Z};
@@ -931,7 +933,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 fsub(CL, g);
                 float gg = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; j++) { gg = fmaf(g[j], g[j], gg); lds[(as_row0(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j]; }
+                for (int j = 0; j < 6; j++) {
+                    gg = fmaf(g[j], g[j], gg);
+                    if (NC == 2 && s == 4) P.scratch[((size_t)(r * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
+                    else lds[(as_row0(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j];
+                }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 T.inv[r] = rcp(gg + diagc + Rr);
@@ -1039,7 +1045,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
                 float aref0 = T.aref[0], aref1 = T.aref[1], aref2 = T.aref[2], aref3 = T.aref[3];
                 float inv0 = T.inv[0], inv1 = T.inv[1], inv2 = T.inv[2], inv3 = T.inv[3];
-                if (c == 0) {
+                if (c == 0 && NC == 1) {
                     const float4v *pk = reinterpret_cast<const float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                     const float4v a4 = pk[0], i4 = pk[64];
                     aref0 = a4.x; aref1 = a4.y; aref2 = a4.z; aref3 = a4.w;
@@ -1184,7 +1190,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                 for (int r = 0; r < nrow; r++)
 #pragma unroll
-                    for (int k = 0; k < 3; k++) g[r][k] = *reinterpret_cast<const float2v *>(&lds[(as_row0(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                    for (int k = 0; k < 3; k++)
+                        g[r][k] = (NC == 2 && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
+                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0(s) + r) * LDS_ROW + k * 128 + lane * 2]);
                 float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
                 const float arefv[4] = {T.aref[0], T.aref[1], T.aref[2], T.aref[3]}, invv[4] = {T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
                 // pick the cube this slot talks to (wave-divergent only for Stack)
