@@ -90,19 +90,16 @@ def pinch_setup(o, gap=0.0285):
 
 MAX_DQ, MAX_DV = 2e-2, 2.0   # bound on explained outliers after one control step (rad or m, rad/s or m/s)
 STATS = {"envs": 0, "out": 0, "out_flip": 0, "out_illcond": 0, "max_dq": 0.0, "max_dv": 0.0}
-_twins = {}
-
-
 def _twin(o):
     """the oracle's fp32-arithmetic build (same C source compiled with float) with the same parameters"""
-    key = id(o)
-    if key not in _twins:
-        t = orc.Oracle(o.task, o.n, f32=True)
+    t = getattr(o, "_f32_twin", None)
+    if t is None:
         import ctypes
+
+        t = orc.Oracle(o.task, o.n, f32=True)
         ctypes.memmove(ctypes.byref(t.params), ctypes.byref(o.params), ctypes.sizeof(o.params))
-        _twins.clear()
-        _twins[key] = t
-    return _twins[key]
+        o._f32_twin = t
+    return t
 
 
 def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_DV, where=""):
