@@ -770,11 +770,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
     }
 
-    // ---- collision: arm-coupled contact slots (NAS): finger spheres vs cube / floor, link-proxy groups (D3); rows g = L^-1 J^T
+    // ---- collision: arm-coupled contact slots (NAS): finger spheres vs cube / floor, arm-link proxies (D3); rows g = L^-1 J^T
     //      go to LDS.  Every slot is skipped wave-uniformly when no lane of the wave touches. ----
     ArmSlot AS[NAS];
     bool slot_any[NAS];
-    bool on_cube5 = false;       // slot 4: this lane's contact is against a cube (else the floor)
+    bool link_on_cube = false;       // slot 4: this lane's contact is against a cube (else the floor)
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
     int link_bi = 0;             // slot 4: which proxy
     int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
@@ -848,7 +848,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
             sel += 64 * (bi + 1);
             dist = bestd;
-            on_cube5 = oncube;
+            link_on_cube = oncube;
             slot_cube[2] = cidx;
             link_nj = bi < 2 ? 3 : bi + 2;                       // proxies 0, 1 on link_3 (3 joints); 2 on link_4; 3 on link_5; 4 on link_6
             invw_link = bi < 2 ? INVW_TRAN_L3 : (bi == 2 ? INVW_TRAN_L4 : (bi == 3 ? INVW_TRAN_L5 : INVW_TRAN_L6));
@@ -993,7 +993,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     // lane) the floor<->cube rows only talk to themselves.  Once a sweep changes none of their forces by more than 2e-6 of the
     // largest normal force (warm-started resting or airborne cubes: the update is at the rounding level of fp32), the remaining
     // sweeps of this substep would repeat that no-op and are skipped for the whole wave.
-    const bool cube_coupled = slot_any[0] || slot_any[1] || (slot_any[4] && __any(on_cube5)) || cc_any || wall_any;
+    const bool cube_coupled = slot_any[0] || slot_any[1] || (slot_any[4] && __any(link_on_cube)) || cc_any || wall_any;
     bool floor_quiet = false;
     for (int it = 0; it < max_it; it++) {
         float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep
@@ -1174,14 +1174,14 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
         }
-        // arm-coupled slots: finger spheres, link-proxy groups
+        // arm-coupled slots: finger spheres, arm-link proxies
         if (wave_arm) {
 #pragma unroll
             for (int s = 0; s < NAS; s++) {
                 if (!slot_any[s]) continue;
                 ArmSlot &T = AS[s];
                 const bool may_cube = s < 2 || s == 4;
-                const bool oncube = s < 2 || (s == 4 && on_cube5);
+                const bool oncube = s < 2 || (s == 4 && link_on_cube);
                 const int nrow = as_rows(s);
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
@@ -1199,7 +1199,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
                 const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
                 if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
-                // cube-side inverse inertia of this lane's contact (zero when slot 5 touches the floor: the cube terms vanish)
+                // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
                 const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
                 // The cube's share of the four row residuals is tracked as SCALARS: v_r = d_r . (acceleration of the contact
                 // point of the cube), wn = n . (angular acceleration).  A force change dlt on row j moves them by closed-form

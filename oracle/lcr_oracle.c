@@ -845,7 +845,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     memcpy(a0, tau, sizeof(real) * nv);
     chol_solve(L, nv, a0); /* qacc_smooth */
 
-    /* -- collision (D3, D5) in fixed order: floor-cube(s), cube-cube, rails, sphere-cube, sphere-floor, link-proxy groups */
+    /* -- collision (D3, D5) in fixed order: floor-cube(s), cube-cube, rails, sphere-cube, sphere-floor, arm-link proxies */
     contact_t con[MAX_CONTACTS];
     int ncon = 0;
     for (int c = 0; c < nc; c++) ncon += collide_plane_box(&K, c, con + ncon);
