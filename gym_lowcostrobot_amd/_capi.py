@@ -132,12 +132,18 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m gym_lowcostrobot_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
-    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two runtimes in one process do not coexist when the system
-    # one (ours) initialises first (torch then reports "No HIP GPUs are available"), so if torch is installed it is
-    # imported BEFORE liblcr_hip.so is loaded; set LCR_NO_TORCH_PRELOAD=1 to skip (processes that never use torch).
-    if "torch" not in sys.modules and os.environ.get("LCR_NO_TORCH_PRELOAD") != "1" and importlib.util.find_spec("torch"):
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so, same SONAME as the system one).  Two HIP
+    # runtimes in one process do not coexist, so whichever of torch and this library comes first must settle on ONE copy.
+    # If torch is installed but not imported yet, its bundled runtime is pre-loaded here BY PATH (no `import torch`): the
+    # dynamic linker then resolves liblcr_hip.so's DT_NEEDED libamdhip64.so.7 to that already-loaded object, and a later
+    # `import torch` finds its own runtime in place -- the import order no longer matters.  LCR_NO_TORCH_PRELOAD=1 skips this
+    # (processes that never use torch run on the system runtime of /opt/rocm).
+    if "torch" not in sys.modules and os.environ.get("LCR_NO_TORCH_PRELOAD") != "1":
         try:
-            import torch  # noqa: F401
+            spec = importlib.util.find_spec("torch")
+            rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so") if spec and spec.submodule_search_locations else None
+            if rt and os.path.exists(rt):
+                ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         except Exception:
             pass
     L = ctypes.CDLL(LIB_PATH)
