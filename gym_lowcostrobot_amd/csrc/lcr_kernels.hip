@@ -495,10 +495,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.aref[1] = -B_DEF * vp.y;
             T.aref[2] = B_DEF * vp.x;       // t2 = -x
             T.aref[3] = -B_DEF * cww[c].z;  // torsion about n
-            T.inv[0] = rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn);
-            T.inv[1] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf);
-            T.inv[2] = rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf);
-            T.inv[3] = rcp(iinv + Rt);
+            // (an inactive slot gets inv = 0: with f = 0 its row updates then come out as exactly zero in the sweeps, no per-sweep selects)
+            T.inv[0] = T.act ? rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn) : 0.f;
+            T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
+            T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
+            T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
             if (c == 0 && NC == 1) {
                 float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                 pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
@@ -667,7 +668,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
                     }
                     ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
-                    ccl[(size_t)(s * CC_REC + 11 + r) * CS] = rcp(diag + Rr);
+                    ccl[(size_t)(s * CC_REC + 11 + r) * CS] = cc_act[s] ? rcp(diag + Rr) : 0.f;
                 }
                 ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
             }
@@ -752,10 +753,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     T.aref[1] = -B_DEF * vp.y;
                     T.aref[2] = -B_DEF * sg * vp.z;
                     T.aref[3] = -B_DEF * sg * w.x;
-                    T.inv[0] = rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn);
-                    T.inv[1] = rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf);
-                    T.inv[2] = rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf);
-                    T.inv[3] = rcp(iinv + Rt);
+                    T.inv[0] = T.act ? rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn) : 0.f;
+                    T.inv[1] = T.act ? rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf) : 0.f;
+                    T.inv[2] = T.act ? rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf) : 0.f;
+                    T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
 #pragma unroll
                     for (int k = 0; k < 4; k++) T.f[k] = T.act ? W.wall[2 * pr + c][k] : 0.f;   // warm start
                     // a += M^-1 J^T f in pair coordinates
@@ -940,9 +941,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
-                T.inv[r] = rcp(gg + diagc + Rr);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
                 const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
+                T.inv[r] = row_on ? rcp(gg + diagc + Rr) : 0.f;              // (a row that is off: f = 0 and inv = 0 -> its updates are exactly 0)
                 const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
 #pragma unroll
@@ -1057,15 +1058,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float u3 = cal[c].z - aref3 + Rt * T.f[3];
                 const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
                 float nf = fmaxf(T.f[0] - u0 * inv0, 0.f);
-                const float d0 = T.act ? nf - T.f[0] : 0.f;
-                const float d1a = T.act ? -(u1 + B01 * d0) * inv1 : 0.f;
-                const float d2a = T.act ? -(u2 + B02 * d0 + B12 * d1a) * inv2 : 0.f;
-                const float d3a = T.act ? -(u3 + B13 * d1a + B23 * d2a) * inv3 : 0.f;
+                const float d0 = nf - T.f[0];                               // (inactive slot: f = 0, inv = 0 -> every delta is 0)
+                const float d1a = -(u1 + B01 * d0) * inv1;
+                const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv2;
+                const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv3;
                 // elliptic cone: radial projection of the friction part
                 const float fn = T.f[0] + d0;
                 const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
                 const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
                 const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                 T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
                 track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
@@ -1088,7 +1089,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             if (cc_any) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const bool act = cc_act[s];
                     const f3 pos = mk(ccl[(size_t)(s * CC_REC + 0) * CS], ccl[(size_t)(s * CC_REC + 1) * CS], ccl[(size_t)(s * CC_REC + 2) * CS]);
                     const f3 r0 = pos - S.cp[0], r1 = pos - S.cp[1];
                     const float Rn = ccl[(size_t)(s * CC_REC + 15) * CS];
@@ -1113,15 +1113,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float B01 = -iinv * (p00 * p01 + p10 * p11), B02 = -iinv * (p00 * p02 + p10 * p12), B12 = -iinv * (p01 * p02 + p11 * p12);
                     const float B13 = -iinv * (p02 + p12), B23 = iinv * (p01 + p11);   // n.((r0+r1) x t1) = -(r0+r1).t2, n.((r0+r1) x t2) = (r0+r1).t1
                     const float nf = fmaxf(f[0] - u0 * inv[0], 0.f);
-                    const float d0 = act ? nf - f[0] : 0.f;
-                    const float d1a = act ? -(u1 + B01 * d0) * inv[1] : 0.f;
-                    const float d2a = act ? -(u2 + B02 * d0 + B12 * d1a) * inv[2] : 0.f;
-                    const float d3a = act ? -(u3 + B13 * d1a + B23 * d2a) * inv[3] : 0.f;
+                    const float d0 = nf - f[0];
+                    const float d1a = -(u1 + B01 * d0) * inv[1];
+                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv[2];
+                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv[3];
                     // elliptic cone: radial projection of the friction part
                     const float fn = f[0] + d0;
                     const float g1 = f[1] + d1a, g2 = f[2] + d2a, g3 = f[3] + d3a;
                     const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                    const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
                     const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
                     track(d0, d1a, d2a, d3a, fn, f[1] + e1, f[2] + e2, f[3] + e3);
                     ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
@@ -1153,15 +1153,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float B01 = -sg * iinv * r.x * r.y, B02 = -iinv * r.x * r.z, B12 = -sg * iinv * r.y * r.z;
                     const float B13 = -sg * iinv * r.z, B23 = iinv * r.y;
                     const float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
-                    const float d0 = T.act ? nf - T.f[0] : 0.f;
-                    const float d1a = T.act ? -(u1 + B01 * d0) * T.inv[1] : 0.f;
-                    const float d2a = T.act ? -(u2 + B02 * d0 + B12 * d1a) * T.inv[2] : 0.f;
-                    const float d3a = T.act ? -(u3 + B13 * d1a + B23 * d2a) * T.inv[3] : 0.f;
+                    const float d0 = nf - T.f[0];
+                    const float d1a = -(u1 + B01 * d0) * T.inv[1];
+                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
+                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
                     // elliptic cone: radial projection of the friction part
                     const float fn = T.f[0] + d0;
                     const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
                     const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                    const float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
                     const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                     T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
                     track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
@@ -1246,8 +1246,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     float res = gy + jc_a - arefv[r] + Rr * T.f[r];
                     float nf = T.f[r] - res * invv[r];
                     if (r == 0) nf = fmaxf(nf, 0.f);
-                    const bool row_on = T.act && (s != 4 || r < 3 || oncube);
-                    float dlt = row_on ? nf - T.f[r] : 0.f;
+                    float dlt = nf - T.f[r];
                     T.f[r] += dlt;
                     dtr[r] = dlt;
                     {
@@ -1263,7 +1262,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
                     const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
                     float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow == 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
-                    float sc = fn <= 0.f ? 0.f : (s2 > fn * fn ? fn * rsq(s2) : 1.f);
+                    float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
 #pragma unroll
                     for (int r = 1; r < nrow; r++) {
                         float dlt = T.f[r] * sc - T.f[r];
