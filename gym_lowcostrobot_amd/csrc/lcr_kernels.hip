@@ -56,10 +56,14 @@ constexpr float RT_FF = (MU_FINGER * MU_FINGER) / (MU_TORS * MU_TORS);
 constexpr float WALL_X = 0.115f, WALL_Y0 = 0.10f, WALL_Y1 = 0.17f, WALL_TOP = 0.012f;
 constexpr float INVW_DOF[6] = {lcrm::INVW_DOF1, lcrm::INVW_DOF2, lcrm::INVW_DOF3, lcrm::INVW_DOF4, lcrm::INVW_DOF5, lcrm::INVW_DOF6};
 
-// MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi())
+// MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi()): y = 2x^2 for x <= 0.5, 1 - 2(1-x)^2 above.  Branch-free:
+// with t = min(x, 1-x) both halves are 0.5 -/+ (0.5 - 2t^2), the sign being that of x - 0.5 (a divergent if/else costs two
+// exec-mask round trips per call, and there are about ten calls per substep).
 DEV float impedance(float dist, float d0, float dw, float inv_width) {
-    float x = fminf(fabsf(dist) * inv_width, 1.0f);
-    float y = x <= 0.5f ? 2.0f * x * x : 1.0f - 2.0f * (1.0f - x) * (1.0f - x);
+    const float x = fminf(fabsf(dist) * inv_width, 1.0f);
+    const float t = fminf(x, 1.0f - x);
+    const float u = fmaf(-2.0f * t, t, 0.5f);                 // >= 0
+    const float y = 0.5f + copysignf(u, x - 0.5f);
     return fmaf(y, dw - d0, d0);
 }
 
