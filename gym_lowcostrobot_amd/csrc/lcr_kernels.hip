@@ -994,12 +994,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     //      of the wave, at most 50 sweeps ----
     const int max_it = ADAPT ? 50 : P.pgs_iters;
     int sweeps_done = 0;
-    // Quiescent floor rows: when nothing else in this wave acts on a cube (no finger / proxy / cube<->cube / rail contact in any
-    // lane) the floor<->cube rows only talk to themselves.  Once a sweep changes none of their forces by more than 2e-6 of the
-    // largest normal force (warm-started resting or airborne cubes: the update is at the rounding level of fp32), the remaining
-    // sweeps of this substep would repeat that no-op and are skipped for the whole wave.
-    const bool cube_coupled = slot_any[0] || slot_any[1] || (slot_any[4] && __any(link_on_cube)) || cc_any || wall_any;
-    bool floor_quiet = false;
     for (int it = 0; it < max_it; it++) {
         float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep
         auto track = [&](float d0, float d1, float d2, float d3, float f0, float f1, float f2, float f3_) {
@@ -1034,8 +1028,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
         }
         // floor <-> cube
-        if (!floor_quiet) {
-        float fl_chg = 0.f, fl_max = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
 #pragma unroll
@@ -1074,8 +1066,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                 T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
                 track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
-                fl_chg = fmaxf(fmaxf(fl_chg, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
-                fl_max = fmaxf(fl_max, fn);
                 // a += M^-1 J^T delta
                 ca[c].z = fmaf(minv, d0, ca[c].z);
                 ca[c].y = fmaf(minv, d1, ca[c].y);
@@ -1084,8 +1074,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 cal[c].y = fmaf(iinv, -r.x * d0 - r.z * d2, cal[c].y);
                 cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
             }
-        }
-        if (!cube_coupled) floor_quiet = __all(fl_chg <= 2e-6f * fl_max) != 0;
         }
         // cube <-> cube (Stack): block form of the four rows of each contact.  With an orthonormal frame the couplings between
         // the rows need only the projections of the two lever arms on the frame: (r x d_i).(r x d_j) = -(r.d_i)(r.d_j), i != j.
