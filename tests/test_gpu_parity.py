@@ -502,11 +502,11 @@ def test_bench_two_ranks_on_one_gpu(hip_lib):
     assert j["value"] == pytest.approx(8192 * 20 / (j["ms_per_step"] * 20e-3), rel=1e-6) and j["state_finite"]
 
 
-def _states_with_slots(task, bits, n_want, seed, n_try=24000, cube_near_gripper=False):
+def _states_with_slots(task, bits, n_want, seed, n_try=24000, cube_near_gripper=False, action_mode=0):
     """arm configurations (inside the joint-mode target box) whose first control step has the given constraint slots active"""
     from oracle import orc
     rng = np.random.default_rng(seed)
-    o = orc.Oracle(task, n_try, auto_reset=0, max_episode_steps=0)
+    o = orc.Oracle(task, n_try, auto_reset=0, max_episode_steps=0, action_mode=action_mode)
     o.reset(seeds=np.arange(n_try))
     q, qd = util.random_arm_state(rng, n_try, scale_v=1.0)
     o.qpos[:, :6] = q; o.qvel[:, :6] = qd
@@ -526,12 +526,13 @@ def _states_with_slots(task, bits, n_want, seed, n_try=24000, cube_near_gripper=
     return q0[idx], v0[idx]
 
 
-@pytest.mark.parametrize("task,bit,near", [("reach", 16, False), ("push", 16, True), ("lift", 16, True), ("stack", 16, False)])
-def test_link_proxy_contacts(hip_lib, task, bit, near):
-    """arm-link proxies (D3, slot 16): forearm / gripper body on the floor, gripper body against the cube"""
-    qpos, qvel = _states_with_slots(task, [bit], 256, seed=50 + bit, cube_near_gripper=near)
+@pytest.mark.parametrize("task,bit,near,mode", [("reach", 16, False, "joint"), ("push", 16, True, "joint"), ("lift", 16, True, "joint"),
+                                                ("stack", 16, False, "joint"), ("pick_place", 16, True, "ee"), ("push_loop", 16, False, "joint")])
+def test_link_proxy_contacts(hip_lib, task, bit, near, mode):
+    """arm-link proxies (D3, slot 16): forearm / gripper body on the floor, gripper body against the cube; joint and ee action modes"""
+    qpos, qvel = _states_with_slots(task, [bit], 256, seed=50 + bit, cube_near_gripper=near, action_mode={"joint": 0, "ee": 1}[mode])
     n = len(qpos)
-    sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0)
+    sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, action_mode=mode)
     o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
     o.qpos[:] = qpos; o.qvel[:] = qvel
     rng = np.random.default_rng(3)
