@@ -57,7 +57,7 @@ class LcrConfig(ctypes.Structure):
         ("base_seed", ctypes.c_uint64),
         ("pgs_tol", ctypes.c_double),
         ("diagnostics", ctypes.c_int32),
-        ("_pad", ctypes.c_int32),
+        ("finger_cube_condim", ctypes.c_int32),
     ]
 
 

@@ -122,6 +122,9 @@ int lcr_config_default(lcr_config *cfg, int task) {
     cfg->arm_collision = 1;
     cfg->base_seed = 0;
     cfg->pgs_tol = 1e-6;
+    // rolling rows of the finger<->cube contacts: on where the pair's rolling coefficient is not negligible (PushCubeLoop: 1.5 m,
+    // push_cube_loop.xml:31), off where it is MuJoCo's default 1e-4 m (deviation D4, quantified by tools/condim6_effect.py)
+    cfg->finger_cube_condim = task == LCR_TASK_PUSH_LOOP ? 6 : 4;
     cfg->diagnostics = 0;
     return LCR_OK;
 }
@@ -149,6 +152,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->n_envs > (1 << 26)) return fail(LCR_ERR_INVALID, "n_envs %d exceeds 67108864 per handle; shard the batch over several handles", cfg->n_envs);
     if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
     if (cfg->pgs_iters < 0 && !(cfg->pgs_tol > 0)) return fail(LCR_ERR_INVALID, "pgs_tol must be positive in converged mode (pgs_iters < 0)");
+    if (cfg->finger_cube_condim != 0 && cfg->finger_cube_condim != 4 && cfg->finger_cube_condim != 6) return fail(LCR_ERR_INVALID, "finger_cube_condim must be 4 or 6");
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
     int k = lcr_action_dim(cfg);
@@ -204,7 +208,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_goal = off; off += al(sizeof(int) * N);
     size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
-    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * 24 * N);   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
+    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 6 ? 48 : 24) * N);   // (+ its rolling rows)   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
@@ -254,6 +258,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.inv_mu_ct2 = (float)(1.0 / (mut * mut));
         D.rt_fc = (float)(muf * muf / (muft * muft));
         D.inv_mu_fct2 = (float)(1.0 / (muft * muft));
+        const double mur = lcrm::SCENE_CUBE_MU_ROLL[cfg->task], mufr = mur > 0.0001 ? mur : 0.0001;   // rolling: max(cube, finger default 1e-4)
+        D.rr_fc = (float)(muf * muf / (mufr * mufr));
+        D.inv_mu_fcr2 = (float)(1.0 / (mufr * mufr));
+        D.roll = (cfg->finger_cube_condim == 6 || (cfg->finger_cube_condim == 0 && loop)) ? 1 : 0;   // 0 = the task's default
         D.walls = loop ? 1 : 0;
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

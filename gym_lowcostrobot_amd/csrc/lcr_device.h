@@ -53,6 +53,11 @@ struct LcrDev {
     // image observations
     unsigned char *img_front, *img_top;  // [n][240][320][3] or null
     unsigned char *img_bg;               // [2][240][320][3] env-independent background of camera_front / camera_top, or null
+    // (appended: the offsets of everything above are what the tuned default kernels were compiled against)
+    float rr_fc;         // finger<->cube: mu_tan^2 / mu_roll^2   (ROLL kernels: lcr_config.finger_cube_condim = 6)
+    float inv_mu_fcr2;   // finger<->cube: 1 / mu_roll^2
+    int roll;            // 1: finger<->cube slots carry the two rolling rows
+    int _pad1;
 };
 
 // pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height

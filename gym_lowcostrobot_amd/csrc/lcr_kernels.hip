@@ -241,9 +241,10 @@ DEV void store_state(const LcrDev &P, int e, const EnvState<NC> &S) {
 // ------------------------------------------------------------------------------------------------
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+template <int NRW>
 struct ArmSlot {
     f3 n, t1, t2, rc;  // frame and contact point relative to the cube centre (cube slots only)
-    float f[4], aref[4], inv[4];
+    float f[NRW], aref[NRW], inv[NRW];   // rows: normal, two tangents, torsion (NRW = 6: + two rolling rows, finger<->cube slots of the ROLL kernels)
     float Rn;
     bool act;
 };
@@ -253,13 +254,16 @@ struct ArmSlot {
 // arm-coupled contact slots: 0,1 finger sphere 0/1 vs cube; 2,3 finger sphere 0/1 vs floor; 4 the arm-link proxies (D3): one
 // contact, vs floor or (gripper body) cube per lane, 4 rows (the torsion row only on a cube: link<->floor is condim 3)
 constexpr int NAS = 5;
-constexpr int as_rows(int) { return 4; }
-constexpr int as_row0(int s) { return 4 * s; }
+// ROLL kernels (lcr_config.finger_cube_condim = 6): the finger<->cube slots 0, 1 carry MuJoCo's two rolling-friction rows as well
+// (follower.xml:15 condim="6"; deviation D4 is then limited to the finger<->floor contacts)
+template <bool ROLL> constexpr int as_rows(int s) { return (ROLL && s < 2) ? 6 : 4; }
+// first LDS row of a slot (Stack keeps four LDS rows per slot in every variant: its rolling rows live in the global scratch)
+template <bool ROLL, int NC> constexpr int as_row0(int s) { return (ROLL && NC == 1) ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
 constexpr int AS_TOTAL_ROWS = 20;
-template <int NC>
+template <int NC, int NRW>
 struct Warm {
     float floor[NC][4][4];
-    float arm[NAS][4];
+    float arm[NAS][NRW];
     float lim[6];
     float wall[4][4];
     bool cc_prev[4];
@@ -277,7 +281,10 @@ constexpr int LDS_PARK_FLOATS = 4 * 2 * 64 * 4;
 // (16 floats per lane each, 16 KiB: they are read and written by every sweep of the waves that determine the launch time);
 // the four g rows of its arm-link proxy slot live in a coalesced global scratch array instead ([12][N] float2, L1/L2 resident).
 constexpr int LDS_CC_FLOATS = 4 * CC_REC * 64;
-template <int NC, bool WALLS> struct LdsSize { static constexpr int value = NC == 2 ? 16 * LDS_ROW + LDS_CC_FLOATS : LDS_G_FLOATS + LDS_PARK_FLOATS; };
+// ROLL kernels: one cube: 24 g rows (36 KiB), no parking; Stack: the four rolling rows join the proxy slot's rows in the global scratch
+template <int NC, bool WALLS, bool ROLL> struct LdsSize {
+    static constexpr int value = NC == 2 ? 16 * LDS_ROW + LDS_CC_FLOATS : (ROLL ? 24 * LDS_ROW : LDS_G_FLOATS + LDS_PARK_FLOATS);
+};
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 // sphere (centre, radius) vs cube box: signed distance, world normal (box -> sphere) and contact point midway between the surfaces
@@ -323,8 +330,9 @@ DEV void diag_choice(Diag &DG, bool act, int slot, int sel) { DG.choice += act ?
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool WALLS, bool ADAPT>
-DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC> &W, Diag &DGtot, int sub_index) {
+template <int NC, bool WALLS, bool ADAPT, bool ROLL>
+DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
+    constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
     // ---- position stage -------------------------------------------------------------------------
@@ -504,7 +512,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
             T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
             T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
-            if (c == 0 && NC == 1) {
+            if (c == 0 && NC == 1 && !ROLL) {
                 float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                 pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
                 pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
@@ -777,7 +785,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 
     // ---- collision: arm-coupled contact slots (NAS): finger spheres vs cube / floor, arm-link proxies (D3); rows g = L^-1 J^T
     //      go to LDS.  Every slot is skipped wave-uniformly when no lane of the wave touches. ----
-    ArmSlot AS[NAS];
+    ArmSlot<NRW> AS[NAS];
     bool slot_any[NAS];
     bool link_on_cube = false;       // slot 4: this lane's contact is against a cube (else the floor)
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
@@ -790,7 +798,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     for (int s = 0; s < NAS; s++) {
         const int sp = s & 1;
         const bool may_cube = s < 2 || s == 4;   // literal after unrolling
-        ArmSlot &T = AS[s];
+        ArmSlot<NRW> &T = AS[s];
         f3 pos = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 1.f);
         float dist = 1.f;
         int cidx = 0;
@@ -865,7 +873,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
         slot_any[s] = __any(T.act) != 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { T.f[k] = 0.f; T.aref[k] = 0.f; T.inv[k] = 0.f; }
+        for (int k = 0; k < NRW; k++) { T.f[k] = 0.f; T.aref[k] = 0.f; T.inv[k] = 0.f; }
         T.Rn = 1.f; T.n = n; T.t1 = mk(0.f, 1.f, 0.f); T.t2 = mk(-1.f, 0.f, 0.f); T.rc = mk(0.f, 0.f, 0.f);
         if (slot_any[s]) {  // wave-uniform: skip the whole row set-up when no lane of the wave touches
             if (s == 4) {
@@ -912,8 +920,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 if (s == 4 && j >= 3 && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int r = 0; r < as_rows(s); r++) {
-                const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
+            for (int r = 0; r < as_rows<ROLL>(s); r++) {
+                f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));   // row 3: rotation about n (torsion)
+                if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }     // rows 4, 5: rotation about t1, t2 (rolling)
                 float g[6];
                 float vel = 0.f;
 #pragma unroll
@@ -941,9 +950,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int j = 0; j < 6; j++) {
                     gg = fmaf(g[j], g[j], gg);
                     if (NC == 2 && s == 4) P.scratch[((size_t)(r * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
-                    else lds[(as_row0(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j];
+                    else if (NC == 2 && r >= 4) P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
+                    else lds[(as_row0<ROLL, NC>(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j];
                 }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                if (ROLL && r > 3) Rr = Rf * P.rr_fc;
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
                 const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
@@ -1042,7 +1053,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
                 float aref0 = T.aref[0], aref1 = T.aref[1], aref2 = T.aref[2], aref3 = T.aref[3];
                 float inv0 = T.inv[0], inv1 = T.inv[1], inv2 = T.inv[2], inv3 = T.inv[3];
-                if (c == 0 && NC == 1) {
+                if (c == 0 && NC == 1 && !ROLL) {
                     const float4v *pk = reinterpret_cast<const float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                     const float4v a4 = pk[0], i4 = pk[64];
                     aref0 = a4.x; aref1 = a4.y; aref2 = a4.z; aref3 = a4.w;
@@ -1171,22 +1182,26 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
             for (int s = 0; s < NAS; s++) {
                 if (!slot_any[s]) continue;
-                ArmSlot &T = AS[s];
+                ArmSlot<NRW> &T = AS[s];
                 const bool may_cube = s < 2 || s == 4;
                 const bool oncube = s < 2 || (s == 4 && link_on_cube);
-                const int nrow = as_rows(s);
+                constexpr bool roll = ROLL;
+                const int nrow = (roll && s < 2) ? 6 : 4;
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
                 // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
-                float2v g[4][3];
+                float2v g[NRW][3];
 #pragma unroll
                 for (int r = 0; r < nrow; r++)
 #pragma unroll
                     for (int k = 0; k < 3; k++)
                         g[r][k] = (NC == 2 && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
-                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                                  : (NC == 2 && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
+                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
                 float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
-                const float arefv[4] = {T.aref[0], T.aref[1], T.aref[2], T.aref[3]}, invv[4] = {T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
+                float arefv[NRW], invv[NRW], f_in[NRW];
+#pragma unroll
+                for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; f_in[r] = T.f[r]; }
                 // pick the cube this slot talks to (wave-divergent only for Stack)
                 f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
                 const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
@@ -1198,13 +1213,14 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // couplings, because (rc x d_i).(rc x d_j) = |rc|^2 delta_ij - (rc.d_i)(rc.d_j) for the orthonormal frame:
                 //   v_i -= dlt (k delta_ij - iinv p_i p_j), k = minv + iinv |rc|^2, p_i = rc . d_i;   wn -= iinv dlt n.(rc x d_j)
                 // and the summed force is applied to the cube once at the end of the slot.
-                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f;
-                float f_in[4] = {T.f[0], T.f[1], T.f[2], T.f[3]};
+                // (ROLL: the rolling rows need the angular acceleration about t1 and t2 as well: wq = (n, t1, t2) . alpha, wn = wq[0])
+                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f, w1 = 0.f, w2 = 0.f;
                 if (may_cube) {
                     const f3 Ac = a_lin + cross(a_ang, T.rc);
                     vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
                     pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
                     wn = dot(T.n, a_ang);
+                    if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
                     kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
                     if (s == 4) {   // floor lanes: no cube share in the residuals
 #pragma unroll
@@ -1222,19 +1238,35 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         // n.(rc x t1) = -rc.t2, n.(rc x t2) = rc.t1, n.(rc x n) = 0
                         if (j == 1) wn = fmaf(iinv_e * dlt, pq[2], wn);
                         if (j == 2) wn = fmaf(-iinv_e * dlt, pq[1], wn);
-                    } else {   // torsion: angular acceleration changes by -iinv dlt n; contact point by (-iinv dlt n) x rc
+                        if (nrow == 6) {   // d_i . (rc x d_j) = rc . (d_j x d_i), right-handed frame n x t1 = t2, t1 x t2 = n, t2 x n = t1
+                            if (j == 0) { w1 = fmaf(-iinv_e * dlt, pq[2], w1); w2 = fmaf(iinv_e * dlt, pq[1], w2); }
+                            if (j == 1) w2 = fmaf(-iinv_e * dlt, pq[0], w2);
+                            if (j == 2) w1 = fmaf(iinv_e * dlt, pq[0], w1);
+                        }
+                    } else if (j == 3) {   // torsion: angular acceleration changes by -iinv dlt n; contact point by (-iinv dlt n) x rc
                         wn = fmaf(-iinv_e, dlt, wn);
                         vq[1] = fmaf(iinv_e * dlt, pq[2], vq[1]);    // t1.(n x rc) = -p_2
                         vq[2] = fmaf(-iinv_e * dlt, pq[1], vq[2]);   // t2.(n x rc) =  p_1
+                    } else if (j == 4) {   // rolling about t1: alpha -= iinv dlt t1; point acceleration += (-iinv dlt t1) x rc
+                        w1 = fmaf(-iinv_e, dlt, w1);
+                        vq[0] = fmaf(-iinv_e * dlt, pq[2], vq[0]);   // n.(t1 x rc)  =  p_2
+                        vq[2] = fmaf(iinv_e * dlt, pq[0], vq[2]);    // t2.(t1 x rc) = -p_0
+                    } else {               // rolling about t2
+                        w2 = fmaf(-iinv_e, dlt, w2);
+                        vq[0] = fmaf(iinv_e * dlt, pq[1], vq[0]);    // n.(t2 x rc)  = -p_1
+                        vq[1] = fmaf(-iinv_e * dlt, pq[0], vq[1]);   // t1.(t2 x rc) =  p_0
                     }
                 };
-                float dtr[4] = {0.f, 0.f, 0.f, 0.f};
+                float dtr[NRW];
+#pragma unroll
+                for (int r = 0; r < NRW; r++) dtr[r] = 0.f;
 #pragma unroll
                 for (int r = 0; r < nrow; r++) {
                     const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
                     const float gy = acc.x + acc.y;
-                    const float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
-                    const float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
                     float res = gy + jc_a - arefv[r] + Rr * T.f[r];
                     float nf = T.f[r] - res * invv[r];
                     if (r == 0) nf = fmaxf(nf, 0.f);
@@ -1253,7 +1285,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     float fn = T.f[0];
                     const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
                     const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
-                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow == 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
+                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow >= 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
+                    if constexpr (ROLL) { if (nrow == 6) s2 = fmaf(T.f[4] * T.f[4] + T.f[5] * T.f[5], P.inv_mu_fcr2, s2); }
                     float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
 #pragma unroll
                     for (int r = 1; r < nrow; r++) {
@@ -1266,12 +1299,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     }
                 }
                 track(dtr[0], dtr[1], dtr[2], dtr[3], T.f[0], T.f[1], T.f[2], T.f[3]);
+                if constexpr (ROLL) { if (nrow == 6) track(dtr[4], dtr[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
                 f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
                 if (may_cube) {
                     const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
                     const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
                     dl_lin = (-minv_e) * Fd;
-                    dl_ang = (-iinv_e) * axpy(e3, T.n, cross(T.rc, Fd));
+                    f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
+                    if constexpr (ROLL) { if (nrow == 6) Td = axpy(T.f[4] - f_in[4], T.t1, axpy(T.f[5] - f_in[5], T.t2, Td)); }
+                    dl_ang = (-iinv_e) * Td;
                 }
                 y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
                 if (may_cube) {
@@ -1298,7 +1334,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
     for (int s = 0; s < NAS; s++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) W.arm[s][k] = AS[s].f[k];
+        for (int k = 0; k < NRW; k++) W.arm[s][k] = AS[s].f[k];
 #pragma unroll
     for (int s = 0; s < 4; s++) W.cc_prev[s] = cc_act[s];
     if (P.diag) {   // wave-uniform
@@ -1445,9 +1481,9 @@ DEV void write_obs18(const LcrDev &P, float *dst, int e, const EnvState<NC> &S, 
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool WALLS, bool ADAPT>
+template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[LdsSize<NC, WALLS>::value];
+    __shared__ float lds[LdsSize<NC, WALLS, ROLL>::value];
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -1536,7 +1572,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     f3 lag_cube[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) lag_cube[c] = S.cp[c];
-    Warm<NC> W;
+    Warm<NC, ROLL ? 6 : 4> W;
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -1546,7 +1582,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
     for (int s = 0; s < NAS; s++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) W.arm[s][k] = 0.f;
+        for (int k = 0; k < (ROLL ? 6 : 4); k++) W.arm[s][k] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; s++) W.cc_prev[s] = false;
 #pragma unroll
@@ -1556,7 +1592,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
         for (int k = 0; k < 4; k++) W.wall[s][k] = 0.f;
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
@@ -1725,20 +1761,26 @@ static int check_launch() {
     return err == hipSuccess ? 0 : (int)err;
 }
 
-template <bool ADAPT>
+template <bool ADAPT, bool ROLL>
 static void launch_step_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
     const bool stack = P.task == 4;
-    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
 }
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
-    if (P.pgs_iters < 0) launch_step_t<true>(P, action_dev, ee_mode, (hipStream_t)stream);   // converged mode
-    else launch_step_t<false>(P, action_dev, ee_mode, (hipStream_t)stream);
+    const hipStream_t st = (hipStream_t)stream;
+    if (P.pgs_iters < 0) {   // converged mode
+        if (P.roll) launch_step_t<true, true>(P, action_dev, ee_mode, st);
+        else launch_step_t<true, false>(P, action_dev, ee_mode, st);
+    } else {
+        if (P.roll) launch_step_t<false, true>(P, action_dev, ee_mode, st);   // finger<->cube contacts with rolling rows (condim 6)
+        else launch_step_t<false, false>(P, action_dev, ee_mode, st);
+    }
     return check_launch();
 }
 

@@ -71,6 +71,7 @@ class VecSim:
         arm_collision=True,
         pgs_tol=1e-6,
         diagnostics=False,
+        finger_cube_condim=None,
     ):
         self.L = _capi.load()
         if action_mode not in ACTION_MODES:
@@ -104,6 +105,8 @@ class VecSim:
         cfg.arm_collision = int(bool(arm_collision))
         cfg.pgs_tol = float(pgs_tol)
         cfg.diagnostics = int(bool(diagnostics))
+        if finger_cube_condim is not None:   # default: lcr_config_default's choice for the task (6 for PushCubeLoop, else 4)
+            cfg.finger_cube_condim = int(finger_cube_condim)
         self.cfg = cfg
         self.n = int(n_envs)
         self.device = int(device)

@@ -87,7 +87,10 @@ typedef struct lcr_config {
     uint64_t base_seed;        /* envs never explicitly seeded use SeedSequence(base_seed + global env id) */
     double pgs_tol;            /* 1e-6; used when pgs_iters < 0 */
     int32_t diagnostics;       /* 1: lcr_out_view.active_mask / active_count / max_sweeps are written by every step */
-    int32_t _pad;
+    int32_t finger_cube_condim; /* rows of a finger<->cube contact.  6 = MuJoCo's: normal, two tangents, torsion, two rolling (follower.xml:15
+                                  condim="6" wins the max rule over the cube's 4; rolling coefficient = max of both geoms).  4 = without the
+                                  rolling rows (8-12 % faster).  lcr_config_default: 6 for PushCubeLoop (coefficient 1.5), 4 for the other
+                                  tasks (MuJoCo's default 1e-4: deviation D4).  0 = the task's default */
 } lcr_config;
 
 typedef struct lcr_sim lcr_sim;

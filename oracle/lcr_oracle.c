@@ -109,7 +109,7 @@ static const int LPX_GROUP[NLPX] = {0, 0, 0, 0, 0};
 static const int LPX_CUBE[NLPX] = {0, 0, 0, 1, 1};
 /* link geoms: MuJoCo geom defaults friction (1, 0.005, 0.0001), condim 3, priority 0.  vs floor (priority 0, friction 0.1):
  * max rule -> mu 1, condim 3, default solref/solimp.  vs cube (priority 1): the cube's condim 4, friction, solimp win (P9). */
-static const double MU_LINK_FLOOR[3] = {1.0, 1.0, 0.005};
+static const double MU_LINK_FLOOR[5] = {1.0, 1.0, 0.005, 0.0001, 0.0001};
 
 /* default solver parameters (MJ-DOC XML reference): solref=(0.02,1) solimp=(0.9,0.95,0.001,0.5,2) */
 static const double SOLREF[2] = {0.02, 1.0};
@@ -118,11 +118,11 @@ static const double SOLIMP_DEFAULT[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
 static const double SOLIMP_FINGER[5] = {0.015, 1.0, 0.036, 0.5, 2.0};
 /* P9: cube (priority 1) vs finger (priority 1): equal priority -> solimp averaged (solmix 1:1), friction max */
 static const double SOLIMP_FINGER_CUBE[5] = {0.4575, 0.975, 0.0185, 0.5, 2.0};
-static const double MU_CUBE[3] = {0.5, 0.5, 0.005};   /* reach_cube.xml:26 friction="0.5" (+default torsional) */
-static const double MU_FINGER[3] = {1.5, 1.5, 0.005}; /* follower.xml:15 friction="1.5" */
+static const double MU_CUBE[5] = {0.5, 0.5, 0.005, 0.0001, 0.0001};   /* reach_cube.xml:26 friction="0.5" (+default torsional, rolling) */
+static const double MU_FINGER[5] = {1.5, 1.5, 0.005, 0.0001, 0.0001}; /* follower.xml:15 friction="1.5"; entries 3, 4 (rolling) only with condim6 */
 /* push_cube_loop.xml:31 cube friction="1.5 1.5 1.5" (tangential, torsional, rolling), priority 1: used against the floor
  * and the walls (priority 0) and, by the max rule, against the fingers (priority 1) */
-static const double MU_LOOP[3] = {1.5, 1.5, 1.5};
+static const double MU_LOOP[5] = {1.5, 1.5, 1.5, 1.5, 1.5};   /* push_cube_loop.xml:31 friction="1.5 1.5 1.5" */
 /* push_cube_loop.xml:44-47 rails: inner faces of the four wall boxes, top of the walls */
 #define WALL_X 0.115
 #define WALL_Y0 0.10
@@ -424,16 +424,16 @@ static void make_frame(real *fr /*[9]*/, const real *n) {
 typedef struct {
     int b1, b2;       /* body ids: -1 world, 0..5 arm link, 6,7 cubes; frame normal points b1 -> b2 */
     real pos[3], frame[9], dist;
-    const double *mu; /* [3] tan, tan, torsional */
+    const double *mu; /* [5] tan, tan, torsional, rolling, rolling */
     const double *solimp;
     int slot; /* warm-start slot id: 0-3 floor-cube0, 4-7 floor-cube1, 8-11 cube-cube / rails, 12-13 sphere-cube, 14-15 sphere-floor,
                  16 arm-link proxies */
-    int dim;  /* rows: 3 (n, t1, t2) or 4 (+ torsion) */
+    int dim;  /* rows: 3 (n, t1, t2), 4 (+ torsion) or 6 (+ rolling about t1, t2: only with orc_params.condim6, D4) */
     int sel;  /* discrete choice behind this contact (which vertex / candidate / face / member): diagnostics, see lag_t.choice */
 } contact_t;
 
 #define MAX_CONTACTS (8 + 8 + ORC_MAX_ARM_CONTACTS + NLGRP)
-#define MAX_ROWS (12 + 4 * MAX_CONTACTS)
+#define MAX_ROWS (12 + 6 * MAX_CONTACTS)
 #define ORC_PGS_CAP 50
 
 /* plane z=0 (geom1, world) vs box (geom2): MJ-DOC mjc_PlaneBox -- vertex i=(+-,+-,+-) by bits 0,1,2;
@@ -787,7 +787,7 @@ typedef struct {
 } lag_t;
 /* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
  * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
-typedef struct { real lim[12]; real slot[18][4]; } warm_t;
+typedef struct { real lim[12]; real slot[18][6]; } warm_t;
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
                     warm_t *warm, int diag, int sub_index) {
@@ -896,6 +896,9 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         }
     for (int ci = 0; ci < ncon; ci++) {
         contact_t *ct = &con[ci];
+        /* finger geoms: follower.xml:15 condim="6" wins the max rule.  condim6 = 1: finger<->cube contacts get the two rolling rows
+         * (the kernel's finger_cube_condim = 6); 2: finger<->floor contacts as well (study of deviation D4 only) */
+        if ((P->condim6 >= 1 && (ct->slot == 12 || ct->slot == 13)) || (P->condim6 >= 2 && (ct->slot == 14 || ct->slot == 15))) ct->dim = 6;
         real Jp1[3 * ORC_NV_MAX], Jr1[3 * ORC_NV_MAX], Jp2[3 * ORC_NV_MAX], Jr2[3 * ORC_NV_MAX];
         jac_point(&K, nv, ct->b1, ct->pos, Jp1, Jr1);
         jac_point(&K, nv, ct->b2, ct->pos, Jp2, Jr2);
@@ -911,7 +914,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         choice += (uint32_t)(ct->slot + 1) * (uint32_t)(ct->sel + 1) * 2654435761u;
         for (int r = 0; r < ct->dim; r++) {
             real *Jrow = J + (size_t)(nr + r) * nv;
-            const real *fr = ct->frame + 3 * (r < 3 ? r : 0);
+            const real *fr = ct->frame + 3 * (r < 3 ? r : (r == 3 ? 0 : r - 3)); /* rows 4, 5: rotation about t1, t2 */
             for (int d = 0; d < nv; d++) {
                 real s = 0;
                 if (r < 3) for (int k3 = 0; k3 < 3; k3++) s += fr[k3] * (Jp2[k3 * nv + d] - Jp1[k3 * nv + d]);
@@ -1054,6 +1057,7 @@ void orc_default_params(orc_params *p, int task) {
     p->warm_start = 1;
     p->arm_collision = 1;
     p->pgs_tol = 1e-6;
+    p->condim6 = task == ORC_TASK_PUSH_LOOP ? 1 : 0; /* as lcr_config_default: rolling rows where the coefficient is 1.5, not where it is 1e-4 */
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
 int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }

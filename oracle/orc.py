@@ -34,6 +34,8 @@ class OrcParams(ctypes.Structure):
         ("warm_start", ctypes.c_int32),
         ("arm_collision", ctypes.c_int32),
         ("pgs_tol", ctypes.c_double),
+        ("condim6", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
     ]
 
 

@@ -36,6 +36,7 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.distance_threshold == 0.05 and cfg.cube_xy_range == 0.3 and cfg.n_substeps == 20
         assert cfg.max_episode_steps == 50                        # gym_lowcostrobot/__init__.py:12
         assert cfg.impratio == 100.0
+        assert cfg.finger_cube_condim == (6 if task == "push_loop" else 4)   # rolling rows where the coefficient is 1.5 (push_cube_loop.xml:31)
         k = hip_lib.lcr_action_dim(ctypes.byref(cfg))
         assert k == (5 if task in ("reach", "push", "push_loop") else 6)  # block_gripper defaults reach:82 / lift:82
         cfg.action_mode = _capi.ACTION_MODES["ee"]
@@ -59,6 +60,10 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
     cfg.n_envs = (1 << 26) + 1
     assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
     assert b"shard" in hip_lib.lcr_last_error()
+    hip_lib.lcr_config_default(ctypes.byref(cfg), 0)
+    cfg.finger_cube_condim = 5
+    assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
+    assert b"finger_cube_condim" in hip_lib.lcr_last_error()
     hip_lib.lcr_config_default(ctypes.byref(cfg), 0)
     cfg.action_mode = 7
     assert hip_lib.lcr_action_dim(ctypes.byref(cfg)) == _capi.LCR_ERR_INVALID

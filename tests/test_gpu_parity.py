@@ -352,6 +352,41 @@ def test_pinch_grasp_finger_cube_contacts(hip_lib, task):
     sim.close()
 
 
+@pytest.mark.parametrize("task", ["lift", "stack", "push_loop", "pick_place"])
+def test_rolling_rows_finger_cube_condim6(hip_lib, task):
+    """finger_cube_condim = 6: the finger<->cube slots carry MuJoCo's two rolling-friction rows (follower.xml:15 condim="6"; rolling
+    coefficient 1e-4, PushCubeLoop 1.5); pinched cube (both slots active in every env) and a free rollout, kernel vs oracle(condim6=1)"""
+    rng = np.random.default_rng(77)
+    n = 256
+    sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, finger_cube_condim=6)
+    o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+    util.pinch_setup(o)
+    o.qpos[:, 6:9] += rng.normal(0, 3e-4, (n, 3))
+    o.qpos[:, 5] += rng.uniform(-0.02, 0.02, n)
+    o.qvel[:, :6] = rng.normal(0, 0.1, (n, 6))
+    o.qvel[:, 9:12] = rng.normal(0, 0.5, (n, 3))   # the cube spins against the fingers: the rolling rows have work to do
+    k = sim.action_dim
+    for t in range(6):
+        a = rng.uniform(-0.1, 0.1, (n, k)).astype(np.float32)
+        if k == 6:
+            a[:, 5] = 0.2
+        # (PushCubeLoop: torsional and rolling coefficients 1.5 make the pinched cube a stiff 12-row problem: twice the position tolerance)
+        dq, dv, ok, st = util.parity_step(sim, o, a, 4e-5 if task == "push_loop" else 2e-5, 4e-3, where=("roll", task, t))
+        assert ok.mean() >= (0.9 if task == "push_loop" else 0.97), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])   # (every outlier is explained: parity_step)
+        assert ((o.active_mask >> 12) & 3).astype(bool).mean() > 0.5 or t > 2   # finger<->cube slots really are active
+    # the rolling rows change the result (else the test would not see them): same state, kernel without them
+    sim4, o4 = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, finger_cube_condim=4)
+    for name in ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time"):
+        getattr(o4, name)[...] = getattr(o, name)
+    util.push_state(sim4, o4); util.push_state(sim, o)
+    a = np.zeros((n, k), np.float32)
+    sim.step(a); sim4.step(a)
+    d = np.abs(util.pull_state(sim)["qvel"] - util.pull_state(sim4)["qvel"]).max(axis=1)
+    print("rolling rows effect", task, "median", np.median(d), "p90", np.percentile(d, 90), "max", d.max())
+    assert np.percentile(d, 90) > (1e-2 if task == "push_loop" else 1e-5), (np.median(d), np.percentile(d, 90))
+    sim.close(); sim4.close()
+
+
 def test_divergence_guard(hip_lib):
     """a poisoned state (NaN / inf / huge) ends the episode as truncated and the env restarts clean, others untouched"""
     n = 128

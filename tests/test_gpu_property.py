@@ -1,5 +1,7 @@
-"""Property-based GPU parity (hypothesis): random task / action mode / reward type / solver settings / thresholds / batch
+"""Property-based GPU parity (hypothesis): random task / action mode / reward type / solver settings / contact rows / thresholds / batch
 size / seeds -- the HIP kernel must track the oracle under every configuration, not only the defaults."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -12,7 +14,8 @@ pytestmark = pytest.mark.gpu
 TASKS = ["reach", "lift", "push", "pick_place", "stack", "push_loop"]
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=int(os.environ.get("LCR_HYP_EXAMPLES", "25")),   # (soak runs: LCR_HYP_EXAMPLES=800)
+           deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(
     task=st.sampled_from(TASKS),
     mode=st.sampled_from(["joint", "ee"]),
@@ -22,11 +25,12 @@ TASKS = ["reach", "lift", "push", "pick_place", "stack", "push_loop"]
     pgs_iters=st.integers(min_value=1, max_value=8),
     impratio=st.sampled_from([1.0, 10.0, 100.0]),
     thr=st.floats(min_value=0.02, max_value=0.2),
+    condim=st.sampled_from([None, 4, 6]),
     seed=st.integers(min_value=0, max_value=2**40),
 )
-def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, seed):
+def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, seed):
     kw = dict(action_mode=mode, reward_type=reward, n_substeps=n_substeps, pgs_iters=pgs_iters, impratio=impratio,
-              distance_threshold=thr, auto_reset=False, max_episode_steps=0)
+              distance_threshold=thr, auto_reset=False, max_episode_steps=0, finger_cube_condim=condim)
     sim, o = util.make_pair(task, n, **kw)
     rng = np.random.default_rng(seed % (2**32))
     seeds = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(seed)) % np.uint64(2**63)

@@ -549,3 +549,25 @@ def test_render_oracle_places_the_scene_by_the_pinhole_model():
     a = ro.render("push", q, [0.0, 0.1, 0.005], "camera_top").astype(int)
     b = ro.render("push", q, [0.1, 0.25, 0.005], "camera_top").astype(int)
     assert (np.abs(a - b).max(-1) > 10).mean() > 0.005
+
+
+def test_rolling_rows_of_the_finger_cube_contacts():
+    """condim6 (the kernel's finger_cube_condim = 6): the two rolling rows oppose the relative rotation of finger and cube about the
+    contact tangents.  A pinched cube is given a spin about its z axis; the tangential friction at the two off-centre contact points
+    turns part of it into tumbling about y.  PushCubeLoop (rolling coefficient 1.5 m: effectively a rotational lock to the fingers)
+    -> no tumbling; with the default coefficient 1e-4 m (Lift) the rows are there but hardly matter."""
+    from tests import util
+    n = 8
+    res = {}
+    for task in ("push_loop", "lift"):
+        for c6 in (0, 1):
+            o = orc.Oracle(task, n, auto_reset=0, max_episode_steps=0, condim6=c6, n_substeps=5)
+            o.reset(seeds=np.arange(n))
+            util.pinch_setup(o)
+            o.qvel[:, 9:12] = np.array([0.0, 0.0, 3.0])
+            o.step(np.zeros((n, o.action_dim), np.float32), threads=0)
+            assert ((o.active_mask >> 12) & 3 == 3).all()
+            res[task, c6] = o.qvel[:, 9:12].copy()
+    assert np.abs(res["push_loop", 0][:, 1]).min() > 0.3 and np.abs(res["push_loop", 1][:, 1]).max() < 0.02, (res["push_loop", 0][0], res["push_loop", 1][0])
+    assert np.abs(res["lift", 1] - res["lift", 0]).max() < 1e-2 * np.abs(res["lift", 0]).max()
+    assert orc.Oracle("push_loop", 1).params.condim6 == 1 and orc.Oracle("lift", 1).params.condim6 == 0   # defaults by task

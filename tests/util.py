@@ -48,6 +48,8 @@ def make_pair(task, n, **kw):
             if k == "reward_type":
                 v = {"sparse": 0, "dense": 1}[v]
             okw[k] = int(v) if isinstance(v, bool) else v
+    if kw.get("finger_cube_condim") is not None:
+        okw["condim6"] = 1 if kw["finger_cube_condim"] == 6 else 0   # rolling rows on the finger<->cube contacts (default: by task, both sides)
     o = orc.Oracle(task, n, **okw)
     kw.setdefault("diagnostics", True)
     sim = VecSim(task, n, observation_mode="state", **kw)

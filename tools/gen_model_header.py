@@ -35,12 +35,12 @@ SCENE_OF_TASK = ["reach_cube", "lift_cube", "push_cube", "pick_place_cube", "sta
 
 
 def scene_cube(task):
-    """(mass, inertia, (mu_tan, mu_tors)) of the (first) cube of a scene; geom friction defaults (1, 0.005, 0.0001) (MJ-DOC)"""
+    """(mass, inertia, (mu_tan, mu_tors, mu_roll), half size) of the (first) cube of a scene; geom friction defaults (1, 0.005, 0.0001) (MJ-DOC)"""
     b = [x for x in _G["scenes"][SCENE_OF_TASK[task]]["bodies"] if x["joints"] and x["joints"][0].get("type") == "free"][0]
     fr = b["geoms"][0].get("friction", 1.0)
     fr = list(fr) if isinstance(fr, list) else [fr]
     fr = fr + [1.0, 0.005, 0.0001][len(fr):]
-    return b["inertial"]["mass"], b["inertial"]["diaginertia"][0], (fr[0], fr[1]), b["geoms"][0]["size"][0]
+    return b["inertial"]["mass"], b["inertial"]["diaginertia"][0], (fr[0], fr[1], fr[2]), b["geoms"][0]["size"][0]
 
 
 # finger proxies (deviation D3): one sphere per finger geom, fitted to the tip of the fixed finger of the
@@ -170,6 +170,7 @@ def main():
     L.append("constexpr double SCENE_CUBE_INERTIA[6] = {" + ", ".join(repr(float(c[1])) for c in cubes) + "};")
     L.append("constexpr double SCENE_CUBE_MU[6] = {" + ", ".join(repr(float(c[2][0])) for c in cubes) + "};")
     L.append("constexpr double SCENE_CUBE_MU_TORS[6] = {" + ", ".join(repr(float(c[2][1])) for c in cubes) + "};")
+    L.append("constexpr double SCENE_CUBE_MU_ROLL[6] = {" + ", ".join(repr(float(c[2][2])) for c in cubes) + "};")
     L.append(f"constexpr float CUBE_HALF = {f(cubes[0][3])};")
     L.append("}  // namespace lcrm")
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gym_lowcostrobot_amd", "csrc", "lcr_model_gen.h")
