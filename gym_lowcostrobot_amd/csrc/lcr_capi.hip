@@ -122,9 +122,10 @@ int lcr_config_default(lcr_config *cfg, int task) {
     cfg->arm_collision = 1;
     cfg->base_seed = 0;
     cfg->pgs_tol = 1e-6;
-    // rolling rows of the finger<->cube contacts: on where the pair's rolling coefficient is not negligible (PushCubeLoop: 1.5 m,
-    // push_cube_loop.xml:31), off where it is MuJoCo's default 1e-4 m (deviation D4, quantified by tools/condim6_effect.py)
-    cfg->finger_cube_condim = task == LCR_TASK_PUSH_LOOP ? 6 : 4;
+    // rolling rows of the finger<->cube contacts: on where their effect on a touched cube within one control step exceeds the fp32
+    // parity tolerance in the median (tools/condim6_effect.py: PushCubeLoop 1.4e-2 -- rolling coefficient 1.5 m, push_cube_loop.xml:31;
+    // StackTwoCubes 4e-4 -- default coefficient 1e-4 m but cube inertia 1.1e-5), off where it does not (<= 4e-5: deviation D4)
+    cfg->finger_cube_condim = (task == LCR_TASK_PUSH_LOOP || task == LCR_TASK_STACK) ? 6 : 4;
     cfg->diagnostics = 0;
     return LCR_OK;
 }
@@ -208,7 +209,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_goal = off; off += al(sizeof(int) * N);
     size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
-    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 6 ? 48 : 24) * N);   // (+ its rolling rows)   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
+    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 4 ? 24 : 48) * N);   // (+ the rolling rows of the finger slots)   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
@@ -261,7 +262,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         const double mur = lcrm::SCENE_CUBE_MU_ROLL[cfg->task], mufr = mur > 0.0001 ? mur : 0.0001;   // rolling: max(cube, finger default 1e-4)
         D.rr_fc = (float)(muf * muf / (mufr * mufr));
         D.inv_mu_fcr2 = (float)(1.0 / (mufr * mufr));
-        D.roll = (cfg->finger_cube_condim == 6 || (cfg->finger_cube_condim == 0 && loop)) ? 1 : 0;   // 0 = the task's default
+        const bool roll_default = loop || cfg->task == LCR_TASK_STACK;
+        D.roll = (cfg->finger_cube_condim == 6 || (cfg->finger_cube_condim == 0 && roll_default)) ? 1 : 0;   // 0 = the task's default
         D.walls = loop ? 1 : 0;
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

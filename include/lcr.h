@@ -89,8 +89,9 @@ typedef struct lcr_config {
     int32_t diagnostics;       /* 1: lcr_out_view.active_mask / active_count / max_sweeps are written by every step */
     int32_t finger_cube_condim; /* rows of a finger<->cube contact.  6 = MuJoCo's: normal, two tangents, torsion, two rolling (follower.xml:15
                                   condim="6" wins the max rule over the cube's 4; rolling coefficient = max of both geoms).  4 = without the
-                                  rolling rows (8-12 % faster).  lcr_config_default: 6 for PushCubeLoop (coefficient 1.5), 4 for the other
-                                  tasks (MuJoCo's default 1e-4: deviation D4).  0 = the task's default */
+                                  rolling rows (8-12 % faster).  lcr_config_default: 6 for PushCubeLoop (coefficient 1.5 m) and
+                                  StackTwoCubes (light cubes), 4 for the other tasks (effect below the parity tolerance: deviation D4,
+                                  DESIGN.md).  0 = the task's default */
 } lcr_config;
 
 typedef struct lcr_sim lcr_sim;

@@ -1057,7 +1057,7 @@ void orc_default_params(orc_params *p, int task) {
     p->warm_start = 1;
     p->arm_collision = 1;
     p->pgs_tol = 1e-6;
-    p->condim6 = task == ORC_TASK_PUSH_LOOP ? 1 : 0; /* as lcr_config_default: rolling rows where the coefficient is 1.5, not where it is 1e-4 */
+    p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
 int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }

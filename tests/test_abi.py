@@ -36,7 +36,7 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.distance_threshold == 0.05 and cfg.cube_xy_range == 0.3 and cfg.n_substeps == 20
         assert cfg.max_episode_steps == 50                        # gym_lowcostrobot/__init__.py:12
         assert cfg.impratio == 100.0
-        assert cfg.finger_cube_condim == (6 if task == "push_loop" else 4)   # rolling rows where the coefficient is 1.5 (push_cube_loop.xml:31)
+        assert cfg.finger_cube_condim == (6 if task in ("push_loop", "stack") else 4)   # rolling rows where they matter
         k = hip_lib.lcr_action_dim(ctypes.byref(cfg))
         assert k == (5 if task in ("reach", "push", "push_loop") else 6)  # block_gripper defaults reach:82 / lift:82
         cfg.action_mode = _capi.ACTION_MODES["ee"]

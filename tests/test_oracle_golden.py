@@ -570,4 +570,4 @@ def test_rolling_rows_of_the_finger_cube_contacts():
             res[task, c6] = o.qvel[:, 9:12].copy()
     assert np.abs(res["push_loop", 0][:, 1]).min() > 0.3 and np.abs(res["push_loop", 1][:, 1]).max() < 0.02, (res["push_loop", 0][0], res["push_loop", 1][0])
     assert np.abs(res["lift", 1] - res["lift", 0]).max() < 1e-2 * np.abs(res["lift", 0]).max()
-    assert orc.Oracle("push_loop", 1).params.condim6 == 1 and orc.Oracle("lift", 1).params.condim6 == 0   # defaults by task
+    assert [orc.Oracle(t, 1).params.condim6 for t in ("reach", "lift", "push", "pick_place", "stack", "push_loop")] == [0, 0, 0, 0, 1, 1]   # defaults by task
