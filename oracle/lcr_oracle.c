@@ -243,6 +243,7 @@ typedef struct {
     int ncube;
     real cR[2][9], cp[2][3];
     const double *mu_cube, *mu_finger_cube;
+    int cc_points;    /* cube<->cube manifold: 4 (default) or 8 points (study of deviation D5) */
 } kin_t;
 
 static void arm_kinematics(const real *q, kin_t *K) {
@@ -652,14 +653,15 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
         v3sub(d, V[i], K->cp[A]);
         Vu[i] = v3dot(d, u); Vv[i] = v3dot(d, v); Vd[i] = v3dot(d, m) - h;
     }
-    /* selection state: 4 diagonal-extreme slots */
-    real spos[4][3], sdist[4], skey[4];
-    int sidx[4] = {-1, -1, -1, -1};
+    /* selection state: 4 diagonal-extreme slots (+ 4 axis-extreme slots when cc_points == 8: study of D5) */
+    const int nsel = K->cc_points == 8 ? 8 : 4;
+    real spos[8][3], sdist[8], skey[8];
+    int sidx[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     int cand = 0;
 #define CONSIDER(PX, PY, PZ, DIST, CU, CV)                                                        \
     do {                                                                                          \
-        real key_[4] = {(CU) + (CV), -(CU) + (CV), -(CU) - (CV), (CU) - (CV)};                     \
-        for (int s_ = 0; s_ < 4; s_++)                                                            \
+        real key_[8] = {(CU) + (CV), -(CU) + (CV), -(CU) - (CV), (CU) - (CV), (CU), (CV), -(CU), -(CV)}; \
+        for (int s_ = 0; s_ < nsel; s_++)                                                         \
             if (sidx[s_] < 0 || key_[s_] > skey[s_]) {                                            \
                 skey[s_] = key_[s_]; sidx[s_] = cand; sdist[s_] = (DIST);                          \
                 spos[s_][0] = (PX); spos[s_][1] = (PY); spos[s_][2] = (PZ);                        \
@@ -706,13 +708,13 @@ static int collide_box_box(const kin_t *K, contact_t *out) {
     }
 #undef CONSIDER
     int cnt = 0;
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < nsel; s++) {
         if (sidx[s] < 0) continue;
         int dup = 0;
         for (int s2 = 0; s2 < s; s2++) if (sidx[s2] == sidx[s]) dup = 1;
         if (dup) continue;
         contact_t *ct = &out[cnt];
-        ct->slot = 8 + s;
+        ct->slot = s < 4 ? 8 + s : 24 + (s - 4);
         ct->b1 = 6; ct->b2 = 7; ct->dist = sdist[s];
         v3copy(ct->pos, spos[s]);
         make_frame(ct->frame, n);
@@ -787,7 +789,7 @@ typedef struct {
 } lag_t;
 /* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
  * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
-typedef struct { real lim[12]; real slot[18][6]; } warm_t;
+typedef struct { real lim[12]; real slot[28][6]; } warm_t;   /* slots 24..27: the extra cube<->cube points of the D5 study */
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
                     warm_t *warm, int diag, int sub_index) {
@@ -797,6 +799,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     /* -- position stage: normalise quaternions, kinematics */
     K.ncube = nc;
     K.mu_cube = T->mu_cube; K.mu_finger_cube = T->mu_finger_cube;
+    K.cc_points = P->cc_points == 8 ? 8 : 4;
     for (int c = 0; c < nc; c++) {
         real *qq = qpos + 6 + 7 * c + 3, n2 = 0;
         for (int k = 0; k < 4; k++) n2 += qq[k] * qq[k];
@@ -1057,6 +1060,7 @@ void orc_default_params(orc_params *p, int task) {
     p->warm_start = 1;
     p->arm_collision = 1;
     p->pgs_tol = 1e-6;
+    p->cc_points = 4;
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
