@@ -264,6 +264,11 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.inv_mu_fcr2 = (float)(1.0 / (mufr * mufr));
         const bool roll_default = loop || cfg->task == LCR_TASK_STACK;
         D.roll = (cfg->finger_cube_condim == 6 || (cfg->finger_cube_condim == 0 && roll_default)) ? 1 : 0;   // 0 = the task's default
+        // Stack shards of at most three waves per CU (MI355X: up to 49 152 envs; BASELINE config 5's per-GPU size is 32 768) run the kernel
+        // variant that keeps every g row in LDS (46 / 52 KiB per wave, 3 x 52 <= 160 KiB); LCR_STACK_LDS=small|big overrides the choice
+        // (tests exercise both variants at small sizes)
+        D.big_lds = (cfg->task == LCR_TASK_STACK && (N + 63) / 64 <= 3 * (size_t)prop.multiProcessorCount) ? 1 : 0;
+        if (const char *ov = getenv("LCR_STACK_LDS")) { if (cfg->task == LCR_TASK_STACK) D.big_lds = strcmp(ov, "big") == 0 ? 1 : (strcmp(ov, "small") == 0 ? 0 : D.big_lds); }
         D.walls = loop ? 1 : 0;
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

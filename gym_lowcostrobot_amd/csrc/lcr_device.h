@@ -57,7 +57,7 @@ struct LcrDev {
     float rr_fc;         // finger<->cube: mu_tan^2 / mu_roll^2   (ROLL kernels: lcr_config.finger_cube_condim = 6)
     float inv_mu_fcr2;   // finger<->cube: 1 / mu_roll^2
     int roll;            // 1: finger<->cube slots carry the two rolling rows
-    int _pad1;
+    int big_lds;         // Stack: the shard has at most three waves per CU -> the variant that keeps every g row in LDS (46 / 52 KiB per wave)
 };
 
 // pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height

@@ -258,7 +258,8 @@ constexpr int NAS = 5;
 // (follower.xml:15 condim="6"; deviation D4 is then limited to the finger<->floor contacts)
 template <bool ROLL> constexpr int as_rows(int s) { return (ROLL && s < 2) ? 6 : 4; }
 // first LDS row of a slot (Stack keeps four LDS rows per slot in every variant: its rolling rows live in the global scratch)
-template <bool ROLL, int NC> constexpr int as_row0(int s) { return (ROLL && NC == 1) ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
+// (BIG: the Stack variant for shards of at most three waves per CU, which keeps every g row in LDS)
+template <bool ROLL, int NC, bool BIG> constexpr int as_row0(int s) { return (ROLL && (NC == 1 || BIG)) ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
 constexpr int AS_TOTAL_ROWS = 20;
 template <int NC, int NRW>
 struct Warm {
@@ -282,8 +283,11 @@ constexpr int LDS_PARK_FLOATS = 4 * 2 * 64 * 4;
 // the four g rows of its arm-link proxy slot live in a coalesced global scratch array instead ([12][N] float2, L1/L2 resident).
 constexpr int LDS_CC_FLOATS = 4 * CC_REC * 64;
 // ROLL kernels: one cube: 24 g rows (36 KiB), no parking; Stack: the four rolling rows join the proxy slot's rows in the global scratch
-template <int NC, bool WALLS, bool ROLL> struct LdsSize {
-    static constexpr int value = NC == 2 ? 16 * LDS_ROW + LDS_CC_FLOATS : (ROLL ? 24 * LDS_ROW : LDS_G_FLOATS + LDS_PARK_FLOATS);
+// BIG (Stack, <= 3 waves per CU, i.e. <= 49 152 envs on an MI355X; the per-GPU shard of BASELINE config 5 is 32 768): all 20 / 24 g rows and
+// the cube<->cube records in LDS (46 / 52 KiB per wave), nothing in the global scratch
+template <int NC, bool BIG, bool ROLL> constexpr int cc_base_rows() { return (NC == 2 && BIG) ? (ROLL ? 24 : 20) : 16; }
+template <int NC, bool WALLS, bool ROLL, bool BIG> struct LdsSize {
+    static constexpr int value = NC == 2 ? cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + LDS_CC_FLOATS : (ROLL ? 24 * LDS_ROW : LDS_G_FLOATS + LDS_PARK_FLOATS);
 };
 typedef float float4v __attribute__((ext_vector_type(4)));
 
@@ -330,7 +334,7 @@ DEV void diag_choice(Diag &DG, bool act, int slot, int sel) { DG.choice += act ?
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool WALLS, bool ADAPT, bool ROLL>
+template <int NC, bool WALLS, bool ADAPT, bool ROLL, bool BIG>
 DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
@@ -536,7 +540,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool cc_act[4] = {false, false, false, false};
     bool cc_any = false;
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
-    float *ccl = lds + 16 * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
+    float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
     const size_t CS = 64;
     if constexpr (NC == 2) {
         const f3 dc = S.cp[1] - S.cp[0];
@@ -949,9 +953,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
                     gg = fmaf(g[j], g[j], gg);
-                    if (NC == 2 && s == 4) P.scratch[((size_t)(r * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
-                    else if (NC == 2 && r >= 4) P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
-                    else lds[(as_row0<ROLL, NC>(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j];
+                    if (NC == 2 && !BIG && s == 4) P.scratch[((size_t)(r * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
+                    else if (NC == 2 && !BIG && r >= 4) P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
+                    else lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j];
                 }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 if (ROLL && r > 3) Rr = Rf * P.rr_fc;
@@ -1195,9 +1199,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int r = 0; r < nrow; r++)
 #pragma unroll
                     for (int k = 0; k < 3; k++)
-                        g[r][k] = (NC == 2 && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
-                                  : (NC == 2 && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
-                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                        g[r][k] = (NC == 2 && !BIG && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
+                                  : (NC == 2 && !BIG && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
+                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
                 float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
                 float arefv[NRW], invv[NRW], f_in[NRW];
 #pragma unroll
@@ -1481,9 +1485,9 @@ DEV void write_obs18(const LcrDev &P, float *dst, int e, const EnvState<NC> &S, 
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL>
+template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL, bool BIG>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[LdsSize<NC, WALLS, ROLL>::value];
+    __shared__ float lds[LdsSize<NC, WALLS, ROLL, BIG>::value];
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -1592,7 +1596,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
         for (int k = 0; k < 4; k++) W.wall[s][k] = 0.f;
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
@@ -1765,12 +1769,15 @@ template <bool ADAPT, bool ROLL>
 static void launch_step_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
     const bool stack = P.task == 4;
-    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else if (P.big_lds) {   // Stack shard of at most three waves per CU: every g row in LDS
+        if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+        else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    } else if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
 }
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
     const hipStream_t st = (hipStream_t)stream;

@@ -644,6 +644,26 @@ def test_image_observations_vs_cpu_raycaster(hip_lib, task):
     sim.close()
 
 
+@pytest.mark.parametrize("which", ["rollout_joint", "rollout_ee", "cube_on_cube", "rolling_rows", "link_proxy", "converged"])
+def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which):
+    """StackTwoCubes has two kernel variants: shards of at most three waves per CU (<= 49 152 envs on an MI355X; every other Stack test
+    here) keep all g rows in LDS; larger ones keep the proxy slot's and the rolling rows in a global scratch array.  LCR_STACK_LDS=small
+    forces the second variant at test sizes."""
+    monkeypatch.setenv("LCR_STACK_LDS", "small")
+    if which == "rollout_joint":
+        test_step_rollout_vs_oracle(hip_lib, "stack", "joint")
+    elif which == "rollout_ee":
+        test_step_rollout_vs_oracle(hip_lib, "stack", "ee")
+    elif which == "cube_on_cube":
+        test_stack_cube_on_cube_contacts(hip_lib)
+    elif which == "rolling_rows":
+        test_rolling_rows_finger_cube_condim6(hip_lib, "stack")
+    elif which == "link_proxy":
+        test_link_proxy_contacts(hip_lib, "stack", 16, False, "joint")
+    else:
+        test_converged_solver_mode(hip_lib, "stack")
+
+
 def test_zz_outlier_census(hip_lib):
     """(runs last in this file) every out-of-tolerance env seen by the parity loops above differed from the oracle in its
     active set; print the census"""
