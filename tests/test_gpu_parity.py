@@ -15,6 +15,11 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
+
+def _vecsim(*a, **kw):
+    from gym_lowcostrobot_amd import VecSim
+    return VecSim(*a, **kw)
+
 N = 512
 MAX_DQ, MAX_DV = util.MAX_DQ, util.MAX_DV
 
@@ -662,6 +667,24 @@ def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which
         test_link_proxy_contacts(hip_lib, "stack", 16, False, "joint")
     else:
         test_converged_solver_mode(hip_lib, "stack")
+
+
+def test_stack_variants_are_bit_identical(hip_lib, monkeypatch):
+    """the two Stack kernel variants (g rows in LDS / partly in global scratch) differ in storage only: same bits out, so a Stack
+    batch gives the same trajectory whatever the shard size selects"""
+    n = 512
+    sims = []
+    for mode in ("small", "big"):
+        monkeypatch.setenv("LCR_STACK_LDS", mode)
+        sims.append(_vecsim("stack", n, observation_mode="state", base_seed=3))
+    act = np.random.default_rng(9).uniform(-1, 1, (6, n, 6)).astype(np.float32)
+    for t in range(6):
+        for sim in sims:
+            sim.step(act[t])
+        a, b = util.pull_state(sims[0]), util.pull_state(sims[1])
+        np.testing.assert_array_equal(a["qpos"], b["qpos"]); np.testing.assert_array_equal(a["qvel"], b["qvel"])
+    for sim in sims:
+        sim.close()
 
 
 def test_zz_outlier_census(hip_lib):
