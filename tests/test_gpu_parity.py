@@ -123,15 +123,17 @@ def test_auto_reset_and_timelimit(hip_lib):
     sim.close()
 
 
-def test_shard_invariance_and_determinism(hip_lib):
-    """env i's trajectory depends only on its GLOBAL id: one sim of 2M envs == two sims of M envs (bit-exact)"""
+@pytest.mark.parametrize("task,mode,M,steps", [("reach", "joint", 4096, 8), ("pick_place", "ee", 4096, 8), ("push_loop", "joint", 2048, 8),
+                                               ("stack", "joint", 32768, 55)])
+def test_shard_invariance_and_determinism(hip_lib, task, mode, M, steps):
+    """env i's trajectory depends only on its GLOBAL id: one sim of 2M envs == two sims of M envs (bit-exact), across auto-resets.
+    (Stack: the 65 536-env batch runs the kernel variant with rows in global scratch, its two 32 768-env shards the all-LDS one.)"""
     from gym_lowcostrobot_amd import VecSim
-    M = 4096
-    whole = VecSim("reach", 2 * M, observation_mode="state", base_seed=11)
-    lo = VecSim("reach", M, observation_mode="state", base_seed=11, env_id_offset=0)
-    hi = VecSim("reach", M, observation_mode="state", base_seed=11, env_id_offset=M)
+    whole = VecSim(task, 2 * M, observation_mode="state", action_mode=mode, base_seed=11)
+    lo = VecSim(task, M, observation_mode="state", action_mode=mode, base_seed=11, env_id_offset=0)
+    hi = VecSim(task, M, observation_mode="state", action_mode=mode, base_seed=11, env_id_offset=M)
     aw, al, ah = whole.alloc_actions(), lo.alloc_actions(), hi.alloc_actions()
-    for t in range(8):
+    for t in range(steps):
         whole.fill_random_actions(aw, 0, t); lo.fill_random_actions(al, 0, t); hi.fill_random_actions(ah, 0, t)
         whole.step_device(aw.ptr); lo.step_device(al.ptr); hi.step_device(ah.ptr)
     sw, sl, sh = whole.get_state(), lo.get_state(), hi.get_state()
