@@ -1,6 +1,8 @@
 """Host-side mirror of the reference env classes: what reference tests/test_env.py checks with
 gymnasium's check_env (spaces well-formed, reset obs in space & float32, same-seed determinism, step arity
 and types), restated without gymnasium (absent from this image) + the reference's exception behaviour."""
+import os
+
 import numpy as np
 import pytest
 
@@ -322,3 +324,31 @@ def test_ppo_example_learns(hip_lib):
     assert len(hist) == 6 and all(np.isfinite(h["loss"]) and np.isfinite(h["mean_reward"]) for h in hist)
     assert hist[-1]["mean_reward"] > hist[0]["mean_reward"] + 0.02, hist          # dense reward = -distance: the arm learns to approach
     assert hist[-1]["successes"] > hist[0]["successes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["lib_first", "torch_first"])
+def test_hip_runtime_is_shared_with_torch_in_either_import_order(order):
+    """liblcr_hip.so and torch must end up on ONE HIP runtime whichever is imported first: a second
+    copy of libamdhip64 in the process breaks stream / pointer sharing.  Run in a fresh interpreter."""
+    import subprocess
+    import sys
+    a = "from gym_lowcostrobot_amd import VecSim; sim = VecSim('reach', 128, observation_mode='state')"
+    b = "import torch; x = torch.ones(8, device='cuda')"
+    body = (a + "\n" + b) if order == "lib_first" else (b + "\n" + a)
+    code = body + """
+import numpy as np
+sim.set_stream(torch.cuda.current_stream().cuda_stream)
+sim.reset(seeds=np.arange(128))
+v = sim.arm_qpos.torch()                       # zero-copy view of simulator memory in torch
+sim.step(np.zeros((128, sim.action_dim), np.float32))
+torch.cuda.synchronize()
+assert v.is_cuda and torch.isfinite(v).all() and float((x * 2).sum()) == 16.0
+maps = open('/proc/self/maps').read()
+libs = {ln.split()[-1] for ln in maps.splitlines() if 'libamdhip64' in ln}
+assert len(libs) == 1, libs
+print('one runtime:', libs)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "one runtime" in r.stdout
