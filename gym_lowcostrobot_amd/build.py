@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcr_hip.so")
-SOURCES = ["lcr_capi.hip", "lcr_kernels.hip", "lcr_render.hip"]
+SOURCES = ["lcr_capi.hip", "lcr_kernels.hip", "lcr_render.hip"]   # (bench.kernel_sha16 and the tools hash / compile these)
 HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", os.path.join("..", "..", "include", "lcr.h")]
 # -ffast-math: the kernels carry no NaN/inf/signed-zero semantics (the -0.0 sparse reward is built from its bit pattern,
 # the fp64 reset sampling uses explicitly rounded __dmul_rn/__dadd_rn); -fno-slp-vectorize: packed-f32 formation by the
@@ -27,26 +27,39 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# (source, object, extra flags): lcr_kernels.hip is compiled four times, LCR_PART selecting the step-kernel instantiations a unit emits
+# (0 one-cube kernels + dispatcher + small kernels, 1 PushCubeLoop, 2 / 3 the two StackTwoCubes variants) -- 32 kernels of ~50-100 KB
+# code each take 80 s in one unit, ~30 s as four units compiled concurrently
+UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
+         ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels.hip", "lcr_kernels_walls.o", ["-DLCR_PART=1"]),
+         ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"])]
+
+
 def build(force=False, verbose=False):
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     deps = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
-    for src in SOURCES:
+    objs, jobs = [], []
+    for src, obj, extra in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, obj)
         if force or _newer(o, [s] + deps):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
         objs.append(o)
-    if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+
+    def run(cmd):
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))   # (re-raises the first failure)
+    if force or _newer(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs)
     return LIB
 
 

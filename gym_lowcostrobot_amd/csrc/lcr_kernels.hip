@@ -27,6 +27,12 @@
 
 using namespace lcrdev;
 
+// translation-unit selection, see the launchers at the end of the file
+#ifndef LCR_PART
+#define LCR_PART (-1)
+#endif
+#define LCR_HAS_PART(k) (LCR_PART == -1 || LCR_PART == (k))
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -158,7 +164,7 @@ DEV double pcg_double(Pcg &g) {
 }
 DEV uint32_t ss_hashmix(uint32_t v, uint32_t &hc) { v ^= hc; hc *= 0x931e8875u; v *= hc; v ^= v >> 16; return v; }
 DEV uint32_t ss_mix(uint32_t x, uint32_t y) { uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y; r ^= r >> 16; return r; }
-DEV Pcg pcg_seed(unsigned long long seed) {  // SeedSequence(seed).generate_state(4, uint64) -> pcg64 srandom
+__attribute__((unused)) DEV Pcg pcg_seed(unsigned long long seed) {  // SeedSequence(seed).generate_state(4, uint64) -> pcg64 srandom
     uint32_t ent0 = (uint32_t)seed, ent1 = (uint32_t)(seed >> 32);
     uint32_t pool[4], hc = 0x43b0d7e5u;
     pool[0] = ss_hashmix(ent0, hc);
@@ -1720,6 +1726,7 @@ __global__ __launch_bounds__(256) void lcr_reset_kernel(LcrDev P, const unsigned
     P.elapsed[e] = 0;
 }
 
+#if LCR_HAS_PART(0)
 // ------------------------------------------------------------------------------------------------
 // synthetic policy: U(-1,1) from Philox4x32-10 keyed (seed, global env id, step)
 // ------------------------------------------------------------------------------------------------
@@ -1755,6 +1762,8 @@ __global__ __launch_bounds__(64) void lcr_calib_copy_kernel(const float *__restr
     if (i < n) dst[i] = src[i] + 1.0f;
 }
 
+#endif   // LCR_HAS_PART(0)
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1765,29 +1774,74 @@ static int check_launch() {
     return err == hipSuccess ? 0 : (int)err;
 }
 
+// The step kernel has 32 instantiations.  gym_lowcostrobot_amd/build.py compiles this file four times in parallel, -DLCR_PART=0..3
+// selecting which launchers -- and hence which instantiations -- a translation unit emits: 0 the one-cube kernels (+ the dispatcher and
+// the small kernels), 1 PushCubeLoop, 2 / 3 the two StackTwoCubes variants.  Without the macro (tools/) everything is in one unit.
+// the four solver-mode / contact-row variants of one launcher
+#define LCR_DISPATCH_MODES(fn)                                              \
+    do {                                                                    \
+        if (P.pgs_iters < 0) {   /* converged mode */                       \
+            if (P.roll) fn<true, true>(P, action_dev, ee_mode, st);         \
+            else fn<true, false>(P, action_dev, ee_mode, st);               \
+        } else {                                                            \
+            if (P.roll) fn<false, true>(P, action_dev, ee_mode, st);   /* six-row finger<->cube contacts */ \
+            else fn<false, false>(P, action_dev, ee_mode, st);              \
+        }                                                                   \
+    } while (0)
+
+int lcr_launch_step_walls(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st);
+int lcr_launch_step_stack(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st);
+int lcr_launch_step_stack_big(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st);
+
+#if LCR_HAS_PART(1)
 template <bool ADAPT, bool ROLL>
-static void launch_step_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+static void launch_walls_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
-    const bool stack = P.task == 4;
-    if (P.walls && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (P.walls && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && !ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (!stack && ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else if (P.big_lds) {   // Stack shard of at most three waves per CU: every g row in LDS
-        if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-        else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    } else if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+}
+int lcr_launch_step_walls(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+    LCR_DISPATCH_MODES(launch_walls_t);
+    return check_launch();
+}
+#endif
+#if LCR_HAS_PART(2)
+template <bool ADAPT, bool ROLL>
+static void launch_stack_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+    const int blocks = (P.n + 63) / 64;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
     else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+}
+int lcr_launch_step_stack(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+    LCR_DISPATCH_MODES(launch_stack_t);
+    return check_launch();
+}
+#endif
+#if LCR_HAS_PART(3)
+template <bool ADAPT, bool ROLL>
+static void launch_stack_big_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {   // shard of at most three waves per CU: every g row in LDS
+    const int blocks = (P.n + 63) / 64;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+}
+int lcr_launch_step_stack_big(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+    LCR_DISPATCH_MODES(launch_stack_big_t);
+    return check_launch();
+}
+#endif
+
+#if LCR_HAS_PART(0)
+template <bool ADAPT, bool ROLL>
+static void launch_one_cube_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+    const int blocks = (P.n + 63) / 64;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<1, true, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
 }
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
     const hipStream_t st = (hipStream_t)stream;
-    if (P.pgs_iters < 0) {   // converged mode
-        if (P.roll) launch_step_t<true, true>(P, action_dev, ee_mode, st);
-        else launch_step_t<true, false>(P, action_dev, ee_mode, st);
-    } else {
-        if (P.roll) launch_step_t<false, true>(P, action_dev, ee_mode, st);   // finger<->cube contacts with rolling rows (condim 6)
-        else launch_step_t<false, false>(P, action_dev, ee_mode, st);
-    }
+    if (P.walls) return lcr_launch_step_walls(P, action_dev, ee_mode, st);
+    if (P.task == 4) return P.big_lds ? lcr_launch_step_stack_big(P, action_dev, ee_mode, st) : lcr_launch_step_stack(P, action_dev, ee_mode, st);
+    LCR_DISPATCH_MODES(launch_one_cube_t);
     return check_launch();
 }
 
@@ -1810,3 +1864,4 @@ int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream) 
     hipLaunchKernelGGL(lcr_calib_copy_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, src, dst, n);
     return check_launch();
 }
+#endif   // LCR_HAS_PART(0)

@@ -111,7 +111,7 @@ def kernels(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm", nargs="?")
-    ap.add_argument("--kernel", default="lcr_step_kernelILi1ELb0ELb0E")
+    ap.add_argument("--kernel", default="lcr_step_kernelILi1ELb0ELb0ELb0ELb0ELb0E", help="substring of the mangled name (default: the bench kernel: one cube, joint, no rails, fixed sweeps, four-row contacts)")
     ap.add_argument("--out")
     a = ap.parse_args()
     path = a.asm
