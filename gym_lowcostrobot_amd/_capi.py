@@ -17,6 +17,7 @@ ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
 REWARD_TYPES = {"sparse": 0, "dense": 1}
 COMPAT_ZERO_QVEL_ON_RESET = 1
+COMPAT_COLD_SOLVE_EACH_STEP = 2   # contact solver starts every control step from zero forces (default: forces carried across steps)
 IMG_H, IMG_W = 240, 320
 
 LCR_OK, LCR_ERR_INVALID, LCR_ERR_NO_DEVICE, LCR_ERR_HIP, LCR_ERR_OOM, LCR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5

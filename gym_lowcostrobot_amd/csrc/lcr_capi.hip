@@ -210,6 +210,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
     size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 4 ? 24 : 48) * N);   // (+ the rolling rows of the finger slots)   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
+    const bool carry_warm = !(cfg->compat & LCR_COMPAT_COLD_SOLVE_EACH_STEP);
+    size_t o_warm = off; if (carry_warm) off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
@@ -311,6 +313,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.choice = cfg->diagnostics ? (unsigned *)(base + o_diag + 3 * al(sizeof(unsigned) * N)) : nullptr;
     D.ctrl_out = cfg->diagnostics ? (float *)(base + o_diag + 4 * al(sizeof(unsigned) * N)) : nullptr;
     D.scratch = cfg->task == LCR_TASK_STACK ? (float *)(base + o_scr) : nullptr;
+    D.warm = carry_warm ? (float *)(base + o_warm) : nullptr;
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
     D.img_bg = s->has_images ? (unsigned char *)(base + o_bg) : nullptr;
@@ -506,6 +509,8 @@ int lcr_set_state(lcr_sim *s, const double *qpos, const double *qvel, const doub
         return hipMemcpy(dst, tmp.data(), cnt * sizeof(float), hipMemcpyHostToDevice);
     };
     if (qpos) HIPCHK(push(s->dev.qpos, qpos, s->nq * N));
+    // a state set from outside starts without carried constraint forces (cold solve in the first substep of the next step)
+    if ((qpos || qvel) && s->dev.warm) HIPCHK(hipMemsetAsync(s->dev.warm, 0, sizeof(float) * LCR_NWARM * N, s->stream));   // (ordered before the next step on the sim's stream)
     if (qvel) HIPCHK(push(s->dev.qvel, qvel, s->nv * N));
     if (ee_lag) HIPCHK(push(s->dev.ee_lag, ee_lag, 3 * N));
     if (target) HIPCHK(hipMemcpy(s->dev.target, target, 3 * N * sizeof(float), hipMemcpyHostToDevice));

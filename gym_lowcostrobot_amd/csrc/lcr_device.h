@@ -4,6 +4,8 @@
 
 #define LCR_OBS_DIM 18
 
+constexpr int LCR_NWARM = 104;   // floats per env in LcrDev::warm (layout: lcr_kernels.hip WARM_*)
+
 struct LcrDev {
     int n;            // envs on this device
     int k;            // action components
@@ -57,6 +59,7 @@ struct LcrDev {
     float rr_fc;         // finger<->cube: mu_tan^2 / mu_roll^2   (ROLL kernels: lcr_config.finger_cube_condim = 6)
     float inv_mu_fcr2;   // finger<->cube: 1 / mu_roll^2
     int roll;            // 1: finger<->cube slots carry the two rolling rows
+    float *warm;         // [LCR_NWARM][n] constraint forces carried from one control step to the next (warm start), or null
     int big_lds;         // Stack: the shard has at most three waves per CU -> the variant that keeps every g row in LDS (46 / 52 KiB per wave)
 };
 

@@ -267,6 +267,8 @@ template <bool ROLL> constexpr int as_rows(int s) { return (ROLL && s < 2) ? 6 :
 // (BIG: the Stack variant for shards of at most three waves per CU, which keeps every g row in LDS)
 template <bool ROLL, int NC, bool BIG> constexpr int as_row0(int s) { return (ROLL && (NC == 1 || BIG)) ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
 constexpr int AS_TOTAL_ROWS = 20;
+// layout of LcrDev::warm ([LCR_NWARM][N] floats): the Warm fields of one env between two control steps
+constexpr int WARM_FLOOR = 0, WARM_ARM = 32, WARM_LIM = 62, WARM_WALL = 68, WARM_CC = 84, WARM_CCPREV = 100;   // LCR_NWARM = 104 (lcr_device.h)
 template <int NC, int NRW>
 struct Warm {
     float floor[NC][4][4];
@@ -957,11 +959,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 fsub(CL, g);
                 float gg = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    gg = fmaf(g[j], g[j], gg);
-                    if (NC == 2 && !BIG && s == 4) P.scratch[((size_t)(r * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
-                    else if (NC == 2 && !BIG && r >= 4) P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + (j >> 1)) * P.n + env) * 2 + (j & 1)] = g[j];
-                    else lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + (j >> 1) * 128 + lane * 2 + (j & 1)] = g[j];
+                for (int j = 0; j < 6; j++) gg = fmaf(g[j], g[j], gg);
+                // (stored as the float2 pairs the sweeps load: a scalar store read back through a float2 lvalue would be a strict-aliasing
+                //  violation, and the compiler did move such loads above the stores in one kernel variant)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float2v gp = {g[2 * k], g[2 * k + 1]};
+                    if (NC == 2 && !BIG && s == 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2]) = gp;
+                    else if (NC == 2 && !BIG && r >= 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2]) = gp;
+                    else *reinterpret_cast<float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
                 }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                 if (ROLL && r > 3) Rr = Rf * P.rr_fc;
@@ -1582,25 +1588,39 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     f3 lag_cube[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) lag_cube[c] = S.cp[c];
+    // Constraint forces for the warm start of the first substep: carried from the previous control step (P.warm: [LCR_NWARM][N],
+    // zero after reset / set_state), as MuJoCo carries mjData.qacc_warmstart from one mj_step to the next -- the reference never
+    // resets it between env.step calls.  With LCR_COMPAT_COLD_SOLVE_EACH_STEP (P.warm == nullptr) every control step starts from zero.
     Warm<NC, ROLL ? 6 : 4> W;
+    const bool carry = P.warm != nullptr;   // wave-uniform
+    auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) W.floor[c][s][k] = 0.f;
+            for (int k = 0; k < 4; k++) W.floor[c][s][k] = wld(WARM_FLOOR + 16 * c + 4 * s + k);
 #pragma unroll
     for (int s = 0; s < NAS; s++)
 #pragma unroll
-        for (int k = 0; k < (ROLL ? 6 : 4); k++) W.arm[s][k] = 0.f;
+        for (int k = 0; k < (ROLL ? 6 : 4); k++) W.arm[s][k] = wld(WARM_ARM + 6 * s + k);
 #pragma unroll
-    for (int s = 0; s < 4; s++) W.cc_prev[s] = false;
-#pragma unroll
-    for (int j = 0; j < 6; j++) W.lim[j] = 0.f;
+    for (int j = 0; j < 6; j++) W.lim[j] = wld(WARM_LIM + j);
 #pragma unroll
     for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) W.wall[s][k] = 0.f;
+        for (int k = 0; k < 4; k++) W.wall[s][k] = WALLS ? wld(WARM_WALL + 4 * s + k) : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) W.cc_prev[s] = false;
+    if constexpr (NC == 2) {   // cube<->cube forces live in their LDS records between substeps
+        float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            W.cc_prev[s] = wld(WARM_CCPREV + s) != 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(WARM_CC + 4 * s + r);
+        }
+    }
     Diag DG = {0u, 0u, 0u, 0u};
     for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     if (P.diag && valid) {
@@ -1698,6 +1718,36 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         if (WALLS) P.goal[e] = goal;
         if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);  // data.time advances in mj_step only
     }
+    if (carry && valid) {   // forces for the next control step's first substep; an env that was just reset starts from zero
+        auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) wst(WARM_FLOOR + 16 * c + 4 * s + k, W.floor[c][s][k]);
+#pragma unroll
+        for (int s = 0; s < NAS; s++)
+#pragma unroll
+            for (int k = 0; k < (ROLL ? 6 : 4); k++) wst(WARM_ARM + 6 * s + k, W.arm[s][k]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) wst(WARM_LIM + j, W.lim[j]);
+        if constexpr (WALLS) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) wst(WARM_WALL + 4 * s + k, W.wall[s][k]);
+        }
+        if constexpr (NC == 2) {
+            const float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                wst(WARM_CCPREV + s, W.cc_prev[s] ? 1.f : 0.f);
+#pragma unroll
+                for (int r = 0; r < 4; r++) wst(WARM_CC + 4 * s + r, W.cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1724,6 +1774,8 @@ __global__ __launch_bounds__(256) void lcr_reset_kernel(LcrDev P, const unsigned
     if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }
     P.ee_lag[e] = ee.x; P.ee_lag[N + e] = ee.y; P.ee_lag[2 * N + e] = ee.z;
     P.elapsed[e] = 0;
+    if (P.warm)
+        for (int i = 0; i < LCR_NWARM; i++) P.warm[(size_t)i * N + e] = 0.f;   // no constraint forces carried into a new episode
 }
 
 #if LCR_HAS_PART(0)

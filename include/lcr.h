@@ -51,7 +51,11 @@ enum { LCR_REWARD_SPARSE = 0, LCR_REWARD_DENSE = 1 };        /* reward_type   re
 
 /* compat bits: every reference quirk is reproduced when the bit is CLEAR */
 enum {
-    LCR_COMPAT_ZERO_QVEL_ON_RESET = 1u << 0 /* set: zero qvel in reset (deviates from reach_cube_env.py:297-311) */
+    LCR_COMPAT_ZERO_QVEL_ON_RESET = 1u << 0, /* set: zero qvel in reset (deviates from reach_cube_env.py:297-311) */
+    LCR_COMPAT_COLD_SOLVE_EACH_STEP = 1u << 1 /* set: the contact solver starts every control step from zero forces, so that a step is a pure
+                                                 function of (qpos, qvel, action).  Clear (default): the forces of the last substep warm-start
+                                                 the next control step, as MuJoCo's mjData.qacc_warmstart does across env.step calls (the
+                                                 reference never resets it); lcr_reset / auto-reset / lcr_set_state clear them */
 };
 
 #define LCR_IMG_H 240

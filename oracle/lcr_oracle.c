@@ -790,6 +790,7 @@ typedef struct {
 /* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
  * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
 typedef struct { real lim[12]; real slot[28][6]; } warm_t;   /* slots 24..27: the extra cube<->cube points of the D5 study */
+int orc_warm_bytes(void) { return (int)sizeof(warm_t); } /* stride of orc_io.warm */
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
                     warm_t *warm, int diag, int sub_index) {
@@ -1281,6 +1282,7 @@ void orc_reset(const orc_params *p, orc_io *io, int n, const uint8_t *mask, cons
     for (int e = 0; e < n; e++) {
         if (mask && !mask[e]) continue;
         if (seeds) orc_rng_seed(seeds[e], io->rng + 4 * (size_t)e);
+        if (io->warm) memset((char *)io->warm + (size_t)e * sizeof(warm_t), 0, sizeof(warm_t));
         reset_one(p, &T, io->qpos + (size_t)e * ORC_NQ_MAX, io->qvel + (size_t)e * ORC_NV_MAX, io->ee_lag + 3 * (size_t)e,
                   io->target + 3 * (size_t)e, io->elapsed + e, io->rng + 4 * (size_t)e, io->goal ? io->goal[e] : 0);
         if (io->obs) write_obs(p, &T, io->qpos + (size_t)e * ORC_NQ_MAX, io->qvel + (size_t)e * ORC_NV_MAX, io->target + 3 * (size_t)e,
@@ -1316,10 +1318,14 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     (void)k;
     /* ---- 20 x mj_step reach:276-279 */
     lag_t lag;
-    warm_t warm;
+    warm_t warm_local, *warmp = &warm_local;
     memset(&lag, 0, sizeof lag);
-    memset(&warm, 0, sizeof warm);
-    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, &warm, e == 0 && s == P->n_substeps - 1, s);
+    memset(&warm_local, 0, sizeof warm_local);
+    /* The constraint forces of the last substep warm-start the first substep of the next control step (io->warm, one warm_t per env, zero
+     * after reset), as MuJoCo carries mjData.qacc_warmstart across mj_step calls and the reference never resets it between env.step calls.
+     * ORC_COMPAT_COLD_SOLVE_EACH_STEP (or io->warm == NULL): every control step starts from zero forces instead. */
+    if (io->warm && !(P->compat & ORC_COMPAT_COLD_SOLVE_EACH_STEP)) warmp = (warm_t *)((char *)io->warm + e * sizeof(warm_t));
+    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, warmp, e == 0 && s == P->n_substeps - 1, s);
     for (int i = 0; i < nq; i++) qpos64[i] = (double)qpos[i];
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];
@@ -1371,6 +1377,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
         if (diverged) for (int d = 0; d < ORC_NV_MAX; d++) qvel64[d] = 0;
         write_obs(P, T, qpos64, qvel64, target, obs);
         io->did_reset[e] = 1;
+        if (io->warm) memset((char *)io->warm + e * sizeof(warm_t), 0, sizeof(warm_t)); /* no forces carried into a new episode */
     }
 }
 

@@ -61,6 +61,7 @@ class OrcIO(ctypes.Structure):
         ("active_count", ctypes.c_void_p),
         ("max_sweeps", ctypes.c_void_p),
         ("choice", ctypes.c_void_p),
+        ("warm", ctypes.c_void_p),
     ]
 
 
@@ -89,6 +90,7 @@ def lib(f32=False):
         L.orc_action_dim.restype = ctypes.c_int
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_ik.restype = ctypes.c_int
+        L.orc_warm_bytes.restype = ctypes.c_int
         _libs[key] = L
     return _libs[key]
 
@@ -135,11 +137,13 @@ class Oracle:
         self.active_count = np.zeros(n, np.uint32)
         self.max_sweeps = np.zeros(n, np.uint32)
         self.choice = np.zeros(n, np.uint32)
+        # constraint forces carried between control steps (opaque records; zero them when a state is set from outside)
+        self.warm = np.zeros((n, (self.L.orc_warm_bytes() + 7) // 8 * 8), np.uint8)
         self.io = OrcIO(
             _p(self.qpos), _p(self.qvel), _p(self.ee_lag), _p(self.target), _p(self.elapsed), _p(self.rng),
             _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.reward64), _p(self.terminated),
             _p(self.truncated), _p(self.is_success), _p(self.did_reset), _p(self.goal), _p(self.sim_time),
-            _p(self.active_mask), _p(self.active_count), _p(self.max_sweeps), _p(self.choice),
+            _p(self.active_mask), _p(self.active_count), _p(self.max_sweeps), _p(self.choice), _p(self.warm),
         )
 
     def reset(self, seeds=None, mask=None):

@@ -689,6 +689,68 @@ def test_stack_variants_are_bit_identical(hip_lib, monkeypatch):
         sim.close()
 
 
+@pytest.mark.parametrize("task,mode,condim,lds", [("reach", "joint", 4, None), ("reach", "ee", 6, None), ("push", "joint", 6, None),
+                                                  ("pick_place", "ee", 4, None), ("lift", "joint", 6, None), ("push_loop", "joint", 6, None),
+                                                  ("push_loop", "ee", 4, None), ("stack", "joint", 6, "small"), ("stack", "ee", 6, "small"),
+                                                  ("stack", "ee", 4, "small"), ("stack", "joint", 6, "big"), ("stack", "ee", 6, "big")])
+def test_every_kernel_variant_is_deterministic(hip_lib, monkeypatch, task, mode, condim, lds):
+    """the same (state, action) stepped four times gives the same bits, and a converged-mode step too -- every template variant of
+    the step kernel (this test found a scalar-store / float2-load aliasing violation that let the compiler move g-row loads above
+    their stores in ONE variant: results differed by 1e-6 from launch to launch)"""
+    if lds:
+        monkeypatch.setenv("LCR_STACK_LDS", lds)
+    n = 512
+    rng = np.random.default_rng(17)
+    for pgs in (4, -1):
+        sim, o = util.make_pair(task, n, action_mode=mode, finger_cube_condim=condim, pgs_iters=pgs, auto_reset=False, max_episode_steps=0)
+        o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+        q, qd = util.random_arm_state(rng, n, scale_v=1.0)
+        o.qpos[:, :6] = q; o.qvel[:, :6] = qd
+        from oracle import orc as _orc
+        o.qpos[: n // 2, 6:8] = _orc.fk(np.zeros(6))[1][:2] + rng.normal(0, 0.01, (n // 2, 2))   # cubes near the gripper in half of the envs
+        util.sync_oracle_to_f32(o)
+        for t in range(2):
+            a = rng.uniform(-1, 1, (n, sim.action_dim)).astype(np.float32)
+            ref = None
+            for rep in range(4):
+                util.push_state(sim, o)
+                sim.step(a)
+                st = util.pull_state(sim)
+                cur = (st["qpos"].copy(), st["qvel"].copy(), sim.active_mask.numpy().copy(), sim.choice.numpy().copy())
+                if ref is None:
+                    ref = cur
+                for x, y in zip(ref, cur):
+                    np.testing.assert_array_equal(x, y)
+            o.step(a, threads=0); util.sync_oracle_to_f32(o)
+        sim.close()
+
+
+@pytest.mark.parametrize("task", ["push", "stack", "push_loop"])
+def test_constraint_forces_carried_across_control_steps(hip_lib, task):
+    """default: the contact forces of the last substep warm-start the next control step (as MuJoCo's qacc_warmstart does across
+    env.step calls); lcr_set_state / reset drop them.  Kernel and oracle, both carrying, agree over consecutive steps WITHOUT
+    re-synchronisation; with LCR_COMPAT_COLD_SOLVE_EACH_STEP the kernel reproduces the cold-start oracle instead, and the two modes differ."""
+    from gym_lowcostrobot_amd import _capi
+    n = 256
+    rng = np.random.default_rng(23)
+    acts = rng.uniform(-0.3, 0.3, (4, n, 6)).astype(np.float32)
+    finals = {}
+    for compat in (0, _capi.COMPAT_COLD_SOLVE_EACH_STEP):
+        sim, o = util.make_pair(task, n, compat=compat, auto_reset=False, max_episode_steps=0)
+        o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+        util.sync_oracle_to_f32(o); util.push_state(sim, o)
+        for t in range(4):                        # no push_state in between: both sides carry (or both start cold)
+            a = acts[t][:, : sim.action_dim]
+            o.step(a, threads=0); sim.step(a)
+            st = util.pull_state(sim)
+            dq = np.abs(st["qpos"] - o.qpos[:, : sim.nq]).max(axis=1)
+            assert np.mean(dq <= 2e-5 * (t + 1)) >= 0.97 and np.median(dq) < 2e-6, (compat, t, np.median(dq), np.sort(dq)[-4:])
+        finals[compat] = st["qpos"].copy()
+        sim.close()
+    d = np.abs(finals[0] - finals[_capi.COMPAT_COLD_SOLVE_EACH_STEP]).max(axis=1)
+    assert np.median(d) > 1e-6, np.median(d)      # resting cubes: a cold solve lets them sink a little at the start of every control step
+
+
 def test_zz_outlier_census(hip_lib):
     """(runs last in this file) every out-of-tolerance env seen by the parity loops above differed from the oracle in its
     active set; print the census"""

@@ -17,7 +17,9 @@ def sync_oracle_to_f32(o):
 
 
 def push_state(sim, o):
-    """oracle (AoS, env-major) -> HIP sim (SoA)"""
+    """oracle (AoS, env-major) -> HIP sim (SoA).  lcr_set_state drops the constraint forces the sim carried from its last control step
+    (the next step starts with a cold solve); the oracle does the same here."""
+    o.warm[:] = 0
     sim.set_state(
         qpos=np.ascontiguousarray(o.qpos[:, : sim.nq].T),
         qvel=np.ascontiguousarray(o.qvel[:, : sim.nv].T),
@@ -100,6 +102,7 @@ def _twin(o):
 
         t = orc.Oracle(o.task, o.n, f32=True)
         ctypes.memmove(ctypes.byref(t.params), ctypes.byref(o.params), ctypes.sizeof(o.params))
+        t.action_dim = t.L.orc_action_dim(ctypes.byref(t.params))   # (depends on the copied action mode / gripper setting)
         o._f32_twin = t
     return t
 
@@ -119,6 +122,7 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
     t = _twin(o)
     for k in ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time"):
         getattr(t, k)[:] = getattr(o, k)
+    t.warm[:] = 0
     o.step(a, threads=0)
     sim.step(a)
     st = pull_state(sim)
