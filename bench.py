@@ -261,6 +261,9 @@ def main():
                 "kernel": "lcr_step_kernel" if args.obs == "state" else "lcr_step_kernel + lcr_render_obs_kernel",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_env_step": alg_bytes,
+                "traffic_note": "traffic counts solver state the SURVEY.md 8(d) formula does not: the constraint forces carried from one control step to the "
+                                "next (warm start as MuJoCo's qacc_warmstart, DESIGN.md section 4 D1) are read and written once per env-step: "
+                                "2 x 4 B x 42 (one cube) .. 84 (Stack) floats",
                 "note": "state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick",
             },
             "state_finite": finite,
