@@ -5,9 +5,11 @@
 // State is SoA [component][env] in HBM: every per-lane scalar load/store is one fully coalesced 256-B
 // wave transaction.  State is read once at kernel entry, kept in VGPRs across all n_substeps physics
 // substeps, and written once at exit; reward / termination / TimeLimit / auto-reset are fused at the tail.
-// The only LDS use is the per-lane scratch of the contact rows that couple into the arm
-// (g = L^-1 J^T, 4 slots x 4 rows x 6 floats, laid out [slot][row][k][lane] => bank-conflict free).
-// MFMA is not used: the largest contraction is 6x6.
+// LDS holds the per-lane contact rows that couple into the arm (g = L^-1 J^T, 5 slots x 4..6 rows x 6 floats, laid out
+// [slot][row][k][lane] => bank-conflict free), the parked constants of the floor slots and, for Stack, the cube<->cube
+// contact records: 38-52 KiB per wave (LdsSize).  MFMA is not used: the largest contraction is 6x6.
+// Template variants of the step kernel: NC cubes (1|2), EE (ee-IK action mode), WALLS (PushCubeLoop rails), ADAPT (converged
+// solver mode), ROLL (six-row finger<->cube contacts), BIG (Stack shards of <= 3 waves per CU: every row in LDS).
 //
 // What is restated here (reference file:line, relative to /root/reference/gym_lowcostrobot/):
 //   apply_action joint mode   envs/reach_cube_env.py:248-273 (+ lift_cube_env.py:258-282 gripper)
@@ -255,8 +257,9 @@ struct ArmSlot {
     bool act;
 };
 
-// constraint forces carried from one substep to the next within a control step (zero at its start): warm start of
-// the PGS sweeps, as MuJoCo warm-starts its solver.  Cube<->cube forces (Stack) persist in their LDS records.
+// constraint forces carried from one substep to the next -- and, through LcrDev::warm, from one control step to the next (zero after
+// a reset or lcr_set_state; zero at every control step with LCR_COMPAT_COLD_SOLVE_EACH_STEP): warm start of the PGS sweeps, as MuJoCo
+// warm-starts its solver from mjData.qacc_warmstart.  Cube<->cube forces (Stack) persist in their LDS records.
 // arm-coupled contact slots: 0,1 finger sphere 0/1 vs cube; 2,3 finger sphere 0/1 vs floor; 4 the arm-link proxies (D3): one
 // contact, vs floor or (gripper body) cube per lane, 4 rows (the torsion row only on a cube: link<->floor is condim 3)
 constexpr int NAS = 5;
