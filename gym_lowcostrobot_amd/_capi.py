@@ -11,7 +11,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+NWARM = 104   # LCR_NWARM: floats per env of carried constraint forces (layout: include/lcr.h)
 TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
@@ -148,6 +149,7 @@ def load():
         except Exception:
             pass
     L = ctypes.CDLL(LIB_PATH)
+    _check_single_hip_runtime()
     vp, i32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64
     L.lcr_abi_version.restype = ctypes.c_int
     L.lcr_last_error.restype = ctypes.c_char_p
@@ -166,8 +168,8 @@ def load():
     L.lcr_get_obs.argtypes = [vp, ctypes.POINTER(LcrObsView)]
     L.lcr_get_outputs.argtypes = [vp, ctypes.POINTER(LcrOutView)]
     L.lcr_fetch_host.argtypes = [vp, ctypes.POINTER(LcrHostView)]
-    L.lcr_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.lcr_set_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lcr_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lcr_set_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lcr_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.lcr_free.argtypes = [vp, vp]
     L.lcr_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
@@ -186,6 +188,24 @@ def load():
         raise OSError(f"liblcr_hip.so ABI {L.lcr_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     _lib = L
     return L
+
+
+def _check_single_hip_runtime():
+    """Two HIP runtimes in one process do not coexist (the second one sees no GPU).  The by-path preload above only unifies them when
+    torch's bundled libamdhip64 has the SONAME liblcr_hip.so was linked against (libamdhip64.so.7 for ROCm 7.x wheels); with a torch
+    wheel built for another ROCm major both would be mapped: say so loudly instead of failing later with 'no HIP device'."""
+    try:
+        with open("/proc/self/maps") as f:
+            libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    real = {os.path.realpath(p) for p in libs}
+    if len(real) > 1:
+        import warnings
+
+        warnings.warn("two HIP runtimes are mapped in this process (" + ", ".join(sorted(real)) + "): liblcr_hip.so was built against the "
+                      "ROCm 7 runtime (libamdhip64.so.7); use a PyTorch-ROCm wheel of the same ROCm major, or set LCR_NO_TORCH_PRELOAD=1 and "
+                      "import torch in a different process", RuntimeWarning, stacklevel=3)
 
 
 def check(rc):

@@ -14,6 +14,8 @@
 #include "lcr_device.h"
 #include "lcr_model_gen.h"
 
+static_assert(LCR_NWARM == LCR_DEV_NWARM, "include/lcr.h and lcr_device.h disagree on the carried-force block");
+
 namespace {
 thread_local char g_err[512] = "";
 
@@ -475,7 +477,7 @@ int lcr_fetch_host(lcr_sim *s, lcr_host_view *out) {
 }
 
 int lcr_get_state(lcr_sim *s, double *qpos, double *qvel, double *ee_lag, float *target, int32_t *elapsed, uint64_t *rng,
-                  int32_t *current_goal, double *sim_time) {
+                  int32_t *current_goal, double *sim_time, float *warm) {
     SIMCHK(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     const size_t N = (size_t)s->dev.n;
@@ -494,11 +496,15 @@ int lcr_get_state(lcr_sim *s, double *qpos, double *qvel, double *ee_lag, float 
     if (rng) HIPCHK(hipMemcpy(rng, s->dev.rng, 4 * N * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (current_goal) HIPCHK(hipMemcpy(current_goal, s->dev.goal, N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (sim_time) HIPCHK(hipMemcpy(sim_time, s->dev.sim_time, N * sizeof(double), hipMemcpyDeviceToHost));
+    if (warm) {   // the carried constraint forces (mjData.qacc_warmstart of the reference's sim); zeros when nothing is carried
+        if (s->dev.warm) HIPCHK(hipMemcpy(warm, s->dev.warm, sizeof(float) * LCR_NWARM * N, hipMemcpyDeviceToHost));
+        else memset(warm, 0, sizeof(float) * LCR_NWARM * N);
+    }
     return LCR_OK;
 }
 
 int lcr_set_state(lcr_sim *s, const double *qpos, const double *qvel, const double *ee_lag, const float *target,
-                  const int32_t *elapsed, const uint64_t *rng, const int32_t *current_goal, const double *sim_time) {
+                  const int32_t *elapsed, const uint64_t *rng, const int32_t *current_goal, const double *sim_time, const float *warm) {
     SIMCHK(s);
     HIPCHK(hipStreamSynchronize(s->stream));
     const size_t N = (size_t)s->dev.n;
@@ -509,8 +515,12 @@ int lcr_set_state(lcr_sim *s, const double *qpos, const double *qvel, const doub
         return hipMemcpy(dst, tmp.data(), cnt * sizeof(float), hipMemcpyHostToDevice);
     };
     if (qpos) HIPCHK(push(s->dev.qpos, qpos, s->nq * N));
-    // a state set from outside starts without carried constraint forces (cold solve in the first substep of the next step)
-    if ((qpos || qvel) && s->dev.warm) HIPCHK(hipMemsetAsync(s->dev.warm, 0, sizeof(float) * LCR_NWARM * N, s->stream));   // (ordered before the next step on the sim's stream)
+    // a state set from outside without its constraint forces starts cold (zero forces in the first substep of the next step);
+    // with them (warm != NULL: a checkpoint taken by lcr_get_state) the next step continues exactly where the saved sim would have
+    if (s->dev.warm) {
+        if (warm) HIPCHK(hipMemcpy(s->dev.warm, warm, sizeof(float) * LCR_NWARM * N, hipMemcpyHostToDevice));
+        else if (qpos || qvel) HIPCHK(hipMemset(s->dev.warm, 0, sizeof(float) * LCR_NWARM * N));
+    }
     if (qvel) HIPCHK(push(s->dev.qvel, qvel, s->nv * N));
     if (ee_lag) HIPCHK(push(s->dev.ee_lag, ee_lag, 3 * N));
     if (target) HIPCHK(hipMemcpy(s->dev.target, target, 3 * N * sizeof(float), hipMemcpyHostToDevice));

@@ -4,7 +4,7 @@
 
 #define LCR_OBS_DIM 18
 
-constexpr int LCR_NWARM = 104;   // floats per env in LcrDev::warm (layout: lcr_kernels.hip WARM_*)
+constexpr int LCR_DEV_NWARM = 104;   // floats per env in LcrDev::warm (layout: lcr_kernels.hip WARM_*; = LCR_NWARM of include/lcr.h)
 
 struct LcrDev {
     int n;            // envs on this device

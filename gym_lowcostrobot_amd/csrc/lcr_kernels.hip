@@ -271,7 +271,7 @@ template <bool ROLL> constexpr int as_rows(int s) { return (ROLL && s < 2) ? 6 :
 template <bool ROLL, int NC, bool BIG> constexpr int as_row0(int s) { return (ROLL && (NC == 1 || BIG)) ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
 constexpr int AS_TOTAL_ROWS = 20;
 // layout of LcrDev::warm ([LCR_NWARM][N] floats): the Warm fields of one env between two control steps
-constexpr int WARM_FLOOR = 0, WARM_ARM = 32, WARM_LIM = 62, WARM_WALL = 68, WARM_CC = 84, WARM_CCPREV = 100;   // LCR_NWARM = 104 (lcr_device.h)
+constexpr int WARM_FLOOR = 0, WARM_ARM = 32, WARM_LIM = 62, WARM_WALL = 68, WARM_CC = 84, WARM_CCPREV = 100;   // LCR_DEV_NWARM = 104 (lcr_device.h) = LCR_NWARM (include/lcr.h, where the layout is part of the ABI)
 template <int NC, int NRW>
 struct Warm {
     float floor[NC][4][4];
@@ -1778,7 +1778,7 @@ __global__ __launch_bounds__(256) void lcr_reset_kernel(LcrDev P, const unsigned
     P.ee_lag[e] = ee.x; P.ee_lag[N + e] = ee.y; P.ee_lag[2 * N + e] = ee.z;
     P.elapsed[e] = 0;
     if (P.warm)
-        for (int i = 0; i < LCR_NWARM; i++) P.warm[(size_t)i * N + e] = 0.f;   // no constraint forces carried into a new episode
+        for (int i = 0; i < LCR_DEV_NWARM; i++) P.warm[(size_t)i * N + e] = 0.f;   // no constraint forces carried into a new episode
 }
 
 #if LCR_HAS_PART(0)

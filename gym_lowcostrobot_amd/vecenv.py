@@ -8,6 +8,8 @@ infos[i]["terminal_observation"], and infos[i]["TimeLimit.truncated"] / ["is_suc
 Host cost per step is O(1) python + one packed device-to-host copy (VecSim.fetch_host, 132 B/env) + work proportional to the
 number of envs that finished an episode in this step; there is no per-env python loop.
 """
+import types
+
 import numpy as np
 
 from . import spaces as sp
@@ -35,11 +37,6 @@ def _obs_spaces(sim, observation_mode):
         if sim.task_name == "stack":
             subs["cube_blue_pos"] = sp.Box(-10.0, 10.0, shape=(3,), dtype=np.float32)
     return subs
-
-
-class _InfoList(list):
-    """infos of one step: a real list (SB3 indexes and iterates it) whose entries for envs that did NOT finish an episode all
-    refer to ONE shared dict per step -- building 65 536 dicts per step would dominate the step time."""
 
 
 class LowCostRobotVecEnv(_SB3VecEnv):
@@ -71,17 +68,33 @@ class LowCostRobotVecEnv(_SB3VecEnv):
         if self.observation_mode in ("image", "both"):
             o["image_front"] = sim.image_front.numpy()
             o["image_top"] = sim.image_top.numpy()
-        # copies: the pinned mirror is overwritten by the next fetch (SB3 keeps observations in its rollout buffer)
-        return {k: np.ascontiguousarray(o[k]) for k in self._keys}
+        # forced copies: the pinned mirror is overwritten by the next fetch and freed by close(), and SB3 keeps the returned arrays
+        # in its rollout buffer (np.ascontiguousarray would hand out a VIEW of the mirror when num_envs == 1, where the transposed
+        # (6, 1) view already counts as contiguous); the frames come from a device-to-host copy of their own
+        return {k: (o[k] if k.startswith("image_") else np.array(o[k], copy=True, order="C")) for k in self._keys}
 
     def _obs(self):
         return self._obs_from(self.sim.fetch_host())
 
-    def _terminal(self, tobs_rows):
-        """terminal observation dicts for the rows of `tobs_rows` (k, 18): arm_qpos6, arm_qvel6, cube3, aux3"""
+    def _terminal_frames(self, t, tq_col):
+        """image_front / image_top of a terminal pose: the kernel has already reset the env (its frame buffers show the reset state),
+        so the last frames of the episode are ray-cast from terminal_obs row `t` (18,) + terminal_quat column `tq_col` (8,)"""
         sim = self.sim
+        qpos = np.zeros(sim.nq)
+        qpos[0:6] = t[0:6]; qpos[6:9] = t[12:15]; qpos[9:13] = tq_col[0:4]
+        if sim.task_name == "stack":
+            qpos[13:16] = t[15:18]; qpos[16:20] = tq_col[4:8]
+        tgt = t[15:18] if sim.task_name in ("push", "pick_place") else None
+        return sim.render_state(qpos, tgt, "camera_front"), sim.render_state(qpos, tgt, "camera_top")
+
+    def _terminal(self, tobs_rows, env_ids):
+        """terminal observation dicts -- EXACTLY the keys of observation_space (SB3's VecTransposeImage and the TimeLimit bootstrap of
+        PPO index every key of infos[i]["terminal_observation"]) -- for the rows of `tobs_rows` (k, 18): arm_qpos6, arm_qvel6, cube3, aux3"""
+        sim = self.sim
+        img = self.observation_mode in ("image", "both")
+        tq = sim.terminal_quat.numpy() if img and len(env_ids) else None
         out = []
-        for t in tobs_rows:
+        for t, e in zip(tobs_rows, env_ids):
             d = {"arm_qpos": t[0:6].copy(), "arm_qvel": t[6:12].copy()}
             if sim.task_name in ("push", "pick_place"):
                 d["target_pos"] = t[15:18].copy()
@@ -89,7 +102,9 @@ class LowCostRobotVecEnv(_SB3VecEnv):
                 d[sim.cube_name] = t[12:15].copy()
                 if sim.task_name == "stack":
                     d["cube_blue_pos"] = t[15:18].copy()
-            out.append(d)
+            if img:
+                d["image_front"], d["image_top"] = self._terminal_frames(t, tq[:, e])
+            out.append({k: d[k] for k in self._keys})
         return out
 
     # ---- SB3 VecEnv API ----
@@ -116,13 +131,15 @@ class LowCostRobotVecEnv(_SB3VecEnv):
         term, trunc, dres = h["terminated"], h["truncated"], h["did_reset"]
         dones = term | trunc
         lift = self.task == "lift"
-        shared = {"TimeLimit.truncated": False} if lift else {"is_success": False, "TimeLimit.truncated": False}
-        infos = _InfoList([shared]) * self.num_envs
+        # envs that did NOT finish an episode all refer to ONE read-only mapping per step (65 536 dicts per step would dominate the step
+        # time); a wrapper that tries to write into it fails loudly instead of leaking the key into every env
+        shared = types.MappingProxyType({"TimeLimit.truncated": False} if lift else {"is_success": False, "TimeLimit.truncated": False})
+        infos = [shared] * self.num_envs
         idx = np.nonzero(dones | dres)[0]
         if idx.size:
             tl = trunc[idx] & ~term[idx]
             succ = h["is_success"][idx]
-            tobs = self._terminal(h["terminal_obs"][idx]) if h["terminal_obs"] is not None else [None] * idx.size
+            tobs = self._terminal(h["terminal_obs"][idx], idx) if h["terminal_obs"] is not None else [None] * idx.size
             for j, i in enumerate(idx):
                 d = {"TimeLimit.truncated": bool(tl[j])}
                 if not lift:
@@ -197,6 +214,13 @@ class LowCostRobotVectorEnv:
                 fin[sim.cube_name] = t[:, 12:15].copy()
                 if sim.task_name == "stack":
                     fin["cube_blue_pos"] = t[:, 15:18].copy()
+            if v.observation_mode in ("image", "both"):   # final frames: ray-cast from the terminal poses of the envs that were reset
+                fin["image_front"] = np.zeros((self.num_envs, 240, 320, 3), np.uint8)
+                fin["image_top"] = np.zeros((self.num_envs, 240, 320, 3), np.uint8)
+                tq = sim.terminal_quat.numpy()
+                for e in np.nonzero(h["did_reset"])[0]:
+                    fin["image_front"][e], fin["image_top"][e] = v._terminal_frames(t[e], tq[:, e])
+            fin = {k: fin[k] for k in v._keys}
             infos["final_obs"] = fin
             infos["_final_obs"] = h["did_reset"].copy()
         return obs, h["reward"].copy(), h["terminated"].copy(), h["truncated"].copy(), infos

@@ -305,12 +305,15 @@ class VecSim:
             "qpos": np.zeros((self.nq, N)), "qvel": np.zeros((self.nv, N)), "ee_lag": np.zeros((3, N)),
             "target": np.zeros((3, N), np.float32), "elapsed": np.zeros(N, np.int32), "rng": np.zeros((4, N), np.uint64),
             "current_goal": np.zeros(N, np.int32), "sim_time": np.zeros(N),
+            "warm": np.zeros((_capi.NWARM, N), np.float32),   # carried constraint forces (mjData.qacc_warmstart of the reference's sim)
         }
         check(self.L.lcr_get_state(self.handle, _vp(st["qpos"]), _vp(st["qvel"]), _vp(st["ee_lag"]), _vp(st["target"]),
-                                   _vp(st["elapsed"]), _vp(st["rng"]), _vp(st["current_goal"]), _vp(st["sim_time"])))
+                                   _vp(st["elapsed"]), _vp(st["rng"]), _vp(st["current_goal"]), _vp(st["sim_time"]), _vp(st["warm"])))
         return st
 
-    def set_state(self, qpos=None, qvel=None, ee_lag=None, target=None, elapsed=None, rng=None, current_goal=None, sim_time=None):
+    def set_state(self, qpos=None, qvel=None, ee_lag=None, target=None, elapsed=None, rng=None, current_goal=None, sim_time=None, warm=None):
+        """Overwrite (parts of) the simulator state.  `set_state(**get_state())` is an exact checkpoint restore.  Setting qpos or qvel
+        WITHOUT `warm` drops the carried constraint forces: the next step then starts from a cold solve."""
         N = self.n
 
         def prep(a, shape, dt):
@@ -325,5 +328,6 @@ class VecSim:
         ee_lag, target = prep(ee_lag, (3, N), np.float64), prep(target, (3, N), np.float32)
         elapsed, rng = prep(elapsed, (N,), np.int32), prep(rng, (4, N), np.uint64)
         current_goal, sim_time = prep(current_goal, (N,), np.int32), prep(sim_time, (N,), np.float64)
+        warm = prep(warm, (_capi.NWARM, N), np.float32)
         check(self.L.lcr_set_state(self.handle, _vp(qpos), _vp(qvel), _vp(ee_lag), _vp(target), _vp(elapsed), _vp(rng),
-                                   _vp(current_goal), _vp(sim_time)))
+                                   _vp(current_goal), _vp(sim_time), _vp(warm)))

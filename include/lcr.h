@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LCR_ABI_VERSION 2
+#define LCR_ABI_VERSION 3
 
 typedef enum lcr_status {
     LCR_OK = 0,
@@ -192,12 +192,27 @@ int lcr_get_outputs(lcr_sim *sim, lcr_out_view *out);
 
 /* Full simulator state (replaces poking env.data.qpos / env.data.qvel, e.g. examples/dynamixel_gym_leader.py:96-98;
  * also checkpoint/resume and the "(qpos, qvel, action) triple" parity tests).  Host pointers, any may be
- * NULL, SoA [component][N]; synchronous. */
+ * NULL, SoA [component][N]; synchronous.
+ * `warm` (ABI v3) is the solver state the reference keeps in mjData.qacc_warmstart between env.step calls
+ * (reach_cube_env.py:276-279 never resets it): the constraint forces of the last substep, [LCR_NWARM][N] float32 --
+ *   rows  0..31  floor<->cube      [cube c][vertex slot s][row k]   at 16 c + 4 s + k   (rows: normal, t1, t2, torsion)
+ *   rows 32..61  arm-coupled slots [slot s][row k]                  at 32 + 6 s + k     (s: 0,1 finger<->cube, 2,3 finger<->floor,
+ *                                                                                           4 arm-link proxies; k < 4, or 6 with rolling rows)
+ *   rows 62..67  joint limits      [joint j]                        at 62 + j
+ *   rows 68..83  rails (PushCubeLoop) [slot s][row k]               at 68 + 4 s + k
+ *   rows 84..99  cube<->cube (Stack)  [slot s][row k]               at 84 + 4 s + k
+ *   rows 100..103 cube<->cube slot s was active in the last substep (0.0 / 1.0)
+ * lcr_get_state + lcr_set_state with all arrays including `warm` is an exact checkpoint: the next lcr_step is bit-identical to
+ * the one the un-checkpointed sim would have made.  lcr_set_state with qpos or qvel but warm == NULL clears the carried forces
+ * (cold solve in the first substep of the next step); with LCR_COMPAT_COLD_SOLVE_EACH_STEP nothing is carried: get returns zeros,
+ * set ignores `warm`. */
+#define LCR_NWARM 104
 int lcr_get_state(lcr_sim *sim, double *qpos /*[nq][N]*/, double *qvel /*[nv][N]*/, double *ee_lag /*[3][N]*/,
                   float *target /*[3][N]*/, int32_t *elapsed /*[N]*/, uint64_t *rng /*[4][N]*/,
-                  int32_t *current_goal /*[N]*/, double *sim_time /*[N]*/);
+                  int32_t *current_goal /*[N]*/, double *sim_time /*[N]*/, float *warm /*[LCR_NWARM][N]*/);
 int lcr_set_state(lcr_sim *sim, const double *qpos, const double *qvel, const double *ee_lag, const float *target,
-                  const int32_t *elapsed, const uint64_t *rng, const int32_t *current_goal, const double *sim_time);
+                  const int32_t *elapsed, const uint64_t *rng, const int32_t *current_goal, const double *sim_time,
+                  const float *warm);
 
 /* small device-memory helpers so a ctypes/numpy caller needs no other GPU library */
 int lcr_malloc(lcr_sim *sim, size_t bytes, void **dev_out);

@@ -21,6 +21,27 @@ def test_registry_table_matches_reference_ids():
     assert isinstance(gym_lowcostrobot.REGISTERED, list)
 
 
+def test_reference_import_paths_resolve():
+    """the import statements reference-side code uses (examples/hdf5_record.py:5-6, examples/gym_manipulation_img_multi.py:3,
+    gym_lowcostrobot/envs/__init__.py:1-6 and the entry points of gym_lowcostrobot/__init__.py:9-43) work against this package"""
+    import importlib
+
+    from gym_lowcostrobot.envs.push_cube_env import PushCubeEnv                        # examples/gym_manipulation_img_multi.py:3
+    from gym_lowcostrobot.envs.reach_cube_env import ReachCubeEnv                      # examples/hdf5_record.py:5
+    from gym_lowcostrobot.envs.wrappers.record_hdf5 import RecordHDF5Wrapper           # examples/hdf5_record.py:6
+    from gym_lowcostrobot_amd import recorder
+
+    assert PushCubeEnv is envs.PushCubeEnv and ReachCubeEnv is envs.ReachCubeEnv and RecordHDF5Wrapper is recorder.RecordHDF5Wrapper
+    for mod, cls in [("lift_cube_env", "LiftCubeEnv"), ("pick_place_cube_env", "PickPlaceCubeEnv"), ("push_cube_env", "PushCubeEnv"),
+                     ("reach_cube_env", "ReachCubeEnv"), ("stack_two_cubes_env", "StackTwoCubesEnv"), ("push_cube_loop_env", "PushCubeLoopEnv")]:
+        m = importlib.import_module(f"gym_lowcostrobot.envs.{mod}")                    # envs/__init__.py:1-6 `from .<mod> import <cls>`
+        assert getattr(m, cls) is getattr(envs, cls)
+    for env_id, cls in envs.REGISTRY.items():                                          # entry_point="gym_lowcostrobot.envs:<cls>"
+        pkg, name = f"gym_lowcostrobot.envs:{cls}".split(":")
+        assert getattr(importlib.import_module(pkg), name) is getattr(envs, cls), env_id
+    assert isinstance(gym_lowcostrobot.__version__, str)
+
+
 def test_constructor_validation_precedes_device_use():
     with pytest.raises(ValueError, match="Invalid action mode"):
         envs.ReachCubeEnv(observation_mode="state", action_mode="cartesian")
@@ -270,7 +291,11 @@ def test_vecenv_observation_modes(hip_lib, task, mode):
     for t in range(3):
         obs, rew, dones, infos = v.step(rng.uniform(-1, 1, (n, v.action_space.shape[0])).astype(np.float32))
     assert dones.all() and all("terminal_observation" in i for i in infos)
-    assert set(infos[0]["terminal_observation"]) == {k for k in want if not k.startswith("image")}
+    assert set(infos[0]["terminal_observation"]) == want      # exactly observation_space's keys (SB3 VecTransposeImage indexes every image key)
+    for k, val in infos[0]["terminal_observation"].items():
+        assert val.shape == v.observation_space[k].shape and val.dtype == v.observation_space[k].dtype, k
+    if "image_front" in want:
+        assert infos[0]["terminal_observation"]["image_front"].std() > 5
     if "image_front" in obs:
         assert obs["image_front"].std() > 5
     v.close()
@@ -279,8 +304,29 @@ def test_vecenv_observation_modes(hip_lib, task, mode):
     assert set(o) == want
     o, r, te, tr, inf = g.step(np.zeros((n, g.single_action_space.shape[0]), np.float32))
     o, r, te, tr, inf = g.step(np.zeros((n, g.single_action_space.shape[0]), np.float32))
-    assert tr.all() and inf["_final_obs"].all() and set(inf["final_obs"]) == {k for k in want if not k.startswith("image")}
+    assert tr.all() and inf["_final_obs"].all() and set(inf["final_obs"]) == want
+    if "image_top" in want:
+        assert inf["final_obs"]["image_top"].shape == (n, 240, 320, 3) and inf["final_obs"]["image_top"][n - 1].std() > 5
     g.close()
+
+
+@pytest.mark.gpu
+def test_vecenv_single_env_observations_do_not_alias_the_fetch_buffer(hip_lib):
+    """num_envs == 1: the returned observation arrays are copies -- SB3 puts `self._last_obs` into its rollout buffer AFTER the next
+    env.step, so an array aliasing the pinned fetch mirror would silently hold the NEXT observation"""
+    from gym_lowcostrobot_amd import LowCostRobotVecEnv
+
+    v = LowCostRobotVecEnv("reach", 1, seed=3)
+    obs0 = v.reset()
+    keep = {k: a.copy() for k, a in obs0.items()}
+    obs1, _, _, infos = v.step(np.full((1, 5), 0.8, np.float32))
+    for k in keep:
+        np.testing.assert_array_equal(obs0[k], keep[k])                      # unchanged by the next step's fetch
+    assert np.abs(obs1["arm_qpos"] - obs0["arm_qpos"]).max() > 1e-3
+    with pytest.raises(TypeError):
+        infos[0]["episode"] = 1                                              # the shared per-step info mapping is read-only
+    v.close()
+    np.testing.assert_array_equal(obs0["arm_qpos"], keep["arm_qpos"])        # and they survive close() (hipHostFree of the mirror)
 
 
 @pytest.mark.gpu

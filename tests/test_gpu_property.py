@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 TASKS = ["reach", "lift", "push", "pick_place", "stack", "push_loop"]
 
 
-@settings(max_examples=int(os.environ.get("LCR_HYP_EXAMPLES", "25")),   # (soak runs: LCR_HYP_EXAMPLES=800)
+@settings(max_examples=int(os.environ.get("LCR_HYP_EXAMPLES", "100")),   # (soak runs: LCR_HYP_EXAMPLES=800)
            deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(
     task=st.sampled_from(TASKS),
@@ -26,11 +26,16 @@ TASKS = ["reach", "lift", "push", "pick_place", "stack", "push_loop"]
     impratio=st.sampled_from([1.0, 10.0, 100.0]),
     thr=st.floats(min_value=0.02, max_value=0.2),
     condim=st.sampled_from([None, 4, 6]),
+    solve=st.sampled_from(["carry", "resync_cold", "compat_cold"]),
+    arm_collision=st.booleans(),
     seed=st.integers(min_value=0, max_value=2**40),
 )
-def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, seed):
+def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, solve, arm_collision, seed):
     kw = dict(action_mode=mode, reward_type=reward, n_substeps=n_substeps, pgs_iters=pgs_iters, impratio=impratio,
-              distance_threshold=thr, auto_reset=False, max_episode_steps=0, finger_cube_condim=condim)
+              distance_threshold=thr, auto_reset=False, max_episode_steps=0, finger_cube_condim=condim, arm_collision=arm_collision,
+              # "carry": the default product mode, each step starts from the oracle's carried forces; "resync_cold": default mode, forces
+              # dropped by lcr_set_state; "compat_cold": LCR_COMPAT_COLD_SOLVE_EACH_STEP on both sides (the kernel then has no warm array)
+              compat=2 if solve == "compat_cold" else 0)
     sim, o = util.make_pair(task, n, **kw)
     rng = np.random.default_rng(seed % (2**32))
     seeds = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(seed)) % np.uint64(2**63)
@@ -40,7 +45,7 @@ def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps,
     np.testing.assert_array_equal(st0["rng"], o.rng)
     for t in range(3):
         a = rng.uniform(-1.3, 1.3, (n, sim.action_dim)).astype(np.float32)
-        dq, dv, ok, st1 = util.parity_step(sim, o, a, 3e-5, 5e-3, max_dq=5e-2, max_dv=5.0, where=(task, mode, n_substeps, pgs_iters, t))
+        dq, dv, ok, st1 = util.parity_step(sim, o, a, 3e-5, 5e-3, max_dq=5e-2, max_dv=5.0, where=(task, mode, n_substeps, pgs_iters, solve, t), carry=solve == "carry")
         assert ok.mean() >= min(0.97, 1 - 1.5 / n) or ok.sum() >= n - 1, (t, ok.mean(), np.sort(dq)[-3:], np.sort(dv)[-3:])
         out = sim.outputs()
         same = out["terminated"] == o.terminated.astype(bool)

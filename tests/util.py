@@ -10,16 +10,52 @@ def f32r(x):
     return np.asarray(x, np.float32).astype(np.float64)
 
 
-def sync_oracle_to_f32(o):
+def warm_view(o):
+    """the oracle's carried constraint forces as an (n, 180) array of its scalar type: [0:12] limit rows (2 j + side), then 28 slots x 6 rows
+    (warm_t of oracle/lcr_oracle.c; slot ids: 0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor, 16 link proxies)"""
+    dt = np.float32 if o.L is orc.lib(True) else np.float64
+    return o.warm.view(dt)[:, :180]
+
+
+def sync_oracle_to_f32(o, carry=False):
     o.qpos[:] = f32r(o.qpos)
     o.qvel[:] = f32r(o.qvel)
     o.ee_lag[:] = f32r(o.ee_lag)
+    if carry:
+        w = warm_view(o)
+        w[:] = f32r(w)
 
 
-def push_state(sim, o):
-    """oracle (AoS, env-major) -> HIP sim (SoA).  lcr_set_state drops the constraint forces the sim carried from its last control step
-    (the next step starts with a cold solve); the oracle does the same here."""
-    o.warm[:] = 0
+_ARM_SLOT = (12, 13, 14, 15, 16)   # oracle slot id of the kernel's arm-coupled slot s
+
+
+def warm_o2k(o):
+    """oracle warm records -> the [LCR_NWARM][n] float32 block of lcr_set_state (layout: include/lcr.h)"""
+    w = warm_view(o).astype(np.float64)
+    lim, slot = w[:, :12], w[:, 12:].reshape(o.n, 28, 6)
+    k = np.zeros((104, o.n), np.float32)
+    for c in range(2):
+        for s4 in range(4):
+            k[16 * c + 4 * s4: 16 * c + 4 * s4 + 4] = slot[:, 4 * c + s4, :4].T
+    for s5, sid in enumerate(_ARM_SLOT):
+        k[32 + 6 * s5: 32 + 6 * s5 + 6] = slot[:, sid, :].T
+    k[62:68] = (lim[:, 0::2] + lim[:, 1::2]).T          # one side at most is active (the other is zero)
+    for s4 in range(4):
+        if o.task == orc.TASKS["push_loop"]:
+            k[68 + 4 * s4: 68 + 4 * s4 + 4] = slot[:, 8 + s4, :4].T
+        if o.task == orc.TASKS["stack"]:
+            k[84 + 4 * s4: 84 + 4 * s4 + 4] = slot[:, 8 + s4, :4].T
+            k[100 + s4] = 1.0                             # "was active": an inactive slot carries zeros, which warm-start like no force
+    return k
+
+
+def push_state(sim, o, carry=False):
+    """oracle (AoS, env-major) -> HIP sim (SoA).  carry=False: lcr_set_state without `warm` drops the constraint forces the sim carried
+    from its last control step (the next step starts with a cold solve) and the oracle does the same here.  carry=True: the oracle's
+    carried forces go to the sim as well (ABI v3), so that both sides warm-start the next step from the same forces -- the product's
+    default mode, in which MuJoCo's qacc_warmstart survives from one env.step to the next (reach_cube_env.py:276-279)."""
+    if not carry:
+        o.warm[:] = 0
     sim.set_state(
         qpos=np.ascontiguousarray(o.qpos[:, : sim.nq].T),
         qvel=np.ascontiguousarray(o.qvel[:, : sim.nv].T),
@@ -29,6 +65,7 @@ def push_state(sim, o):
         rng=np.ascontiguousarray(o.rng.T),
         current_goal=o.goal.copy(),
         sim_time=o.sim_time.copy(),
+        warm=warm_o2k(o) if carry else None,
     )
 
 
@@ -93,7 +130,8 @@ def pinch_setup(o, gap=0.0285):
 
 
 MAX_DQ, MAX_DV = 2e-2, 2.0   # bound on explained outliers after one control step (rad or m, rad/s or m/s)
-STATS = {"envs": 0, "out": 0, "out_flip": 0, "out_illcond": 0, "max_dq": 0.0, "max_dv": 0.0}
+STATS = {"envs": 0, "envs_carry": 0, "out": 0, "out_carry": 0, "out_flip": 0, "out_illcond": 0, "max_dq": 0.0, "max_dv": 0.0}
+CARRY_DEFAULT = False   # tests that run a loop in both modes flip this (pytest fixture `carry_mode` in test_gpu_parity.py)
 def _twin(o):
     """the oracle's fp32-arithmetic build (same C source compiled with float) with the same parameters"""
     t = getattr(o, "_f32_twin", None)
@@ -107,7 +145,7 @@ def _twin(o):
     return t
 
 
-def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_DV, where=""):
+def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_DV, where="", carry=None):
     """One re-synchronised control step of the HIP path and the fp64 oracle from identical float32-representable states.
     Returns (dq, dv, ok) per env.  EVERY env outside the tolerance must be explained, by one of two measurable facts:
       (flip)     its discrete-decision signature differs from the oracle's: which constraint slots were active, how many
@@ -116,13 +154,18 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
       (illcond)  the state is ill-conditioned for fp32 arithmetic as such: the oracle's own fp32 build (same C source, float),
                  stepped from the same state, uses up more than a quarter of the tolerance itself (non-converged PGS on a stiff contact set can
                  amplify rounding by orders of magnitude within one control step).
-    Explained outliers still have to stay within max_dq / max_dv."""
-    sync_oracle_to_f32(o)
-    push_state(sim, o)
+    Explained outliers still have to stay within max_dq / max_dv.
+    carry: both sides start the step from the oracle's carried constraint forces (rounded to float32) instead of from zero forces --
+    the product's default mode (forces carried across lcr_step calls); the oracle's forces are whatever its previous step left."""
+    carry = CARRY_DEFAULT if carry is None else carry
+    sync_oracle_to_f32(o, carry)
+    push_state(sim, o, carry)
     t = _twin(o)
     for k in ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time"):
         getattr(t, k)[:] = getattr(o, k)
     t.warm[:] = 0
+    if carry:
+        warm_view(t)[:] = warm_view(o)
     o.step(a, threads=0)
     sim.step(a)
     st = pull_state(sim)
@@ -137,10 +180,11 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
         # (a quarter of the tolerance: two differently formulated fp32 computations may differ a few times more from each other
         #  than one of them does from fp64)
         ill = ((tq > 0.25 * atol_q) | (tv > 0.25 * atol_v)) | (t.active_count != o.active_count) | (t.choice != o.choice)
-        STATS["out"] += int((~ok).sum()); STATS["out_flip"] += int((~ok & flip).sum()); STATS["out_illcond"] += int((~ok & ~flip & ill).sum())
+        STATS["out"] += int((~ok).sum()); STATS["out_carry"] += int((~ok).sum()) if carry else 0; STATS["out_flip"] += int((~ok & flip).sum()); STATS["out_illcond"] += int((~ok & ~flip & ill).sum())
         bad = ~ok & ~flip & ~ill
         assert not bad.any(), (where, np.nonzero(bad)[0][:8], dq[bad][:8], dv[bad][:8])
     STATS["envs"] += sim.n
+    STATS["envs_carry"] += sim.n if carry else 0
     STATS["max_dq"] = max(STATS["max_dq"], float(dq.max())); STATS["max_dv"] = max(STATS["max_dv"], float(dv.max()))
     assert dq.max() <= max_dq and dv.max() <= max_dv, (where, float(dq.max()), float(dv.max()))
     return dq, dv, ok, st
