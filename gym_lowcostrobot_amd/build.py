@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcr_hip.so")
-SOURCES = ["lcr_capi.hip", "lcr_kernels.hip", "lcr_render.hip"]   # (bench.kernel_sha16 and the tools hash / compile these)
-HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", os.path.join("..", "..", "include", "lcr.h")]
+SOURCES = ["lcr_capi.hip", "lcr_kernels.hip", "lcr_kernels2.hip", "lcr_render.hip"]   # (bench.kernel_sha16 and the tools hash / compile these)
+HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", "lcr_step_common.h", os.path.join("..", "..", "include", "lcr.h")]
 # -ffast-math: the kernels carry no NaN/inf/signed-zero semantics (the -0.0 sparse reward is built from its bit pattern,
 # the fp64 reset sampling uses explicitly rounded __dmul_rn/__dadd_rn); -fno-slp-vectorize: packed-f32 formation by the
 # SLP vectoriser costs more moves than it saves here (measured on MI355X: 0.340 ms -> 0.286 ms per 65 536-env step).
@@ -32,7 +32,10 @@ def _newer(target, deps):
 # code each take 80 s in one unit, ~30 s as four units compiled concurrently
 UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
          ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels.hip", "lcr_kernels_walls.o", ["-DLCR_PART=1"]),
-         ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"])]
+         ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
+         # the two-cooperating-waves family (lcr_kernels2.hip): 10 one cube, 11 PushCubeLoop, 12 StackTwoCubes
+         ("lcr_kernels2.hip", "lcr_kernels2.o", ["-DLCR_PART=10"]), ("lcr_kernels2.hip", "lcr_kernels2_walls.o", ["-DLCR_PART=11"]),
+         ("lcr_kernels2.hip", "lcr_kernels2_stack.o", ["-DLCR_PART=12"])]
 
 
 def build(force=False, verbose=False):

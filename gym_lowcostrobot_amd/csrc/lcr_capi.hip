@@ -274,9 +274,22 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.big_lds = (cfg->task == LCR_TASK_STACK && (N + 63) / 64 <= 3 * (size_t)prop.multiProcessorCount) ? 1 : 0;
         if (const char *ov = getenv("LCR_STACK_LDS")) { if (cfg->task == LCR_TASK_STACK) D.big_lds = strcmp(ov, "big") == 0 ? 1 : (strcmp(ov, "small") == 0 ? 0 : D.big_lds); }
         D.walls = loop ? 1 : 0;
+        // step-kernel family.  Shards whose 2 x ceil(N / 64) waves fit the chip's SIMDs one each (<= 32 768 envs on an MI355X: BASELINE configs 4
+        // and 5) run the two-cooperating-waves kernels (lcr_kernels2.hip, variant compiled for one wave per SIMD); larger shards run the
+        // one-wave-per-64-envs kernels until the two-waves-per-SIMD variant is faster (measured: DESIGN.md section 5).
+        // LCR_STEP_KERNEL=single|coop1|coop2 overrides (tests and profiling exercise every family at small sizes).
+        {
+            const size_t waves2 = 2 * ((N + 63) / 64), simds = 4 * (size_t)prop.multiProcessorCount;
+            D.coop = waves2 <= simds ? 1 : 0;
+            if (const char *ov = getenv("LCR_STEP_KERNEL")) {
+                if (strcmp(ov, "single") == 0) D.coop = 0;
+                else if (strcmp(ov, "coop1") == 0) D.coop = 1;
+                else if (strcmp(ov, "coop2") == 0) D.coop = 2;
+            }
+        }
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;
-    D.diag = cfg->diagnostics;   // 2: max_sweeps carries the wave's cycle count instead (profiling aid)
+    D.diag = cfg->diagnostics;   // 2: max_sweeps carries the wave's cycle count instead (profiling aid, one-wave kernels); 3: per-wave phase cycles of the two-wave kernels
     D.pgs_tol = (float)cfg->pgs_tol;
     D.cube_mass = (float)cm;
     D.cube_minv = (float)(1.0 / cm);

@@ -60,6 +60,8 @@ struct LcrDev {
     float inv_mu_fcr2;   // finger<->cube: 1 / mu_roll^2
     int roll;            // 1: finger<->cube slots carry the two rolling rows
     float *warm;         // [LCR_NWARM][n] constraint forces carried from one control step to the next (warm start), or null
+    int coop;            // 0: one wave per 64 envs (lcr_kernels.hip); 1 / 2: two cooperating waves per 64 envs (lcr_kernels2.hip) compiled for
+                         // one / two waves per SIMD (<= 512 / <= 256 registers per lane)
     int big_lds;         // Stack: the shard has at most three waves per CU -> the variant that keeps every g row in LDS (46 / 52 KiB per wave)
 };
 
@@ -72,6 +74,10 @@ struct LcrCam {
 
 // launchers implemented in lcr_kernels.hip / lcr_render.hip (plain C++ linkage, same shared object)
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
+// two-cooperating-waves family (lcr_kernels2.hip); occ = waves per SIMD the variant is compiled for
+int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
+int lcr_launch_step2_walls(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
+int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,
                      unsigned long long base_seed, void *stream);
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,

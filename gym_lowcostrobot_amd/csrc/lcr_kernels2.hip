@@ -1,0 +1,1689 @@
+// lcr_kernels2.hip -- the step kernel as TWO COOPERATING WAVES per 64 environments (gfx950).
+//
+// Why: with one wave per 64 envs (lcr_kernels.hip) a 65 536-env batch puts exactly one wave on each of the 1024 SIMDs, and a lone wave
+// issues one instruction per ~5.2 cycles although a SIMD can issue one per ~2 (tools/ubench/valu_issue.hip): the
+// launch lasts as long as the serial instruction chain of its slowest wave.  A shard of 32 768 envs (BASELINE configs 4 and 5) even
+// leaves half the SIMDs without a wave.  Here a workgroup is two waves that share the 64 envs -- lane l of both waves is env l:
+//
+//   wave A ("arm")   forward kinematics, joint-space inertia + Cholesky, RNE bias, actuation, every contact row that couples into the
+//                    arm (finger spheres, arm-link proxies, joint limits), implicitfast solve + integration of the arm; the action
+//                    head (incl. the IK loop of ee mode) and the fused tail (reward, termination, TimeLimit, auto-reset, write-back);
+//   wave B ("cubes") cube kinematics, floor<->cube / cube<->cube / rail contacts and their rows, integration of the cubes.
+//
+// The two constraint sets touch disjoint unknowns (arm acceleration y vs cube accelerations ca / cal) unless a finger sphere or a gripper
+// proxy touches a cube, so their Gauss-Seidel sweeps are INDEPENDENT chains in almost every (wave, substep) pair and run concurrently --
+// the result is the same as the sequential order limits -> floor -> cube<->cube -> rails -> arm slots of the oracle.  When some lane of
+// the 64 does have an arm<->cube contact ("coupled", wave-uniform per substep), the sweeps are serialised in exactly that order with
+// the cube accelerations handed over through LDS twice per sweep.  Per substep the waves meet at two barriers (uncoupled):
+//
+//   A: cube pose <- LDS | FK, RNE bias, actuation  -X-  y0 = L^-1 tau | arm collision + rows | flag  -B1-  sweeps (arm chain) | y -> LDS  -Y-             -E-  integrate arm
+//   B: FK, inertia M, L = chol(M) -> LDS           -X-  chol(M + hD) | cube collision + rows      -B1-  sweeps (cube chain)             -Y-  qacc, integrate  -E-
+// (wave B owns the joint-space inertia: it repeats the forward kinematics, factors M and M + h(damping + kv) and, at the end of the
+//  substep, turns wave A's y into the joint acceleration -- wave A never holds a 6x6 matrix across its sweeps)
+//
+// At 32 768 envs per GPU the 1024 waves occupy all 1024 SIMDs (one each, up to 512 registers per lane); at 65 536 envs two waves share
+// a SIMD (<= 256 registers per lane, variant OCC = 2) and issue at twice the rate of a lone wave.
+//
+// Reference map: identical to lcr_kernels.hip (apply_action reach_cube_env.py:223-273, 20 x mj_step :276-279, reward / termination
+// :313-348 and the per-task files, reset :297-311); the arithmetic of every block is the one of lcr_kernels.hip, regrouped by owner.
+#include "lcr_step_common.h"
+
+#ifndef LCR_PART
+#define LCR_PART (-1)
+#endif
+#define LCR_HAS_PART(k) (LCR_PART == -1 || LCR_PART == (k))
+
+namespace {
+
+// ---- LDS layout of a workgroup: float index = field * 64 + lane (bank = lane mod 32: conflict-free) ----
+//  [0, GR * LDS_ROW)            g rows of the arm slots            (wave A only)
+//  [.., + CCF)                  Stack: cube<->cube contact records (wave B only)
+//  POSE: NC * 13 fields         cube pose and velocity at the top of a substep: cp3 cq4 cv3 cw3      (B -> A, after barrier E)
+//  ACC : NC * 6 fields          cube accelerations ca, cal: warm-start share of the arm<->cube slots (A -> B at barrier 1) and the
+//                               hand-over of the coupled sweeps (B -> A -> B); after the last substep: B's diagnostics words
+//  FLAG: 1 field                [0]: "coupled" of this substep (A -> B); after the last substep: do_reset per lane (A -> B)
+//  PARK: 16 fields              aref / inv of the finger<->floor slots (wave A only; read once per sweep as 16-B vectors)
+//  further hand-overs reuse these areas in phases where they are idle: Cholesky factor L (B -> A at barrier X) in the g rows of slots
+//  3, 4; scaled arm acceleration y (A -> B at barrier Y) in POSE; joint acceleration qacc (B -> A at barrier E) in ACC
+template <int NC, bool ROLL> struct Lds2 {
+    static constexpr int GR = ROLL ? 24 : 20;
+    static constexpr int G0 = 0;
+    static constexpr int CC0 = GR * LDS_ROW;
+    static constexpr int POSE0 = CC0 + (NC == 2 ? LDS_CC_FLOATS : 0);
+    static constexpr int ACC0 = POSE0 + NC * 13 * 64;
+    static constexpr int FLAG0 = ACC0 + NC * 6 * 64;
+    static constexpr int PARK0 = FLAG0 + 64;                 // aref[4] | inv[4] of the finger<->floor slots 2, 3 as 16-B vectors: [slot][aref|inv][lane][4]
+    static constexpr int TOTAL = PARK0 + 2 * 2 * 64 * 4;
+    // hand-over of the Cholesky factor (21 + 6 floats per lane, wave B -> wave A at barrier X): aliases the g rows of slots 3 and 4,
+    // which wave A writes only after it has read the factor
+    static constexpr int LFAC0 = G0 + (ROLL ? 16 : 12) * LDS_ROW;
+};
+// an arm-coupled slot between set-up and sweeps; its forces live in the carried-force registers Wf[slot][row]
+template <int NRW>
+struct ArmSlot2 {
+    f3 n, t1, t2, rc;
+    float aref[NRW], inv[NRW];
+    float Rn;
+    bool act;
+};
+template <bool ROLL> constexpr int as2_row0(int s) { return ROLL ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
+
+DEV void wg_barrier() { __syncthreads(); }   // s_waitcnt + s_barrier: LDS (and global) writes before it are visible to the partner wave after it
+
+// ================================================================================================
+// wave A: the arm
+// ================================================================================================
+template <int NC, bool EE, bool WALLS, bool ROLL>
+DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *lds, const int lane, const int e, const bool valid) {
+    using LL = Lds2<NC, ROLL>;
+    using namespace lcrm;
+    constexpr int NRW = ROLL ? 6 : 4;
+    const int N = P.n;
+    float q[6], qd[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { q[j] = P.qpos[j * N + e]; qd[j] = P.qvel[j * N + e]; }
+    f3 target = mk(0.f, 0.f, 0.f);
+    if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
+    int elapsed = P.elapsed[e];
+    int goal = WALLS ? P.goal[e] : 0;
+
+    // ---- apply_action (reach_cube_env.py:223-273) ------------------------------------------------
+    float act[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) act[i] = i < P.k ? clampf(action[(size_t)i * N + e], -1.f, 1.f) : 0.f;  // np.clip reach:234
+    float ctrl[6];
+    f3 lag_ee = mk(0.f, 0.f, 0.f);
+    int ik_iters = 0;
+    if (EE) {
+        f3 eel = mk(P.ee_lag[e], P.ee_lag[N + e], P.ee_lag[2 * N + e]);
+        f3 tgt = mk(eel.x + act[0] * 0.05f, eel.y + act[1] * 0.05f, fmaxf(eel.z + act[2] * 0.05f, 0.f));  // reach:241-242
+        // inverse_kinematics (reach:148-221): fixed 10 iterations with a per-lane "frozen" mask instead of break
+        float qk[6], qstate[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { qk[j] = q[j]; qstate[j] = q[j]; }
+        bool done = false;
+        for (int it = 0; it < 10; it++) {
+            ik_iters += done ? 0 : 1;
+            ArmFrames F;
+            arm_frames(qk, F);
+            f3 site = site_pos(F);
+            f3 err = tgt - site;
+            if (!done) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) qstate[j] = qk[j];  // reach:185 writes the sim state (REF-QUIRK-3)
+            }
+            done = done || (dot(err, err) < 0.01f * 0.01f);  // reach:193
+            f3 Jc[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) Jc[j] = cross(joint_axis(F, j), site - F.p[j]);
+            float A[6][6], b[6];
+#pragma unroll
+            for (int a = 0; a < 5; a++) {
+#pragma unroll
+                for (int c2 = 0; c2 <= a; c2++) A[a][c2] = dot(Jc[a], Jc[c2]) + (a == c2 ? 0.15f : 0.f);
+                b[a] = dot(Jc[a], err);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 5; c2++) A[5][c2] = 0.f;
+            A[5][5] = 0.15f; b[5] = 0.f;
+            Chol6 C;
+            chol6(A, C);
+            fsub(C, b);
+            bsub(C, b);
+            float nn = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) nn = fmaf(b[j], b[j], nn);
+            float scale = nn > 1.f ? rsq(nn) : 1.f;  // reach:210-212
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                float qn = clampf(fmaf(b[j] * scale, 0.5f, qk[j]), JLO[j], JHI[j]);  // reach:215, 141-146
+                qk[j] = done ? qk[j] : qn;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ctrl[j] = qk[j]; q[j] = qstate[j]; }
+        if (P.gripper_active) ctrl[5] = clampf(q[5] + act[3] * 0.2f, JLO[5], JHI[5]);  // lift:253-257
+        else ctrl[5] = 0.f;                                                              // reach:247
+    } else {
+        const float TLO[6] = {-3.14159f, -1.5708f, -1.48353f, -1.91986f, -2.96706f, -1.74533f};  // reach:249-250
+        const float THI[6] = {3.14159f, 1.22173f, 1.74533f, 1.91986f, 2.96706f, 0.0523599f};
+#pragma unroll
+        for (int j = 0; j < 5; j++) ctrl[j] = clampf(act[j] + q[j], TLO[j], THI[j]);
+        float ga = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) ga = (i == P.k - 1) ? act[i] : ga;  // lift:264 action[-1]
+        ctrl[5] = P.gripper_active ? clampf(ga + q[5], TLO[5], THI[5]) : 0.f;
+    }
+
+    // carried constraint forces of the arm-coupled slots and the joint limits (LcrDev::warm, see lcr_step_common.h WARM_*)
+    const bool carry = P.warm != nullptr;
+    auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
+    // (the same registers hold a slot's forces during the sweeps: Wf[s][r] is row r of slot s, Wlim[j] the limit force of joint j)
+    float Wf[NAS][NRW], Wlim[6];
+#pragma unroll
+    for (int s = 0; s < NAS; s++)
+#pragma unroll
+        for (int k = 0; k < NRW; k++) Wf[s][k] = wld(WARM_ARM + 6 * s + k);
+#pragma unroll
+    for (int j = 0; j < 6; j++) Wlim[j] = wld(WARM_LIM + j);
+
+    Diag DGtot = {0u, 0u, 0u, 0u};
+    f3 lag_cube[NC];
+    float *xpose = lds + LL::POSE0 + lane, *xacc = lds + LL::ACC0 + lane;
+    int *xflag = reinterpret_cast<int *>(lds + LL::FLAG0);
+    // cube state as wave B last published it (pose + velocity at the top of the substep / after the last one)
+    f3 cp[NC], cv[NC], cw[NC];
+    float cq[NC][4];
+    auto read_pose = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float *pp = xpose + (size_t)c * 13 * 64;
+            cp[c] = mk(pp[0], pp[64], pp[128]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) cq[c][k] = pp[(3 + k) * 64];
+            cv[c] = mk(pp[7 * 64], pp[8 * 64], pp[9 * 64]);
+            cw[c] = mk(pp[10 * 64], pp[11 * 64], pp[12 * 64]);
+        }
+    };
+    {   // wave B owns the actuation: it needs data.ctrl and, after the IK loop's overwrite of qpos (REF-QUIRK-3), the arm configuration
+        float *ph = lds + LL::G0 + lane;   // (g rows of slot 0: not written again before barriers X, X2 of the first substep)
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ph[j * 64] = ctrl[j]; ph[(6 + j) * 64] = q[j]; }
+    }
+    wg_barrier();   // E0: wave B has published the initial cube pose
+    __builtin_amdgcn_s_setprio(2);   // where two waves share a SIMD the arm wave is the longer chain: it wins the issue arbitration
+
+    // profiling aid (lcr_config.diagnostics = 3): cycles of this wave in total / waiting at barriers / before barrier 1, coupled substeps
+    const bool prof = P.diag == 3;
+    long long pf_t0 = prof ? clock64() : 0, pf_wait = 0, pf_pre = 0, pf_mark = 0, pf_wx = 0, pf_we = 0;
+    unsigned pf_coupled = 0;
+    const float minv = P.cube_minv, iinv = P.cube_iinv;
+    for (int sub = 0; sub < P.n_substeps; sub++) {
+        Diag DG = {0u, 0u, 0u, 0u};
+        if (prof) pf_mark = clock64();
+        // ---- position stage --------------------------------------------------------------------------
+        ArmFrames F;
+        arm_frames(q, F);
+        lag_ee = site_pos(F);
+        f3 z[6];
+        // ---- joint-space inertia: composite rigid bodies referenced to the WORLD ORIGIN + armature; Cholesky factor (-> wave B through LDS) ----
+        Chol6 CL;
+        {
+            f3 v0[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { z[j] = joint_axis(F, j); v0[j] = cross(F.p[j], z[j]); }
+            f3 com[6];
+            Sym3 Iw[6];
+            com[0] = local_point(F, 0, C1x, C1y, C1z); Iw[0] = world_inertia(F.X[0], F.Y[0], F.Z[0], I1_xx, I1_xy, I1_xz, I1_yy, I1_yz, I1_zz);
+            com[1] = local_point(F, 1, C2x, C2y, C2z); Iw[1] = world_inertia(F.X[1], F.Y[1], F.Z[1], I2_xx, I2_xy, I2_xz, I2_yy, I2_yz, I2_zz);
+            com[2] = local_point(F, 2, C3x, C3y, C3z); Iw[2] = world_inertia(F.X[2], F.Y[2], F.Z[2], I3_xx, I3_xy, I3_xz, I3_yy, I3_yz, I3_zz);
+            com[3] = local_point(F, 3, C4x, C4y, C4z); Iw[3] = world_inertia(F.X[3], F.Y[3], F.Z[3], I4_xx, I4_xy, I4_xz, I4_yy, I4_yz, I4_zz);
+            com[4] = local_point(F, 4, C5x, C5y, C5z); Iw[4] = world_inertia(F.X[4], F.Y[4], F.Z[4], I5_xx, I5_xy, I5_xz, I5_yy, I5_yz, I5_zz);
+            com[5] = local_point(F, 5, C6x, C6y, C6z); Iw[5] = world_inertia(F.X[5], F.Y[5], F.Z[5], I6_xx, I6_xy, I6_xz, I6_yy, I6_yz, I6_zz);
+            const float mass[6] = {M1, M2, M3, M4, M5, M6};
+            float Mm[6][6];
+            float mc = 0.f;
+            f3 hc = mk(0.f, 0.f, 0.f);
+            Sym3 Ic = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 5; i >= 0; i--) {
+                const float m = mass[i];
+                const f3 c = com[i];
+                const float cc = dot(c, c);
+                mc += m;
+                hc = axpy(m, c, hc);
+                Ic.xx += Iw[i].xx + m * (cc - c.x * c.x);
+                Ic.yy += Iw[i].yy + m * (cc - c.y * c.y);
+                Ic.zz += Iw[i].zz + m * (cc - c.z * c.z);
+                Ic.xy += Iw[i].xy - m * c.x * c.y;
+                Ic.xz += Iw[i].xz - m * c.x * c.z;
+                Ic.yz += Iw[i].yz - m * c.y * c.z;
+                f3 l = axpy(mc, v0[i], cross(z[i], hc));
+                f3 n = symv(Ic, z[i]) + cross(hc, v0[i]);
+#pragma unroll
+                for (int j = 0; j <= i; j++) Mm[i][j] = dot(z[j], n) + dot(v0[j], l);
+                Mm[i][i] += ARMATURE;
+            }
+            chol6(Mm, CL);
+            float *pl = lds + LL::LFAC0 + lane;
+            int k = 0;
+#pragma unroll
+            for (int i = 1; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < i; j++) pl[(k++) * 64] = CL.L[i][j];
+#pragma unroll
+            for (int i = 0; i < 6; i++) pl[(k++) * 64] = CL.id[i];
+        }
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // X: L is in LDS for wave B; wave B's tau (bias + actuation + damping) is in LDS for this wave
+        if (prof) { pf_wait += clock64() - pf_mark; pf_wx += clock64() - pf_mark; }
+        // y = L^T a  (scaled arm acceleration);  y_smooth = L^-1 tau
+        float y[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) y[j] = lds[LL::G0 + lane + j * 64];   // tau from wave B
+        fsub(CL, y);
+        wg_barrier();   // X2: wave B has read L (its LDS place is reused for contact rows from here on)
+        read_pose();    // cube pose and velocity at the top of this substep (wave B published it before barrier Y of the previous one)
+        CubeRot CR[NC];
+        f3 cww[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            CR[c] = quat_to_cols(cq[c]);
+            cww[c] = axpy(cw[c].x, CR[c].X, axpy(cw[c].y, CR[c].Y, cw[c].z * CR[c].Z));
+            lag_cube[c] = cp[c];   // P8: body xpos as left behind by this mj_step
+        }
+
+        // ---- collision + row set-up of the arm-coupled slots (g rows -> LDS).  The share of the warm-start forces that acts on a
+        //      cube is collected in dca / dcal and handed to wave B at barrier 1. ----
+        f3 dca[NC], dcal[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) { dca[c] = mk(0.f, 0.f, 0.f); dcal[c] = mk(0.f, 0.f, 0.f); }
+        ArmSlot2<NRW> AS[NAS];
+        bool slot_any[NAS];
+        bool link_on_cube = false;
+        int link_nj = 3, link_bi = 0;
+        int slot_cube[3] = {0, 0, 0};
+        {
+        const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
+        const float srad[2] = {SPH0r, SPH1r};
+#pragma unroll
+        for (int s = 0; s < NAS; s++) {
+            const int sp = s & 1;
+            const bool may_cube = s < 2 || s == 4;
+            ArmSlot2<NRW> &T = AS[s];
+            f3 pos = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 1.f);
+            float dist = 1.f;
+            int cidx = 0;
+            bool oncube = s < 2;
+            float invw_link = sp == 0 ? INVW_TRAN_L5 : INVW_TRAN_L6;
+            int sel = 0;
+            if (s < 2) {
+                float bestd = 1e30f;
+                bool near_any = false;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const f3 dd = sph[sp] - cp[c];
+                    near_any = near_any || dot(dd, dd) < (srad[sp] + 1.7321f * CH) * (srad[sp] + 1.7321f * CH);
+                }
+                if (__any(near_any))
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const SBHit hit = sphere_box(sph[sp], srad[sp], cp[c], CR[c]);
+                    if (hit.dist < bestd) { bestd = hit.dist; cidx = c; n = hit.n; pos = hit.pos; sel = 8 * c + hit.code; }
+                }
+                dist = bestd;
+                slot_cube[sp] = cidx;
+            } else if (s < 4) {
+                dist = sph[sp].z - srad[sp];
+                pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
+            } else if (P.arm_collision) {
+                const int plink[5] = {2, 2, 3, 4, 5};
+                const float px[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, py[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, pz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};
+                const float pr[5] = {LPX0r, LPX1r, LPX2r, LPX3r, LPX4r};
+                bool near_any = false;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const f3 dd = F.p[4] - cp[c];
+                    near_any = near_any || dot(dd, dd) < (0.0350f + 1.7321f * CH) * (0.0350f + 1.7321f * CH);
+                }
+                const bool wave_near = __any(near_any) != 0;
+                float bestd = 1e30f;
+                int bi = 0;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int L = plink[i];
+                    const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
+                    const float df = cz - pr[i];
+                    if (df < bestd) { bestd = df; bi = i; oncube = false; }
+                    if (i >= 3 && wave_near) {
+                        const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            const SBHit hit = sphere_box(ci, pr[i], cp[c], CR[c]);
+                            if (hit.dist < bestd) { bestd = hit.dist; bi = i; pos = hit.pos; n = hit.n; oncube = true; cidx = c; sel = 32 + 8 * c + hit.code; }
+                        }
+                    }
+                }
+                link_bi = bi;
+                if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
+                sel += 64 * (bi + 1);
+                dist = bestd;
+                link_on_cube = oncube;
+                slot_cube[2] = cidx;
+                link_nj = bi < 2 ? 3 : bi + 2;
+                invw_link = bi < 2 ? INVW_TRAN_L3 : (bi == 2 ? INVW_TRAN_L4 : (bi == 3 ? INVW_TRAN_L5 : INVW_TRAN_L6));
+            }
+            T.act = dist < 0.f;
+            if (P.diag) {
+                if (may_cube && (s < 2 || oncube)) sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : 16;
+                diag_choice(DG, T.act, 12 + s, sel);
+            }
+            slot_any[s] = __any(T.act) != 0;
+#pragma unroll
+            for (int k = 0; k < NRW; k++) { T.aref[k] = 0.f; T.inv[k] = 0.f; }
+            if (!slot_any[s]) {   // nobody touches: no force is carried
+#pragma unroll
+                for (int k = 0; k < NRW; k++) Wf[s][k] = 0.f;
+            }
+            T.Rn = 1.f; T.n = n; T.t1 = mk(0.f, 1.f, 0.f); T.t2 = mk(-1.f, 0.f, 0.f); T.rc = mk(0.f, 0.f, 0.f);
+            if (slot_any[s]) {
+                if (s == 4) {
+                    const float qx[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, qy[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, qz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};
+                    const int ql[5] = {2, 2, 3, 4, 5};
+                    f2v cb = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        const float m = link_bi == i ? 1.f : 0.f;
+                        const int L = ql[i];
+                        const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
+                        cb = f2v{m, m} * ci + cb;
+                    }
+                    if (!oncube) pos = mk(cb.x, cb.y, 0.5f * dist);
+                }
+                if (may_cube) make_frame(n, T.t1, T.t2);
+                auto joint_on = [&](int j) -> bool {
+                    if (s < 4) return j < (sp == 0 ? 5 : 6);
+                    return j < link_nj;
+                };
+                f3 cube_p = mk(0.f, 0.f, 0.f), cube_v = mk(0.f, 0.f, 0.f), cube_w = mk(0.f, 0.f, 0.f);
+                if (may_cube) {
+                    if (NC == 2 && cidx == 1) { cube_p = cp[NC - 1]; cube_v = cv[NC - 1]; cube_w = cww[NC - 1]; }
+                    else { cube_p = cp[0]; cube_v = cv[0]; cube_w = cww[0]; }
+                    T.rc = pos - cube_p;
+                }
+                float imp, Kc, Bc;
+                if (s < 2) { imp = impedance(dist, D0_FC, DW_FC, 1.0f / W_FC); Kc = K_FC; Bc = B_FC; }
+                else if (s < 4) { imp = impedance(dist, D0_FF, DW_FF, 1.0f / W_FF); Kc = K_FF; Bc = B_FF; }
+                else { imp = impedance(dist, D0_DEF, DW_DEF, 1.0f / W_DEF); Kc = K_DEF; Bc = B_DEF; }
+                float Rn = fmaxf((1.f - imp) * rcp(imp) * (invw_link + ((may_cube && oncube) ? minv : 0.f)), 1e-15f);
+                float Rf = Rn * P.inv_impratio;
+                float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
+                T.Rn = Rn;
+                f3 jc[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const bool lit = s < 4 ? j < (sp == 0 ? 5 : 6) : true;
+                    jc[j] = lit ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
+                    if (s == 4 && j >= 3 && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int r = 0; r < as_rows<ROLL>(s); r++) {
+                    f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
+                    if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }
+                    float g[6];
+                    float vel = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        g[j] = r < 3 ? dot(jc[j], d) : (joint_on(j) ? dot(z[j], d) : 0.f);
+                        vel = fmaf(g[j], qd[j], vel);
+                    }
+                    float diagc = 0.f;
+                    if (may_cube) {
+                        float velc;
+                        if (r < 3) {
+                            f3 rxd = cross(T.rc, d);
+                            velc = dot(d, cube_v) + dot(rxd, cube_w);
+                            diagc = minv + iinv * dot(rxd, rxd);
+                        } else {
+                            velc = dot(d, cube_w);
+                            diagc = iinv;
+                        }
+                        if (s == 4) { velc = oncube ? velc : 0.f; diagc = oncube ? diagc : 0.f; }
+                        vel -= velc;
+                    }
+                    fsub(CL, g);
+                    float gg = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) gg = fmaf(g[j], g[j], gg);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float2v gp = {g[2 * k], g[2 * k + 1]};
+                        *reinterpret_cast<float2v *>(&lds[LL::G0 + (as2_row0<ROLL>(s) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
+                    }
+                    float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) Rr = Rf * P.rr_fc;
+                    T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
+                    const bool row_on = T.act && (s != 4 || r < 3 || oncube);
+                    T.inv[r] = row_on ? rcp(gg + diagc + Rr) : 0.f;
+                    const float fw = row_on ? Wf[s][r] : 0.f;
+                    Wf[s][r] = fw;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) y[j] = fmaf(g[j], fw, y[j]);
+                    if (may_cube) {
+                        const float fc = (s == 4 && !oncube) ? 0.f : fw;
+                        f3 dl = r < 3 ? (-minv * fc) * d : mk(0.f, 0.f, 0.f);
+                        f3 da = r < 3 ? (-iinv * fc) * cross(T.rc, d) : (-iinv * fc) * d;
+                        if (NC == 2 && cidx == 1) { dca[NC - 1] = dca[NC - 1] + dl; dcal[NC - 1] = dcal[NC - 1] + da; }
+                        else { dca[0] = dca[0] + dl; dcal[0] = dcal[0] + da; }
+                    }
+                }
+                if (s == 2 || s == 3) {   // park the per-substep constants of the finger<->floor slots (read back once per sweep)
+                    float4v *pk = reinterpret_cast<float4v *>(lds + LL::PARK0) + (size_t)((s - 2) * 2) * 64 + lane;
+                    pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
+                    pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
+                }
+            }
+        }
+        }
+        // ---- joint limits: rows +-e_j.  g_j = L^-1 (sg e_j), regulariser and reference acceleration once per substep ----
+        bool lim_act[6];
+        bool any_lim = false;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            lim_act[j] = (q[j] < JLO[j]) || (q[j] > JHI[j]);
+            if (P.diag) diag_choice(DG, lim_act[j], 18 + j, q[j] < JLO[j] ? 0 : 1);
+            Wlim[j] = lim_act[j] ? Wlim[j] : 0.f;
+            any_lim = any_lim || lim_act[j];
+        }
+        const bool wave_lim = __any(any_lim) != 0;
+        float glim[6][6], lim_aref[6], lim_R[6], lim_inv[6];
+        if (wave_lim) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool lower = q[j] < JLO[j];
+                const float sg = lower ? 1.f : -1.f;
+                const float pos = lower ? q[j] - JLO[j] : JHI[j] - q[j];
+                const float imp = impedance(pos, D0_DEF, DW_DEF, 1.0f / W_DEF);
+                lim_R[j] = fmaxf((1.f - imp) * rcp(imp) * INVW_DOF[j], 1e-15f);
+                lim_aref[j] = -B_DEF * sg * qd[j] - K_DEF * imp * pos;
+#pragma unroll
+                for (int k = 0; k < 6; k++) glim[j][k] = k == j ? sg : 0.f;
+                fsub(CL, glim[j]);
+                float gg = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { gg = fmaf(glim[j][k], glim[j][k], gg); y[k] = fmaf(glim[j][k], Wlim[j], y[k]); }   // (+ warm-start force)
+                lim_inv[j] = rcp(gg + lim_R[j]);
+            }
+        }
+        const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3] || slot_any[4];
+
+        // ---- is any lane's arm in contact with a cube?  (wave-uniform; decides the sweep schedule of BOTH waves) ----
+        const bool coupled = __any(AS[0].act || AS[1].act || (AS[4].act && link_on_cube)) != 0;
+        const bool cube4 = __any(AS[4].act && link_on_cube) != 0;   // a gripper-body proxy is on a cube somewhere in the wave
+        if (lane == 0) xflag[0] = coupled ? 1 : 0;
+        if (coupled) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float *pa = xacc + (size_t)c * 6 * 64;
+                pa[0] = dca[c].x; pa[64] = dca[c].y; pa[128] = dca[c].z;
+                pa[192] = dcal[c].x; pa[256] = dcal[c].y; pa[320] = dcal[c].z;
+            }
+        }
+        if (prof) { const long long t = clock64(); pf_pre += t - pf_mark; pf_mark = t; pf_coupled += coupled ? 1u : 0u; }
+        wg_barrier();   // B1
+        if (prof) pf_wait += clock64() - pf_mark;
+
+        // ---- sweeps ----
+        auto limit_rows = [&]() {
+            if (wave_lim) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    float gy = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) gy = fmaf(glim[j][k], y[k], gy);
+                    const float res = gy - lim_aref[j] + lim_R[j] * Wlim[j];
+                    const float nf = fmaxf(Wlim[j] - res * lim_inv[j], 0.f);
+                    const float dl = lim_act[j] ? nf - Wlim[j] : 0.f;
+                    Wlim[j] += dl;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) y[k] = fmaf(glim[j][k], dl, y[k]);
+                }
+            }
+        };
+        // one Gauss-Seidel pass over the arm-coupled slots.  CPL = false: no lane touches a cube -- slots 0, 1 are off in every lane
+        // and the proxy slot is a floor contact everywhere, so every cube term drops out at compile time.
+        f3 ca[NC], cal[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) { ca[c] = mk(0.f, 0.f, 0.f); cal[c] = mk(0.f, 0.f, 0.f); }
+        auto arm_rows = [&](auto cpl_tag, auto lo_tag, auto hi_tag) {
+            constexpr bool CPL = decltype(cpl_tag)::value;
+            constexpr int S_LO = decltype(lo_tag)::value, S_HI = decltype(hi_tag)::value;
+            if (!wave_arm) return;
+#pragma unroll
+            for (int s = S_LO; s < S_HI; s++) {
+                if (!slot_any[s]) continue;
+                ArmSlot2<NRW> &T = AS[s];
+                const bool may_cube = CPL && (s < 2 || s == 4);
+                const bool oncube = s < 2 || (s == 4 && link_on_cube);
+                const int nrow = (ROLL && s < 2) ? 6 : 4;
+                const float Rf = T.Rn * P.inv_impratio;
+                const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
+                float2v g[NRW][3];
+#pragma unroll
+                for (int r = 0; r < nrow; r++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        g[r][k] = *reinterpret_cast<const float2v *>(&lds[LL::G0 + (as2_row0<ROLL>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
+                float f_in[NRW];
+#pragma unroll
+                for (int r = 0; r < NRW; r++) f_in[r] = Wf[s][r];
+                // slots 2, 3: reference accelerations and inverse diagonals come back from their LDS parking place
+                float arefv[NRW], invv[NRW];
+#pragma unroll
+                for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; }
+                if (s == 2 || s == 3) {
+                    const float4v *pk = reinterpret_cast<const float4v *>(lds + LL::PARK0) + (size_t)((s - 2) * 2) * 64 + lane;
+                    const float4v a4 = pk[0], i4 = pk[64];
+                    arefv[0] = a4.x; arefv[1] = a4.y; arefv[2] = a4.z; arefv[3] = a4.w;
+                    invv[0] = i4.x; invv[1] = i4.y; invv[2] = i4.z; invv[3] = i4.w;
+                }
+                f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
+                const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
+                if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+                const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
+                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f, w1 = 0.f, w2 = 0.f;
+                if (may_cube) {
+                    const f3 Ac = a_lin + cross(a_ang, T.rc);
+                    vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
+                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
+                    wn = dot(T.n, a_ang);
+                    if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
+                    kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
+                    if (s == 4) {
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
+                        wn = oncube ? wn : 0.f;
+                    }
+                }
+                auto couple = [&](int j, float dlt) {
+                    if (j < 3) {
+                        const float c = iinv_e * pq[j] * dlt;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
+                        vq[j] = fmaf(-kq, dlt, vq[j]);
+                        if (j == 1) wn = fmaf(iinv_e * dlt, pq[2], wn);
+                        if (j == 2) wn = fmaf(-iinv_e * dlt, pq[1], wn);
+                        if (nrow == 6) {
+                            if (j == 0) { w1 = fmaf(-iinv_e * dlt, pq[2], w1); w2 = fmaf(iinv_e * dlt, pq[1], w2); }
+                            if (j == 1) w2 = fmaf(-iinv_e * dlt, pq[0], w2);
+                            if (j == 2) w1 = fmaf(iinv_e * dlt, pq[0], w1);
+                        }
+                    } else if (j == 3) {
+                        wn = fmaf(-iinv_e, dlt, wn);
+                        vq[1] = fmaf(iinv_e * dlt, pq[2], vq[1]);
+                        vq[2] = fmaf(-iinv_e * dlt, pq[1], vq[2]);
+                    } else if (j == 4) {
+                        w1 = fmaf(-iinv_e, dlt, w1);
+                        vq[0] = fmaf(-iinv_e * dlt, pq[2], vq[0]);
+                        vq[2] = fmaf(iinv_e * dlt, pq[0], vq[2]);
+                    } else {
+                        w2 = fmaf(-iinv_e, dlt, w2);
+                        vq[0] = fmaf(iinv_e * dlt, pq[1], vq[0]);
+                        vq[1] = fmaf(-iinv_e * dlt, pq[0], vq[1]);
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < nrow; r++) {
+                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                    const float gy = acc.x + acc.y;
+                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) { jc_a = may_cube ? (r == 4 ? -w1 : -w2) : 0.f; Rr = Rf * P.rr_fc; }
+                    float res = gy + jc_a - arefv[r] + Rr * Wf[s][r];
+                    float nf = Wf[s][r] - res * invv[r];
+                    if (r == 0) nf = fmaxf(nf, 0.f);
+                    float dlt = nf - Wf[s][r];
+                    Wf[s][r] += dlt;
+                    {
+                        const float2v d2 = {dlt, dlt};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                    }
+                    if (may_cube) couple(r, dlt);
+                }
+                {   // cone projection (finger geoms: mu 1.5; a link proxy on the floor: mu 1; on a cube: the cube's friction)
+                    float fn = Wf[s][0];
+                    const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
+                    const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
+                    float s2 = (Wf[s][1] * Wf[s][1] + Wf[s][2] * Wf[s][2]) * imu2 + (nrow >= 4 ? Wf[s][3] * Wf[s][3] * imt2 : 0.f);
+                    if constexpr (ROLL) { if (nrow == 6) s2 = fmaf(Wf[s][4] * Wf[s][4] + Wf[s][5] * Wf[s][5], P.inv_mu_fcr2, s2); }
+                    float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+#pragma unroll
+                    for (int r = 1; r < nrow; r++) {
+                        float dlt = Wf[s][r] * sc - Wf[s][r];
+                        Wf[s][r] += dlt;
+                        const float2v d2 = {dlt, dlt};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                    }
+                }
+                y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
+                if (may_cube) {
+                    const float e0 = Wf[s][0] - f_in[0], e1 = Wf[s][1] - f_in[1], e2 = Wf[s][2] - f_in[2], e3 = Wf[s][3] - f_in[3];
+                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));
+                    const f3 dl_lin = (-minv_e) * Fd;
+                    f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
+                    if constexpr (ROLL) { if (nrow == 6) Td = axpy(Wf[s][4] - f_in[4], T.t1, axpy(Wf[s][5] - f_in[5], T.t2, Td)); }
+                    const f3 dl_ang = (-iinv_e) * Td;
+                    if (NC == 2 && second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }
+                    else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I5 = std::integral_constant<int, NAS>;
+        auto read_acc = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float *pa = xacc + (size_t)c * 6 * 64;
+                ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
+            }
+        };
+        auto write_acc = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float *pa = xacc + (size_t)c * 6 * 64;
+                pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
+                pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
+            }
+        };
+        if (!coupled) {
+            for (int it = 0; it < P.pgs_iters; it++) {
+                limit_rows();
+                arm_rows(std::false_type{}, I2{}, I5{});
+            }
+        } else if (!cube4) {
+            // only the finger spheres touch a cube: the cube accelerations go back to wave B right after slots 0, 1, and the rows that touch
+            // only the arm (slots 2-4, the next sweep's limit rows) overlap with wave B's next pass over the cube rows
+            for (int it = 0; it < P.pgs_iters; it++) {
+                limit_rows();
+                if (prof) pf_mark = clock64();
+                wg_barrier();          // wave B has written the cube accelerations after its rows of this sweep
+                if (prof) pf_wait += clock64() - pf_mark;
+                read_acc();
+                arm_rows(std::true_type{}, I0{}, I2{});
+                write_acc();
+                wg_barrier();
+                arm_rows(std::false_type{}, I2{}, I5{});
+            }
+        } else {
+            for (int it = 0; it < P.pgs_iters; it++) {
+                limit_rows();          // (touch only the arm: overlap with wave B's cube rows)
+                if (prof) pf_mark = clock64();
+                wg_barrier();
+                if (prof) pf_wait += clock64() - pf_mark;
+                read_acc();
+                arm_rows(std::true_type{}, I0{}, I5{});
+                write_acc();
+                wg_barrier();
+            }
+        }
+
+        // (the forces stay in Wf / Wlim for the next substep's warm start; slots nobody touched were zeroed at set-up)
+        if (P.diag) {
+            unsigned m = 0u;
+            m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u;
+            m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;
+            m |= AS[4].act ? (1u << 16) : 0u;
+#pragma unroll
+            for (int j = 0; j < 6; j++) m |= lim_act[j] ? (1u << (18 + j)) : 0u;
+            DGtot.mask |= m;
+            DGtot.count += (unsigned)__popc(m);
+            DGtot.choice += DG.choice * (unsigned)(2 * sub + 1);
+        }
+
+        // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y: wave B holds both factors -----------------
+        {
+            float *py = lds + LL::LFAC0 + lane;   // (the contact rows there are dead after the last sweep; wave A rewrites the place only after barrier E)
+#pragma unroll
+            for (int j = 0; j < 6; j++) py[j * 64] = y[j];
+        }
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // Y: y handed to wave B
+        wg_barrier();   // E: wave B has solved for the joint acceleration, integrated the cubes and published their new pose
+        if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const float qacc = xacc[j * 64];
+            qd[j] = fmaf(H, qacc, qd[j]);
+            q[j] = fmaf(H, qd[j], q[j]);
+        }
+    }
+    if (prof && valid) {
+        P.active_mask[e] = (unsigned)(clock64() - pf_t0); P.active_count[e] = (unsigned)pf_wait;
+        P.max_sweeps[e] = (unsigned)pf_pre; P.choice[e] = pf_coupled;
+        P.ctrl_out[(size_t)2 * N + e] = (float)pf_wx; P.ctrl_out[(size_t)3 * N + e] = (float)pf_we;
+    }
+
+    // ================= fused tail (wave A): reward / termination / TimeLimit / auto-reset / write-back =================
+    read_pose();   // final cube state
+    // wave B's diagnostics words (written after the last barrier E, before T1)
+    wg_barrier();   // T1
+    if (P.diag && !prof && valid) {
+        const unsigned *xb = reinterpret_cast<const unsigned *>(xacc);
+        const unsigned bmask = xb[0], bcount = xb[64], bchoice = xb[128];
+        const unsigned mask = DGtot.mask | bmask;
+        P.active_mask[e] = mask; P.active_count[e] = DGtot.count + bcount;
+        P.max_sweeps[e] = mask ? (unsigned)P.pgs_iters : 0u;
+        P.choice[e] = DGtot.choice + bchoice + (unsigned)ik_iters * 0x9E3779B1u;
+#pragma unroll
+        for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];
+    }
+    EnvState<NC> S;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { S.q[j] = q[j]; S.qd[j] = qd[j]; }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        S.cp[c] = cp[c]; S.cv[c] = cv[c]; S.cw[c] = cw[c];
+#pragma unroll
+        for (int k = 0; k < 4; k++) S.cq[c][k] = cq[c][k];
+    }
+    f3 a3, b3;
+    float reward;
+    bool success, terminated;
+    {
+        const int task = P.task;
+        if (task == 0) { a3 = lag_ee; b3 = lag_cube[0]; }
+        else if (task == 4) { a3 = lag_cube[NC - 1]; b3 = mk(lag_cube[0].x, lag_cube[0].y, lag_cube[0].z + 0.03f); }
+        else if (task == 1) { a3 = lag_ee; b3 = lag_cube[0]; }
+        else { a3 = lag_cube[0]; b3 = target; }
+        f3 df = a3 - b3;
+        float d = sqrtf(dot(df, df));
+        if (task == 5) {  // PushCubeLoop get_reward / get_cube_overlap (push_cube_loop_env.py:334-383), FRESH cube position
+            const float xc = S.cp[0].x, yc = S.cp[0].y, wc = 0.0075f;
+            const float gx = goal ? -0.06f : 0.06f, gy = 0.135f;
+            const float gh0 = 0.0095f, gh1 = 0.0145f;
+            const float xo = fmaxf(0.f, fminf(xc + wc, gx + gh0) - fmaxf(xc - wc, gx - gh0));
+            const float yo = fmaxf(0.f, fminf(yc + wc, gy + gh1) - fmaxf(yc - wc, gy - gh1));
+            const float overlap = xo * yo * (1.f / (4.f * 0.0075f * 0.0075f));
+            success = overlap > 0.95f;
+            terminated = false;
+            const float edge = -gh1 + gy;
+            reward = success ? 5.f : (overlap > 0.f ? overlap - 1.f : clampf(-fabsf(yc - edge) * (1.f / 0.16f) - 1.f, -2.f, -1.f));
+            if (success) goal = 1 - goal;
+        } else if (task == 1) {
+            reward = (lag_cube[0].z - P.height_thr) + d;
+            success = false; terminated = false;
+        } else {
+            success = d < P.dist_thr;
+            terminated = success;
+            reward = P.reward_type == 0 ? __uint_as_float(0x80000000u | (d > P.dist_thr ? 0x3f800000u : 0u)) : -d;
+        }
+    }
+    bool diverged = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++) diverged = diverged || bad_value(S.q[j]) || bad_value(S.qd[j]);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        diverged = diverged || bad_value(S.cp[c].x) || bad_value(S.cp[c].y) || bad_value(S.cp[c].z);
+        diverged = diverged || bad_value(S.cv[c].x) || bad_value(S.cv[c].y) || bad_value(S.cv[c].z);
+        diverged = diverged || bad_value(S.cw[c].x) || bad_value(S.cw[c].y) || bad_value(S.cw[c].z);
+#pragma unroll
+        for (int k = 0; k < 4; k++) diverged = diverged || bad_value(S.cq[c][k]);
+    }
+    if (diverged) { reward = -1.0f; success = false; terminated = false; }
+    elapsed += 1;
+    const bool truncated = diverged || (P.max_steps > 0 && elapsed >= P.max_steps);
+    const bool do_reset = diverged || (P.auto_reset && (terminated || truncated));
+    reinterpret_cast<int *>(lds + LL::FLAG0)[lane] = do_reset ? 1 : 0;   // wave B zeroes its carried forces where the env was reset
+    wg_barrier();   // T2
+    if (valid) {
+        P.reward[e] = reward;
+        P.terminated[e] = terminated;
+        P.truncated[e] = truncated;
+        P.is_success[e] = success;
+        P.did_reset[e] = do_reset;
+    }
+    if (do_reset) {
+        if (valid) {
+            write_obs18<NC>(P, P.term_obs, e, S, target);
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) P.term_quat[(size_t)(4 * c + k) * N + e] = S.cq[c][k];
+        }
+        Pcg g = load_rng(P, e);
+        reset_env<NC>(P, S, g, target, lag_ee, goal);
+        if (diverged) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) S.qd[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) { S.cv[c] = mk(0.f, 0.f, 0.f); S.cw[c] = mk(0.f, 0.f, 0.f); }
+        }
+        if (valid) {
+            store_rng(P, e, g);
+            if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }
+        }
+        elapsed = 0;
+    }
+    if (valid) {
+        store_state<NC>(P, e, S);
+        P.elapsed[e] = elapsed;
+        P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
+        if (WALLS) P.goal[e] = goal;
+        if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);
+    }
+    if (carry && valid) {
+        auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
+#pragma unroll
+        for (int s = 0; s < NAS; s++)
+#pragma unroll
+            for (int k = 0; k < NRW; k++) wst(WARM_ARM + 6 * s + k, Wf[s][k]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) wst(WARM_LIM + j, Wlim[j]);
+    }
+}
+
+// ================================================================================================
+// wave B: the cubes
+// ================================================================================================
+template <int NC, bool EE, bool WALLS, bool ROLL>
+DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, const bool valid) {
+    using LL = Lds2<NC, ROLL>;
+    using namespace lcrm;
+    const int N = P.n;
+    // this wave's copy of the arm configuration (for the joint-space inertia): it starts from the configuration wave A leaves behind
+    // after apply_action (ee mode: the IK overwrite of qpos, REF-QUIRK-3, arrives through LDS) and is integrated with the same qacc
+    float q[6], qd[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { q[j] = P.qpos[j * N + e]; qd[j] = P.qvel[j * N + e]; }
+    f3 cp[NC], cv[NC], cw[NC];
+    float cq[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const float *qp = P.qpos + (size_t)(6 + 7 * c) * N + e;
+        const float *qv = P.qvel + (size_t)(6 + 6 * c) * N + e;
+        cp[c] = mk(qp[0], qp[N], qp[2 * N]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cq[c][k] = qp[(3 + k) * N];
+        cv[c] = mk(qv[0], qv[N], qv[2 * N]);
+        cw[c] = mk(qv[3 * N], qv[4 * N], qv[5 * N]);
+        // quaternions are kept normalised from here on (the integration below normalises; this covers states set from outside)
+        const float n2 = cq[c][0] * cq[c][0] + cq[c][1] * cq[c][1] + cq[c][2] * cq[c][2] + cq[c][3] * cq[c][3];
+        const float in = rsq(n2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cq[c][k] *= in;
+    }
+    float *xpose = lds + LL::POSE0 + lane, *xacc = lds + LL::ACC0 + lane;
+    const int *xflag = reinterpret_cast<const int *>(lds + LL::FLAG0);
+    auto publish_pose = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float *pp = xpose + (size_t)c * 13 * 64;
+            pp[0] = cp[c].x; pp[64] = cp[c].y; pp[128] = cp[c].z;
+#pragma unroll
+            for (int k = 0; k < 4; k++) pp[(3 + k) * 64] = cq[c][k];
+            pp[7 * 64] = cv[c].x; pp[8 * 64] = cv[c].y; pp[9 * 64] = cv[c].z;
+            pp[10 * 64] = cw[c].x; pp[11 * 64] = cw[c].y; pp[12 * 64] = cw[c].z;
+        }
+    };
+    const bool carry = P.warm != nullptr;
+    auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
+    float Wfloor[NC][4][4], Wwall[4][4];
+    bool cc_prev[4] = {false, false, false, false};
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) Wfloor[c][s][k] = wld(WARM_FLOOR + 16 * c + 4 * s + k);
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) Wwall[s][k] = WALLS ? wld(WARM_WALL + 4 * s + k) : 0.f;
+    float *ccl = lds + LL::CC0 + lane;   // Stack: record field k of slot s at ccl[(s * CC_REC + k) * 64]
+    const size_t CS = 64;
+    if constexpr (NC == 2) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            cc_prev[s] = wld(WARM_CCPREV + s) != 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(WARM_CC + 4 * s + r);
+        }
+    }
+    publish_pose();
+    wg_barrier();   // E0
+    float ctrl[6];
+    {   // wave A's actuator targets and post-IK arm configuration
+        const float *ph = lds + LL::G0 + lane;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ctrl[j] = ph[j * 64]; q[j] = ph[(6 + j) * 64]; }
+    }
+
+    const bool prof = P.diag == 3;   // profiling aid: cycles of this wave in total / waiting at barriers -> ctrl_out[0], [1]
+    long long pf_t0 = prof ? clock64() : 0, pf_wait = 0, pf_mark = 0;
+    Diag DGtot = {0u, 0u, 0u, 0u};
+    const float minv = P.cube_minv, iinv = P.cube_iinv;
+    for (int sub = 0; sub < P.n_substeps; sub++) {
+        Diag DG = {0u, 0u, 0u, 0u};
+        // ---- smooth joint forces: recursive Newton-Euler bias (zero joint acceleration, base accelerating at -g), passive damping and the
+        //      position actuators (ctrlrange == joint range via inheritrange; joint-level force clamp) -> tau -> wave A.  The inertia
+        //      tensors are applied in the link frames (R Ic R^T v as three small products). ----
+        {
+            ArmFrames F;
+            arm_frames(q, F);
+            f3 z[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) z[j] = joint_axis(F, j);
+            f3 com[6];
+            com[0] = local_point(F, 0, C1x, C1y, C1z); com[1] = local_point(F, 1, C2x, C2y, C2z); com[2] = local_point(F, 2, C3x, C3y, C3z);
+            com[3] = local_point(F, 3, C4x, C4y, C4z); com[4] = local_point(F, 4, C5x, C5y, C5z); com[5] = local_point(F, 5, C6x, C6y, C6z);
+            const float mass[6] = {M1, M2, M3, M4, M5, M6};
+            const float IC[6][6] = {{I1_xx, I1_xy, I1_xz, I1_yy, I1_yz, I1_zz}, {I2_xx, I2_xy, I2_xz, I2_yy, I2_yz, I2_zz}, {I3_xx, I3_xy, I3_xz, I3_yy, I3_yz, I3_zz},
+                                    {I4_xx, I4_xy, I4_xz, I4_yy, I4_yz, I4_zz}, {I5_xx, I5_xy, I5_xz, I5_yy, I5_yz, I5_zz}, {I6_xx, I6_xy, I6_xz, I6_yy, I6_yz, I6_zz}};
+            auto inertia_apply = [&](int i, f3 v) -> f3 {
+                const f3 l = mk(dot(F.X[i], v), dot(F.Y[i], v), dot(F.Z[i], v));
+                const float ax = fmaf(IC[i][0], l.x, fmaf(IC[i][1], l.y, IC[i][2] * l.z));
+                const float ay = fmaf(IC[i][1], l.x, fmaf(IC[i][3], l.y, IC[i][4] * l.z));
+                const float az = fmaf(IC[i][2], l.x, fmaf(IC[i][4], l.y, IC[i][5] * l.z));
+                return axpy(ax, F.X[i], axpy(ay, F.Y[i], az * F.Z[i]));
+            };
+            f3 w = mk(0.f, 0.f, 0.f), wd = mk(0.f, 0.f, 0.f), a = mk(0.f, 0.f, GRAV), pprev = mk(0.f, 0.f, 0.f);
+            f3 Fi[6], Ni[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                f3 r = F.p[i] - pprev;
+                a = a + cross(wd, r) + wxwxr(w, r, dot(w, w));
+                f3 zq = qd[i] * z[i];
+                wd = wd + cross(w, zq);
+                w = w + zq;
+                f3 rc = com[i] - F.p[i];
+                f3 ac = a + cross(wd, rc) + wxwxr(w, rc, dot(w, w));
+                Fi[i] = mass[i] * ac;
+                Ni[i] = inertia_apply(i, wd) + cross(w, inertia_apply(i, w));
+                pprev = F.p[i];
+            }
+            f3 f = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 5; i >= 0; i--) {
+                f3 nn = Ni[i] + cross(com[i] - F.p[i], Fi[i]);
+                if (i < 5) nn = nn + n + cross(F.p[i + 1] - F.p[i], f);
+                f = f + Fi[i];
+                n = nn;
+                const float bias = dot(z[i], n);
+                const float c = clampf(ctrl[i], JLO[i], JHI[i]);
+                const float fa = clampf(fmaf(KP, c - q[i], -KV * qd[i]), -FRC, FRC);
+                lds[LL::G0 + lane + i * 64] = fa - DAMPING * qd[i] - bias;   // tau_i -> wave A (g rows of slot 0: idle between wave A's last sweep and its next row set-up)
+            }
+        }
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // X: tau is in LDS for wave A; wave A's Cholesky factor of the joint-space inertia is in LDS
+        if (prof) pf_wait += clock64() - pf_mark;
+        Chol6 CL;
+        {
+            const float *pl = lds + LL::LFAC0 + lane;
+            int k = 0;
+#pragma unroll
+            for (int i = 1; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < i; j++) CL.L[i][j] = pl[(k++) * 64];
+#pragma unroll
+            for (int i = 0; i < 6; i++) CL.id[i] = pl[(k++) * 64];
+        }
+        wg_barrier();   // X2: the factor has been read -- wave A may overwrite its LDS place with contact rows
+        // factor of M + h (damping + kv) I for the implicitfast solve at the end of the substep, M = L L^T rebuilt from the factor
+        Chol6 CL2;
+        {
+            float Lf[6][6], Mm[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) Lf[i][j] = i == j ? rcp(CL.id[i]) : CL.L[i][j];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int k = 0; k <= j; k++) m = fmaf(Lf[i][k], Lf[j][k], m);
+                    Mm[i][j] = m + (i == j ? H * (DAMPING + KV) : 0.f);
+                }
+            chol6(Mm, CL2);
+        }
+
+        CubeRot CR[NC];
+        f3 ca[NC], cal[NC], cww[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            CR[c] = quat_to_cols(cq[c]);
+            ca[c] = mk(0.f, 0.f, -GRAV);
+            cal[c] = mk(0.f, 0.f, 0.f);
+            cww[c] = axpy(cw[c].x, CR[c].X, axpy(cw[c].y, CR[c].Y, cw[c].z * CR[c].Z));
+        }
+        // ---- collision: floor <-> cube (MuJoCo plane-box: penetrating vertices in index order, at most 4) ----
+        FloorSlot FS[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) { FS[c][s].act = false; FS[c][s].r = mk(0.f, 0.f, 0.f); FS[c][s].Rn = 1.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { FS[c][s].f[k] = 0.f; FS[c][s].aref[k] = 0.f; FS[c][s].inv[k] = 0.f; } }
+            float sdist[4] = {0.f, 0.f, 0.f, 0.f};
+            const f3 hx = CH * CR[c].X, hy = CH * CR[c].Y, hz = CH * CR[c].Z;
+            f3 rv[8];
+            float vd[8];
+            bool lower_same = true, upper_none = true;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                f3 a = (i & 1) ? hx : neg(hx), b = (i & 2) ? hy : neg(hy), d = (i & 4) ? hz : neg(hz);
+                rv[i] = a + b + d;
+                vd[i] = cp[c].z + rv[i].z;
+                if (i >= 4) upper_none = upper_none && !(vd[i] < 0.f);
+                else if (i > 0) lower_same = lower_same && ((vd[i] < 0.f) == (vd[0] < 0.f));
+            }
+            if (__all(lower_same && upper_none)) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    FS[c][s].r = mk(rv[s].x, rv[s].y, rv[s].z - 0.5f * vd[s]);
+                    sdist[s] = vd[s];
+                    FS[c][s].act = vd[s] < 0.f;
+                    if (P.diag) diag_choice(DG, FS[c][s].act, 4 * c + s, s);
+                }
+            } else {
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float dist = vd[i];
+                    bool pen = dist < 0.f && cnt < 4;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        bool take = pen && cnt == s;
+                        FS[c][s].r.x = take ? rv[i].x : FS[c][s].r.x;
+                        FS[c][s].r.y = take ? rv[i].y : FS[c][s].r.y;
+                        FS[c][s].r.z = take ? rv[i].z - 0.5f * dist : FS[c][s].r.z;
+                        sdist[s] = take ? dist : sdist[s];
+                        FS[c][s].act = FS[c][s].act || take;
+                        if (P.diag) diag_choice(DG, take, 4 * c + s, i);
+                    }
+                    cnt += pen ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                FloorSlot &T = FS[c][s];
+                float imp = impedance(sdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
+                float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
+                float Rf = Rn * P.inv_impratio;
+                float Rt = Rf * P.rt_cube;
+                T.Rn = Rn;
+                f3 vp = cv[c] + cross(cww[c], T.r);
+                T.aref[0] = -B_DEF * vp.z - K_DEF * imp * sdist[s];
+                T.aref[1] = -B_DEF * vp.y;
+                T.aref[2] = B_DEF * vp.x;
+                T.aref[3] = -B_DEF * cww[c].z;
+                T.inv[0] = T.act ? rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn) : 0.f;
+                T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
+                T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
+                T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { T.f[k] = T.act ? Wfloor[c][s][k] : 0.f; }
+                const f3 r = T.r;
+                ca[c].z = fmaf(minv, T.f[0], ca[c].z);
+                ca[c].y = fmaf(minv, T.f[1], ca[c].y);
+                ca[c].x = fmaf(-minv, T.f[2], ca[c].x);
+                cal[c].x = fmaf(iinv, r.y * T.f[0] - r.z * T.f[1], cal[c].x);
+                cal[c].y = fmaf(iinv, -r.x * T.f[0] - r.z * T.f[2], cal[c].y);
+                cal[c].z = fmaf(iinv, r.x * T.f[1] + r.y * T.f[2] + T.f[3], cal[c].z);
+            }
+        }
+
+        // ---- collision: cube <-> cube (Stack); records in LDS (this wave only) ----
+        bool cc_act[4] = {false, false, false, false};
+        bool cc_any = false;
+        f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
+        if constexpr (NC == 2) {
+            const f3 dc = cp[1] - cp[0];
+            const f3 ax0[3] = {CR[0].X, CR[0].Y, CR[0].Z}, ax1[3] = {CR[1].X, CR[1].Y, CR[1].Z};
+            float best = -1e30f, bsgn = 1.f;
+            int bax = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const f3 n = a < 3 ? ax0[a] : ax1[a - 3];
+                float ext = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; j++) ext += fabsf(dot(n, a < 3 ? ax1[j] : ax0[j])) * CH;
+                float dd = dot(n, dc);
+                float sep = fabsf(dd) - CH - ext;
+                if (sep > best) { best = sep; bax = a; bsgn = dd < 0.f ? -1.f : 1.f; }
+            }
+            const bool touching = best < 0.f;
+            int cnt = 0;
+            f3 cpos[4];
+            float cdist[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; s++) cpos[s] = mk(0.f, 0.f, 0.f);
+            if (__any(touching)) {
+                const bool Ais0 = bax < 3;
+                const int k = Ais0 ? bax : bax - 3;
+                auto sel3 = [](int i, f3 a, f3 b, f3 c) { return i == 0 ? a : (i == 1 ? b : c); };
+                const f3 AX = Ais0 ? CR[0].X : CR[1].X, AY = Ais0 ? CR[0].Y : CR[1].Y, AZ = Ais0 ? CR[0].Z : CR[1].Z;
+                const f3 BX = Ais0 ? CR[1].X : CR[0].X, BY = Ais0 ? CR[1].Y : CR[0].Y, BZ = Ais0 ? CR[1].Z : CR[0].Z;
+                const f3 cA = Ais0 ? cp[0] : cp[1], cB = Ais0 ? cp[1] : cp[0];
+                ccn = bsgn * sel3(k, AX, AY, AZ);
+                const f3 m = Ais0 ? ccn : neg(ccn);
+                const f3 u = sel3(k, AY, AZ, AX), v = sel3(k, AZ, AX, AY);
+                const float md0 = dot(m, BX), md1 = dot(m, BY), md2 = dot(m, BZ);
+                int kb = 0; float bd = fabsf(md0);
+                if (fabsf(md1) > bd) { bd = fabsf(md1); kb = 1; }
+                if (fabsf(md2) > bd) { bd = fabsf(md2); kb = 2; }
+                const float mdk = kb == 0 ? md0 : (kb == 1 ? md1 : md2);
+                const float sB = mdk > 0.f ? -1.f : 1.f;
+                const f3 nb = sB * sel3(kb, BX, BY, BZ);
+                const f3 pa = sel3(kb, BY, BZ, BX), qa = sel3(kb, BZ, BX, BY);
+                const f3 fB = axpy(CH, nb, cB);
+                const float mnb = dot(m, nb);
+                const float tol = 1e-4f;
+                const float SP[4] = {1.f, -1.f, -1.f, 1.f}, SQ[4] = {1.f, 1.f, -1.f, -1.f};
+                f3 V[4];
+                float Vu[4], Vv[4], Vd[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    V[i] = axpy(CH * SP[i], pa, axpy(CH * SQ[i], qa, fB));
+                    f3 d = V[i] - cA;
+                    Vu[i] = dot(d, u); Vv[i] = dot(d, v); Vd[i] = dot(d, m) - CH;
+                }
+                float skey[4] = {0.f, 0.f, 0.f, 0.f};
+                int sidx[4] = {-1, -1, -1, -1};
+                auto consider = [&](bool ok, int cand, f3 Pp, float dist, float cu, float cv_) {
+                    const float key[4] = {cu + cv_, -cu + cv_, -cu - cv_, cu - cv_};
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        bool t = ok && (sidx[s] < 0 || key[s] > skey[s]);
+                        skey[s] = t ? key[s] : skey[s];
+                        sidx[s] = t ? cand : sidx[s];
+                        cdist[s] = t ? dist : cdist[s];
+                        cpos[s].x = t ? Pp.x : cpos[s].x; cpos[s].y = t ? Pp.y : cpos[s].y; cpos[s].z = t ? Pp.z : cpos[s].z;
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    bool ok = touching && !(fabsf(Vu[i]) > CH + tol || fabsf(Vv[i]) > CH + tol) && Vd[i] < 0.f;
+                    consider(ok, i, axpy(-0.5f * Vd[i], m, V[i]), Vd[i], Vu[i], Vv[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    f3 a = axpy(CH, m, axpy(CH * SP[j], u, axpy(CH * SQ[j], v, cA)));
+                    f3 d = a - fB;
+                    float t = -dot(d, nb) * rcp(mnb);
+                    bool ok = touching && mnb < -0.5f && !(fabsf(dot(d, pa)) > CH + tol || fabsf(dot(d, qa)) > CH + tol) && t < 0.f;
+                    consider(ok, 4 + j, axpy(0.5f * t, m, a), t, SP[j] * CH, SQ[j] * CH);
+                }
+#pragma unroll
+                for (int ed = 0; ed < 4; ed++) {
+                    const int e2 = (ed + 1) & 3;
+#pragma unroll
+                    for (int l = 0; l < 4; l++) {
+                        const bool on_u = l < 2;
+                        const float sg = (l & 1) ? -1.f : 1.f;
+                        const float cP = on_u ? Vu[ed] : Vv[ed], cQ = on_u ? Vu[e2] : Vv[e2];
+                        const float oP = on_u ? Vv[ed] : Vu[ed], oQ = on_u ? Vv[e2] : Vu[e2];
+                        const float fP = cP - sg * CH, fQ = cQ - sg * CH;
+                        const bool cross_ = (fP < 0.f && fQ > 0.f) || (fP > 0.f && fQ < 0.f);
+                        const float t = fP * rcp(cross_ ? fP - fQ : 1.f);
+                        const float ot = fmaf(t, oQ - oP, oP);
+                        const float d = fmaf(t, Vd[e2] - Vd[ed], Vd[ed]);
+                        bool ok = touching && cross_ && !(fabsf(ot) > CH + tol) && d < 0.f;
+                        f3 X = axpy(t, V[e2] - V[ed], V[ed]);
+                        consider(ok, 8 + 4 * ed + l, axpy(-0.5f * d, m, X), d, on_u ? sg * CH : ot, on_u ? ot : sg * CH);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    bool dup = false;
+#pragma unroll
+                    for (int s2 = 0; s2 < s; s2++) dup = dup || (sidx[s2] == sidx[s]);
+                    cc_act[s] = sidx[s] >= 0 && !dup;
+                    cnt += cc_act[s] ? 1 : 0;
+                    if (P.diag) diag_choice(DG, cc_act[s], 8 + s, sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0.f ? 1 : 0));
+                }
+            }
+            cc_any = __any(cnt > 0) != 0;
+            if (cc_any) {
+                make_frame(ccn, cct1, cct2);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const f3 r0 = cpos[s] - cp[0], r1 = cpos[s] - cp[1];
+                    float imp = impedance(cdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
+                    float Rn = fmaxf((1.f - imp) * rcp(imp) * (2.f * minv), 1e-15f);
+                    float Rf = Rn * P.inv_impratio;
+                    float Rt = Rf * P.rt_cube;
+                    f3 vrel = (cv[1] + cross(cww[1], r1)) - (cv[0] + cross(cww[0], r0));
+                    f3 wrel = cww[1] - cww[0];
+                    ccl[(size_t)(s * CC_REC + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CC_REC + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CC_REC + 2) * CS] = cpos[s].z;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
+                        float vel = r < 3 ? dot(d, vrel) : dot(d, wrel);
+                        float aref = -B_DEF * vel - (r == 0 ? K_DEF * imp * cdist[s] : 0.f);
+                        float diag;
+                        if (r < 3) { f3 a0 = cross(r0, d), a1 = cross(r1, d); diag = 2.f * minv + iinv * (dot(a0, a0) + dot(a1, a1)); }
+                        else diag = 2.f * iinv;
+                        float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                        {
+                            float fw = (cc_act[s] && cc_prev[s]) ? ccl[(size_t)(s * CC_REC + 3 + r) * CS] : 0.f;
+                            ccl[(size_t)(s * CC_REC + 3 + r) * CS] = fw;
+                            if (r < 3) {
+                                f3 a0 = cross(r0, d), a1 = cross(r1, d);
+                                ca[1] = axpy(minv * fw, d, ca[1]); ca[0] = axpy(-minv * fw, d, ca[0]);
+                                cal[1] = axpy(iinv * fw, a1, cal[1]); cal[0] = axpy(-iinv * fw, a0, cal[0]);
+                            } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
+                        }
+                        ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
+                        ccl[(size_t)(s * CC_REC + 11 + r) * CS] = cc_act[s] ? rcp(diag + Rr) : 0.f;
+                    }
+                    ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
+                }
+            }
+        }
+
+        // ---- collision: PushCubeLoop rails (inner faces of the four wall boxes, see lcr_kernels.hip) ----
+        FloorSlot WS[4];
+        float wsg[2] = {1.f, 1.f};
+        bool wall_any = false;
+        if constexpr (WALLS) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) { WS[s].act = false; WS[s].r = mk(0.f, 0.f, 0.f); WS[s].Rn = 1.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { WS[s].f[k] = 0.f; WS[s].aref[k] = 0.f; WS[s].inv[k] = 0.f; } }
+            f3 vw[8];
+            float worst = 1.f;
+            bool lo_x = false, lo_y = false;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
+                vw[i] = axpy(sx, CR[0].X, axpy(sy, CR[0].Y, sz * CR[0].Z));
+                const f3 p = vw[i] + cp[0];
+                const bool low = p.z < WALL_TOP;
+                const float dmin = fminf(fminf(p.x + WALL_X, WALL_X - p.x), fminf(p.y - WALL_Y0, WALL_Y1 - p.y));
+                worst = fminf(worst, low ? dmin : 1.f);
+                lo_x = lo_x || (low && p.x + WALL_X < 0.f);
+                lo_y = lo_y || (low && p.y - WALL_Y0 < 0.f);
+            }
+            wall_any = __any(worst < 0.f) != 0;
+            if (wall_any) {
+                wsg[0] = lo_x ? 1.f : -1.f;
+                wsg[1] = lo_y ? 1.f : -1.f;
+#pragma unroll
+                for (int pr = 0; pr < 2; pr++) {
+                    const float sg = wsg[pr];
+                    const float off = pr == 0 ? WALL_X : (sg > 0.f ? -WALL_Y0 : WALL_Y1);
+                    float d1 = 0.f, d2 = 0.f;
+                    bool h1 = false, h2 = false;
+                    f3 r1 = mk(0.f, 0.f, 0.f), r2 = mk(0.f, 0.f, 0.f);
+                    int i1 = 0, i2 = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const f3 p = vw[i] + cp[0];
+                        const float dist = fmaf(sg, pr == 0 ? p.x : p.y, off);
+                        const bool pen = dist < 0.f && p.z < WALL_TOP;
+                        const bool first = pen && (!h1 || dist < d1);
+                        const bool second = pen && !first && (!h2 || dist < d2);
+                        if (P.diag) { i2 = first ? i1 : (second ? i : i2); i1 = first ? i : i1; }
+                        d2 = first ? d1 : (second ? dist : d2);
+                        r2 = first ? r1 : (second ? vw[i] : r2);
+                        h2 = first ? h1 : (second ? true : h2);
+                        d1 = first ? dist : d1;
+                        r1 = first ? vw[i] : r1;
+                        h1 = h1 || first;
+                    }
+                    const f3 v = pr == 0 ? cv[0] : mk(cv[0].y, cv[0].z, cv[0].x);
+                    const f3 w = pr == 0 ? cww[0] : mk(cww[0].y, cww[0].z, cww[0].x);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        FloorSlot &T = WS[2 * pr + c];
+                        const float dist = c == 0 ? d1 : d2;
+                        const f3 rw = c == 0 ? r1 : r2;
+                        T.act = c == 0 ? h1 : h2;
+                        if (P.diag) diag_choice(DG, T.act, 8 + 2 * pr + c, (c == 0 ? i1 : i2) + 8 * (2 * pr + (sg > 0.f ? 0 : 1)));
+                        f3 r = pr == 0 ? rw : mk(rw.y, rw.z, rw.x);
+                        r.x = fmaf(-0.5f * dist, sg, r.x);
+                        T.r = r;
+                        float imp = impedance(dist, D0_DEF, DW_DEF, 1.0f / W_DEF);
+                        float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
+                        float Rf = Rn * P.inv_impratio;
+                        float Rt = Rf * P.rt_cube;
+                        T.Rn = Rn;
+                        const f3 vp = v + cross(w, r);
+                        T.aref[0] = -B_DEF * sg * vp.x - K_DEF * imp * dist;
+                        T.aref[1] = -B_DEF * vp.y;
+                        T.aref[2] = -B_DEF * sg * vp.z;
+                        T.aref[3] = -B_DEF * sg * w.x;
+                        T.inv[0] = T.act ? rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn) : 0.f;
+                        T.inv[1] = T.act ? rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf) : 0.f;
+                        T.inv[2] = T.act ? rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf) : 0.f;
+                        T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) T.f[k] = T.act ? Wwall[2 * pr + c][k] : 0.f;
+                        const float la = minv * sg * T.f[0], lb = minv * T.f[1], lc = minv * sg * T.f[2];
+                        const float aa = iinv * (-r.z * T.f[1] + sg * r.y * T.f[2] + sg * T.f[3]);
+                        const float ab = iinv * sg * (r.z * T.f[0] - r.x * T.f[2]);
+                        const float ac = iinv * (-sg * r.y * T.f[0] + r.x * T.f[1]);
+                        if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
+                        else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
+                    }
+                }
+            }
+        }
+
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // B1: wave A has set up its rows and decided whether this substep is coupled
+        if (prof) pf_wait += clock64() - pf_mark;
+        const bool coupled = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // (scalar: the barriers below sit under this branch)
+        if (coupled) {   // warm-start forces of the arm<->cube slots act on the cubes too
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float *pa = xacc + (size_t)c * 6 * 64;
+                ca[c] = ca[c] + mk(pa[0], pa[64], pa[128]); cal[c] = cal[c] + mk(pa[192], pa[256], pa[320]);
+            }
+        }
+
+        // ---- one Gauss-Seidel pass over the rows that touch only the cubes ----
+        auto cube_rows = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    FloorSlot &T = FS[c][s];
+                    const f3 r = T.r;
+                    const float Rf = T.Rn * P.inv_impratio;
+                    const float Rt = Rf * P.rt_cube;
+                    const float u0 = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - T.aref[0] + T.Rn * T.f[0];
+                    const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * T.f[1];
+                    const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * T.f[2];
+                    const float u3 = cal[c].z - T.aref[3] + Rt * T.f[3];
+                    const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
+                    float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
+                    const float d0 = nf - T.f[0];
+                    const float d1a = -(u1 + B01 * d0) * T.inv[1];
+                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
+                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
+                    const float fn = T.f[0] + d0;
+                    const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                    const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
+                    T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                    ca[c].z = fmaf(minv, d0, ca[c].z);
+                    ca[c].y = fmaf(minv, d1, ca[c].y);
+                    ca[c].x = fmaf(-minv, d2, ca[c].x);
+                    cal[c].x = fmaf(iinv, r.y * d0 - r.z * d1, cal[c].x);
+                    cal[c].y = fmaf(iinv, -r.x * d0 - r.z * d2, cal[c].y);
+                    cal[c].z = fmaf(iinv, fmaf(r.x, d1, fmaf(r.y, d2, d3)), cal[c].z);
+                }
+            }
+            if constexpr (NC == 2) {
+                if (cc_any) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const f3 pos = mk(ccl[(size_t)(s * CC_REC + 0) * CS], ccl[(size_t)(s * CC_REC + 1) * CS], ccl[(size_t)(s * CC_REC + 2) * CS]);
+                        const f3 r0 = pos - cp[0], r1 = pos - cp[1];
+                        const float Rn = ccl[(size_t)(s * CC_REC + 15) * CS];
+                        const float Rf = Rn * P.inv_impratio;
+                        const float Rt = Rf * P.rt_cube;
+                        float f[4], aref[4], inv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            f[r] = ccl[(size_t)(s * CC_REC + 3 + r) * CS];
+                            aref[r] = ccl[(size_t)(s * CC_REC + 7 + r) * CS];
+                            inv[r] = ccl[(size_t)(s * CC_REC + 11 + r) * CS];
+                        }
+                        const f3 A = (ca[1] + cross(cal[1], r1)) - (ca[0] + cross(cal[0], r0));
+                        const f3 Wr = cal[1] - cal[0];
+                        const float u0 = dot(ccn, A) - aref[0] + Rn * f[0];
+                        const float u1 = dot(cct1, A) - aref[1] + Rf * f[1];
+                        const float u2 = dot(cct2, A) - aref[2] + Rf * f[2];
+                        const float u3 = dot(ccn, Wr) - aref[3] + Rt * f[3];
+                        const float p00 = dot(r0, ccn), p01 = dot(r0, cct1), p02 = dot(r0, cct2);
+                        const float p10 = dot(r1, ccn), p11 = dot(r1, cct1), p12 = dot(r1, cct2);
+                        const float B01 = -iinv * (p00 * p01 + p10 * p11), B02 = -iinv * (p00 * p02 + p10 * p12), B12 = -iinv * (p01 * p02 + p11 * p12);
+                        const float B13 = -iinv * (p02 + p12), B23 = iinv * (p01 + p11);
+                        const float nf = fmaxf(f[0] - u0 * inv[0], 0.f);
+                        const float d0 = nf - f[0];
+                        const float d1a = -(u1 + B01 * d0) * inv[1];
+                        const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv[2];
+                        const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv[3];
+                        const float fn = f[0] + d0;
+                        const float g1 = f[1] + d1a, g2 = f[2] + d2a, g3 = f[3] + d3a;
+                        const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                        const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                        const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
+                        ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
+                        ccl[(size_t)(s * CC_REC + 5) * CS] = f[2] + e2; ccl[(size_t)(s * CC_REC + 6) * CS] = f[3] + e3;
+                        const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
+                        const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
+                        ca[1] = axpy(minv, Fd, ca[1]); ca[0] = axpy(-minv, Fd, ca[0]);
+                        cal[1] = axpy(iinv, T1, cal[1]); cal[0] = axpy(-iinv, T0, cal[0]);
+                    }
+                }
+            }
+            if constexpr (WALLS) {
+                if (wall_any) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        FloorSlot &T = WS[s];
+                        const int pr = s >> 1;
+                        const float sg = wsg[pr];
+                        const f3 r = T.r;
+                        const float Rf = T.Rn * P.inv_impratio, Rt = Rf * P.rt_cube;
+                        const f3 a = pr == 0 ? ca[0] : mk(ca[0].y, ca[0].z, ca[0].x);
+                        const f3 w = pr == 0 ? cal[0] : mk(cal[0].y, cal[0].z, cal[0].x);
+                        const float u0 = sg * (a.x + r.z * w.y - r.y * w.z) - T.aref[0] + T.Rn * T.f[0];
+                        const float u1 = a.y - r.z * w.x + r.x * w.z - T.aref[1] + Rf * T.f[1];
+                        const float u2 = sg * (a.z + r.y * w.x - r.x * w.y) - T.aref[2] + Rf * T.f[2];
+                        const float u3 = sg * w.x - T.aref[3] + Rt * T.f[3];
+                        const float B01 = -sg * iinv * r.x * r.y, B02 = -iinv * r.x * r.z, B12 = -sg * iinv * r.y * r.z;
+                        const float B13 = -sg * iinv * r.z, B23 = iinv * r.y;
+                        const float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
+                        const float d0 = nf - T.f[0];
+                        const float d1a = -(u1 + B01 * d0) * T.inv[1];
+                        const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
+                        const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
+                        const float fn = T.f[0] + d0;
+                        const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                        const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                        const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                        const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
+                        T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                        const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
+                        const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
+                        const float ab = iinv * sg * (r.z * d0 - r.x * d2);
+                        const float ac = iinv * (-sg * r.y * d0 + r.x * d1);
+                        if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
+                        else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
+                    }
+                }
+            }
+        };
+        if (!coupled) {
+            for (int it = 0; it < P.pgs_iters; it++) cube_rows();
+        } else {
+            for (int it = 0; it < P.pgs_iters; it++) {
+                cube_rows();
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    float *pa = xacc + (size_t)c * 6 * 64;
+                    pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
+                    pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
+                }
+                if (prof) pf_mark = clock64();
+                wg_barrier();   // -> wave A: arm slots of this sweep (incl. the arm<->cube rows)
+                wg_barrier();   // <- wave A
+                if (prof) pf_wait += clock64() - pf_mark;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float *pa = xacc + (size_t)c * 6 * 64;
+                    ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
+                }
+            }
+        }
+
+        // ---- keep the forces for the next substep's warm start (inactive slots hold zero) ----------------
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) Wfloor[c][s][k] = FS[c][s].f[k];
+#pragma unroll
+        for (int s = 0; s < 4; s++) cc_prev[s] = cc_act[s];
+        if constexpr (WALLS) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) Wwall[s][k] = WS[s].f[k];
+        }
+        if (P.diag) {
+            unsigned m = 0u;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) m |= FS[c][s].act ? (1u << (4 * c + s)) : 0u;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
+                if (WALLS) m |= WS[s].act ? (1u << (8 + s)) : 0u;
+            }
+            DGtot.mask |= m;
+            DGtot.count += (unsigned)__popc(m);
+            DGtot.choice += DG.choice * (unsigned)(2 * sub + 1);
+        }
+
+        // ---- integrate the cubes ----
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            cv[c] = axpy(H, ca[c], cv[c]);
+            f3 ab = mk(dot(CR[c].X, cal[c]), dot(CR[c].Y, cal[c]), dot(CR[c].Z, cal[c]));
+            cw[c] = axpy(H, ab, cw[c]);
+            cp[c] = axpy(H, cv[c], cp[c]);
+            f3 w = cw[c];
+            float wn2 = dot(w, w);
+            if (wn2 > 0.f) {
+                float iw = rsq(wn2), wn = wn2 * iw;
+                float sh, chf;
+                sincos_small(0.5f * H * wn, &sh, &chf);
+                float s = sh * iw;
+                float dq0 = chf, dq1 = w.x * s, dq2 = w.y * s, dq3 = w.z * s;
+                float q0 = cq[c][0], q1 = cq[c][1], q2 = cq[c][2], q3 = cq[c][3];
+                float r0 = q0 * dq0 - q1 * dq1 - q2 * dq2 - q3 * dq3;
+                float r1 = q0 * dq1 + q1 * dq0 + q2 * dq3 - q3 * dq2;
+                float r2 = q0 * dq2 - q1 * dq3 + q2 * dq0 + q3 * dq1;
+                float r3 = q0 * dq3 + q1 * dq2 - q2 * dq1 + q3 * dq0;
+                float in = rsq(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+                cq[c][0] = r0 * in; cq[c][1] = r1 * in; cq[c][2] = r2 * in; cq[c][3] = r3 * in;
+            }
+        }
+        publish_pose();   // (before barrier Y: this wave finishes its sweeps first, the integration is off the critical path)
+        // ---- implicitfast solve for the arm: (M + h (damping + kv) I) qacc = L y, y from wave A ----
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // Y
+        if (prof) pf_wait += clock64() - pf_mark;
+        {
+            float yv[6], rhs[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) yv[j] = lds[LL::LFAC0 + lane + j * 64];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                float s = rcp(CL.id[i]) * yv[i];  // L_ii y_i
+#pragma unroll
+                for (int k = 0; k < i; k++) s = fmaf(CL.L[i][k], yv[k], s);
+                rhs[i] = s;
+            }
+            fsub(CL2, rhs);
+            bsub(CL2, rhs);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                xacc[j * 64] = rhs[j];
+                qd[j] = fmaf(H, rhs[j], qd[j]);
+                q[j] = fmaf(H, qd[j], q[j]);
+            }
+        }
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // E
+        if (prof) pf_wait += clock64() - pf_mark;
+    }
+    if (prof && valid) { P.ctrl_out[e] = (float)(clock64() - pf_t0); P.ctrl_out[(size_t)N + e] = (float)pf_wait; }
+    // diagnostics words of this wave -> wave A (the ACC area is free now)
+    if (P.diag && !prof) {
+        unsigned *xb = reinterpret_cast<unsigned *>(xacc);
+        xb[0] = DGtot.mask; xb[64] = DGtot.count; xb[128] = DGtot.choice;
+    }
+    wg_barrier();   // T1
+    wg_barrier();   // T2: wave A has decided which envs are reset
+    const bool do_reset = reinterpret_cast<const int *>(lds + LL::FLAG0)[lane] != 0;
+    if (carry && valid) {
+        auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) wst(WARM_FLOOR + 16 * c + 4 * s + k, Wfloor[c][s][k]);
+        if constexpr (WALLS) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) wst(WARM_WALL + 4 * s + k, Wwall[s][k]);
+        }
+        if constexpr (NC == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                wst(WARM_CCPREV + s, cc_prev[s] ? 1.f : 0.f);
+#pragma unroll
+                for (int r = 0; r < 4; r++) wst(WARM_CC + 4 * s + r, cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel: workgroup = 2 waves x 64 lanes over 64 envs.  OCC = waves per SIMD the register budget must allow
+// (1: up to 512 registers per lane -- shards that put at most one wave on a SIMD; 2: <= 256)
+// ------------------------------------------------------------------------------------------------
+template <int NC, bool EE, bool WALLS, bool ROLL, int OCC>
+__global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const float *__restrict__ action) {
+    __shared__ float lds[Lds2<NC, ROLL>::TOTAL];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int e_raw = blockIdx.x * 64 + lane;
+    const bool valid = e_raw < P.n;
+    const int e = valid ? e_raw : P.n - 1;   // tail lanes shadow the last env, their stores are masked
+#if defined(LCR2_ONLY_ARM)        // (register-budget study only: one role compiled alone; such a kernel must not be launched)
+    arm_program<NC, EE, WALLS, ROLL>(P, action, lds, lane, e, valid);
+#elif defined(LCR2_ONLY_CUBE)
+    cube_program<NC, EE, WALLS, ROLL>(P, lds, lane, e, valid);
+#else
+    if (wave == 0) arm_program<NC, EE, WALLS, ROLL>(P, action, lds, lane, e, valid);
+    else cube_program<NC, EE, WALLS, ROLL>(P, lds, lane, e, valid);
+#endif
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers.  build.py compiles this file once per LCR_PART (10: one cube, 11: PushCubeLoop, 12: StackTwoCubes)
+// ------------------------------------------------------------------------------------------------
+static int check_launch2() {
+    hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : (int)err;
+}
+
+template <int NC, bool WALLS>
+static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode, int occ, hipStream_t st) {
+    const int blocks = (P.n + 63) / 64;
+#define LCR2_GO(EE, ROLL, OCC) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, WALLS, ROLL, OCC>), dim3(blocks), dim3(128), 0, st, P, action_dev)
+    if (occ >= 2) {
+        if (ee_mode) { if (P.roll) LCR2_GO(true, true, 2); else LCR2_GO(true, false, 2); }
+        else { if (P.roll) LCR2_GO(false, true, 2); else LCR2_GO(false, false, 2); }
+    } else {
+        if (ee_mode) { if (P.roll) LCR2_GO(true, true, 1); else LCR2_GO(true, false, 1); }
+        else { if (P.roll) LCR2_GO(false, true, 1); else LCR2_GO(false, false, 1); }
+    }
+#undef LCR2_GO
+    return check_launch2();
+}
+
+#if LCR_HAS_PART(10)
+int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
+    return launch2_family<1, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+}
+#endif
+#if LCR_HAS_PART(11)
+int lcr_launch_step2_walls(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
+    return launch2_family<1, true>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+}
+#endif
+#if LCR_HAS_PART(12)
+int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
+    return launch2_family<2, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+}
+#endif

@@ -104,7 +104,7 @@ class VecSim:
         cfg.base_seed = int(base_seed)
         cfg.arm_collision = int(bool(arm_collision))
         cfg.pgs_tol = float(pgs_tol)
-        cfg.diagnostics = int(bool(diagnostics))
+        cfg.diagnostics = int(diagnostics)   # True / 1: decision signature; 2, 3: per-wave cycle read-back (profiling aids)
         if finger_cube_condim is not None:   # default: lcr_config_default's choice for the task (6 for PushCubeLoop, else 4)
             cfg.finger_cube_condim = int(finger_cube_condim)
         self.cfg = cfg

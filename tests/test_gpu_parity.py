@@ -678,17 +678,17 @@ def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which
     forces the second variant at test sizes."""
     monkeypatch.setenv("LCR_STACK_LDS", "small")
     if which == "rollout_joint":
-        test_step_rollout_vs_oracle(hip_lib, "stack", "joint")
+        test_step_rollout_vs_oracle(hip_lib, monkeypatch, "stack", "joint", True)
     elif which == "rollout_ee":
-        test_step_rollout_vs_oracle(hip_lib, "stack", "ee")
+        test_step_rollout_vs_oracle(hip_lib, monkeypatch, "stack", "ee", False)
     elif which == "cube_on_cube":
-        test_stack_cube_on_cube_contacts(hip_lib)
+        test_stack_cube_on_cube_contacts(hip_lib, monkeypatch, True)
     elif which == "rolling_rows":
-        test_rolling_rows_finger_cube_condim6(hip_lib, "stack")
+        test_rolling_rows_finger_cube_condim6(hip_lib, monkeypatch, "stack", True)
     elif which == "link_proxy":
-        test_link_proxy_contacts(hip_lib, "stack", 16, False, "joint")
+        test_link_proxy_contacts(hip_lib, monkeypatch, "stack", 16, False, "joint", True)
     else:
-        test_converged_solver_mode(hip_lib, "stack")
+        test_converged_solver_mode(hip_lib, monkeypatch, "stack", False)
 
 
 def test_stack_variants_are_bit_identical(hip_lib, monkeypatch):
