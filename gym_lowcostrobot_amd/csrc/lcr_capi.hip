@@ -211,7 +211,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_goal = off; off += al(sizeof(int) * N);
     size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
-    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 4 ? 24 : 48) * N);   // (+ the rolling rows of the finger slots)   // g rows of the arm-link proxy slot (Stack keeps its cube<->cube records in LDS instead)
+    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 4 ? 24 : 48) * N);   // Stack (one-wave kernels): g rows of the arm-link proxy slot (+ the rolling rows of the finger slots)
     const bool carry_warm = !(cfg->compat & LCR_COMPAT_COLD_SOLVE_EACH_STEP);
     size_t o_warm = off; if (carry_warm) off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps
     size_t o_act = off; off += al(sizeof(float) * 6 * N);

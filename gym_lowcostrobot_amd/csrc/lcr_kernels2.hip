@@ -82,11 +82,6 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     float q[6], qd[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) { q[j] = P.qpos[j * N + e]; qd[j] = P.qvel[j * N + e]; }
-    f3 target = mk(0.f, 0.f, 0.f);
-    if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
-    int elapsed = P.elapsed[e];
-    int goal = WALLS ? P.goal[e] : 0;
-
     // ---- apply_action (reach_cube_env.py:223-273) ------------------------------------------------
     float act[6];
 #pragma unroll
@@ -155,13 +150,18 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         ctrl[5] = P.gripper_active ? clampf(ga + q[5], TLO[5], THI[5]) : 0.f;
     }
 
+    if (P.diag && P.diag != 3 && valid) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];   // data.ctrl as apply_action left it (reach_cube_env.py:273)
+    }
     // carried constraint forces of the arm-coupled slots and the joint limits (LcrDev::warm, see lcr_step_common.h WARM_*)
     const bool carry = P.warm != nullptr;
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
     // (the same registers hold a slot's forces during the sweeps: Wf[s][r] is row r of slot s, Wlim[j] the limit force of joint j)
+    // (this wave owns slots 2-4: finger<->floor and the arm-link proxies; the finger<->cube slots 0, 1 belong to wave B)
     float Wf[NAS][NRW], Wlim[6];
 #pragma unroll
-    for (int s = 0; s < NAS; s++)
+    for (int s = 2; s < NAS; s++)
 #pragma unroll
         for (int k = 0; k < NRW; k++) Wf[s][k] = wld(WARM_ARM + 6 * s + k);
 #pragma unroll
@@ -262,8 +262,9 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 #pragma unroll
         for (int j = 0; j < 6; j++) y[j] = lds[LL::G0 + lane + j * 64];   // tau from wave B
         fsub(CL, y);
-        wg_barrier();   // X2: wave B has read L (its LDS place is reused for contact rows from here on)
         read_pose();    // cube pose and velocity at the top of this substep (wave B published it before barrier Y of the previous one)
+        wg_barrier();   // X2: wave B has read L (its LDS place is reused for contact rows from here on); this wave has read the pose
+                        //     (wave B reuses the first fields of the pose area for the finger<->cube slots' warm-start share of y)
         CubeRot CR[NC];
         f3 cww[NC];
 #pragma unroll
@@ -286,8 +287,9 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         {
         const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
         const float srad[2] = {SPH0r, SPH1r};
+        slot_any[0] = false; slot_any[1] = false;
 #pragma unroll
-        for (int s = 0; s < NAS; s++) {
+        for (int s = 2; s < NAS; s++) {
             const int sp = s & 1;
             const bool may_cube = s < 2 || s == 4;
             ArmSlot2<NRW> &T = AS[s];
@@ -495,23 +497,31 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 lim_inv[j] = rcp(gg + lim_R[j]);
             }
         }
-        const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3] || slot_any[4];
+        const bool wave_arm = slot_any[2] || slot_any[3] || slot_any[4];
 
-        // ---- is any lane's arm in contact with a cube?  (wave-uniform; decides the sweep schedule of BOTH waves) ----
-        const bool coupled = __any(AS[0].act || AS[1].act || (AS[4].act && link_on_cube)) != 0;
-        const bool cube4 = __any(AS[4].act && link_on_cube) != 0;   // a gripper-body proxy is on a cube somewhere in the wave
-        if (lane == 0) xflag[0] = coupled ? 1 : 0;
-        if (coupled) {
+        // ---- does a gripper-body proxy of some lane touch a cube?  (wave-uniform; with wave B's "a finger sphere touches a cube" it
+        //      decides the sweep schedule of BOTH waves) ----
+        const bool cube4 = __any(AS[4].act && link_on_cube) != 0;
+        if (lane == 0) xflag[1] = cube4 ? 1 : 0;
+        if (cube4) {   // share of slot 4's warm-start forces that acts on a cube
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                float *pa = xacc + (size_t)c * 6 * 64;
+                // (pose area behind wave B's dy01: the ACC area may be overwritten by this wave's y hand-over before wave B has read it)
+                float *pa = xpose + (size_t)(6 + c * 6) * 64;
                 pa[0] = dca[c].x; pa[64] = dca[c].y; pa[128] = dca[c].z;
                 pa[192] = dcal[c].x; pa[256] = dcal[c].y; pa[320] = dcal[c].z;
             }
         }
-        if (prof) { const long long t = clock64(); pf_pre += t - pf_mark; pf_mark = t; pf_coupled += coupled ? 1u : 0u; }
+        if (prof) { const long long t = clock64(); pf_pre += t - pf_mark; pf_mark = t; }
         wg_barrier();   // B1
         if (prof) pf_wait += clock64() - pf_mark;
+        const bool c01 = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // wave B: a finger sphere touches a cube in some lane
+        const bool coupled = c01 || cube4;
+        if (prof) pf_coupled += coupled ? 1u : 0u;
+        if (c01) {   // warm-start forces of the finger<->cube slots act on the arm too: wave B's sum of g_r f_r
+#pragma unroll
+            for (int j = 0; j < 6; j++) y[j] += xpose[j * 64];
+        }
 
         // ---- sweeps ----
         auto limit_rows = [&]() {
@@ -661,59 +671,79 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 }
             }
         };
-        using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I5 = std::integral_constant<int, NAS>;
-        auto read_acc = [&]() {
+        using I2 = std::integral_constant<int, 2>; using I5 = std::integral_constant<int, NAS>;
+        using I4 = std::integral_constant<int, 4>;
+        float *xcc_ = lds + LL::POSE0 + lane;   // hand-over place of the cube accelerations in coupled sweeps (the pose area is idle then)
+        auto read_cube_acc = [&]() {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const float *pa = xacc + (size_t)c * 6 * 64;
+                const float *pa = xcc_ + (size_t)c * 6 * 64;
                 ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
             }
         };
-        auto write_acc = [&]() {
+        auto write_cube_acc = [&]() {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                float *pa = xacc + (size_t)c * 6 * 64;
+                float *pa = xcc_ + (size_t)c * 6 * 64;
                 pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
                 pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
             }
+        };
+        auto bar = [&]() {
+            if (prof) pf_mark = clock64();
+            wg_barrier();
+            if (prof) pf_wait += clock64() - pf_mark;
         };
         if (!coupled) {
             for (int it = 0; it < P.pgs_iters; it++) {
                 limit_rows();
                 arm_rows(std::false_type{}, I2{}, I5{});
             }
-        } else if (!cube4) {
-            // only the finger spheres touch a cube: the cube accelerations go back to wave B right after slots 0, 1, and the rows that touch
-            // only the arm (slots 2-4, the next sweep's limit rows) overlap with wave B's next pass over the cube rows
+        } else if (c01 && !cube4) {
+            // finger spheres on a cube: the arm acceleration y visits wave B between the limit rows and slots 2-4 (Gauss-Seidel order
+            // limits -> cube rows -> slots 0, 1 -> slots 2-4); wave B's next pass over the cube rows overlaps with slots 2-4 here
             for (int it = 0; it < P.pgs_iters; it++) {
                 limit_rows();
-                if (prof) pf_mark = clock64();
-                wg_barrier();          // wave B has written the cube accelerations after its rows of this sweep
-                if (prof) pf_wait += clock64() - pf_mark;
-                read_acc();
-                arm_rows(std::true_type{}, I0{}, I2{});
-                write_acc();
-                wg_barrier();
+#pragma unroll
+                for (int j = 0; j < 6; j++) xacc[j * 64] = y[j];
+                bar();   // S1: y -> wave B
+                bar();   // S2: y <- wave B (after its slots 0, 1)
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = xacc[j * 64];
                 arm_rows(std::false_type{}, I2{}, I5{});
+            }
+        } else if (!c01) {
+            // only a gripper-body proxy (slot 4) touches a cube: the cube accelerations visit this wave for slot 4
+            for (int it = 0; it < P.pgs_iters; it++) {
+                limit_rows();
+                arm_rows(std::false_type{}, I2{}, I4{});
+                bar();   // S1: ca / cal <- wave B (after its cube rows)
+                read_cube_acc();
+                arm_rows(std::true_type{}, I4{}, I5{});
+                write_cube_acc();
+                bar();   // S2: ca / cal -> wave B
             }
         } else {
             for (int it = 0; it < P.pgs_iters; it++) {
-                limit_rows();          // (touch only the arm: overlap with wave B's cube rows)
-                if (prof) pf_mark = clock64();
-                wg_barrier();
-                if (prof) pf_wait += clock64() - pf_mark;
-                read_acc();
-                arm_rows(std::true_type{}, I0{}, I5{});
-                write_acc();
-                wg_barrier();
+                limit_rows();
+#pragma unroll
+                for (int j = 0; j < 6; j++) xacc[j * 64] = y[j];
+                bar();   // S1
+                bar();   // S2: y and ca / cal <- wave B
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = xacc[j * 64];
+                read_cube_acc();
+                arm_rows(std::false_type{}, I2{}, I4{});
+                arm_rows(std::true_type{}, I4{}, I5{});
+                write_cube_acc();
+                bar();   // S3: ca / cal -> wave B
             }
         }
 
         // (the forces stay in Wf / Wlim for the next substep's warm start; slots nobody touched were zeroed at set-up)
         if (P.diag) {
             unsigned m = 0u;
-            m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u;
-            m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;
+            m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;   // (bits 12, 13: wave B)
             m |= AS[4].act ? (1u << 16) : 0u;
 #pragma unroll
             for (int j = 0; j < 6; j++) m |= lim_act[j] ? (1u << (18 + j)) : 0u;
@@ -722,20 +752,36 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
             DGtot.choice += DG.choice * (unsigned)(2 * sub + 1);
         }
 
-        // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y: wave B holds both factors -----------------
-        {
+        // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y, i.e. qacc = Wm y with wave B's Wm = (M + hD)^-1 L ----
+        float qacc[6];
+        if (!c01) {   // wave B parked Wm = (M + hD)^-1 L in the idle LDS place of the rows of slots 0, 1 before barrier 1
+            const float *pw = lds + LL::G0 + lane;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s = fmaf(pw[(i * 6 + k) * 64], y[k], s);
+                qacc[i] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) xacc[j * 64] = qacc[j];   // wave B integrates its copy of the arm state with the same values
+            if (prof) pf_mark = clock64();
+            wg_barrier();   // E: wave B has integrated the cubes and published their new pose
+            if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
+        } else {      // y visits wave B (it holds both factors), qacc comes back
             float *py = lds + LL::LFAC0 + lane;   // (the contact rows there are dead after the last sweep; wave A rewrites the place only after barrier E)
 #pragma unroll
             for (int j = 0; j < 6; j++) py[j * 64] = y[j];
+            if (prof) pf_mark = clock64();
+            wg_barrier();   // Y
+            wg_barrier();   // E
+            if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
+#pragma unroll
+            for (int j = 0; j < 6; j++) qacc[j] = xacc[j * 64];
         }
-        if (prof) pf_mark = clock64();
-        wg_barrier();   // Y: y handed to wave B
-        wg_barrier();   // E: wave B has solved for the joint acceleration, integrated the cubes and published their new pose
-        if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            const float qacc = xacc[j * 64];
-            qd[j] = fmaf(H, qacc, qd[j]);
+            qd[j] = fmaf(H, qacc[j], qd[j]);
             q[j] = fmaf(H, qd[j], q[j]);
         }
     }
@@ -756,9 +802,12 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         P.active_mask[e] = mask; P.active_count[e] = DGtot.count + bcount;
         P.max_sweeps[e] = mask ? (unsigned)P.pgs_iters : 0u;
         P.choice[e] = DGtot.choice + bchoice + (unsigned)ik_iters * 0x9E3779B1u;
-#pragma unroll
-        for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];
     }
+    // (values only the tail needs are loaded here, not carried through the substep loop)
+    f3 target = mk(0.f, 0.f, 0.f);
+    if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
+    int elapsed = P.elapsed[e];
+    int goal = WALLS ? P.goal[e] : 0;
     EnvState<NC> S;
 #pragma unroll
     for (int j = 0; j < 6; j++) { S.q[j] = q[j]; S.qd[j] = qd[j]; }
@@ -856,7 +905,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     if (carry && valid) {
         auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
 #pragma unroll
-        for (int s = 0; s < NAS; s++)
+        for (int s = 2; s < NAS; s++)
 #pragma unroll
             for (int k = 0; k < NRW; k++) wst(WARM_ARM + 6 * s + k, Wf[s][k]);
 #pragma unroll
@@ -921,6 +970,12 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     for (int s = 0; s < 4; s++)
 #pragma unroll
         for (int k = 0; k < 4; k++) Wwall[s][k] = WALLS ? wld(WARM_WALL + 4 * s + k) : 0.f;
+    constexpr int NRW = ROLL ? 6 : 4;
+    float Wf01[2][NRW];   // carried forces of the finger<->cube slots 0, 1 (this wave owns them: they need the cube state)
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int k = 0; k < NRW; k++) Wf01[s][k] = wld(WARM_ARM + 6 * s + k);
     float *ccl = lds + LL::CC0 + lane;   // Stack: record field k of slot s at ccl[(s * CC_REC + k) * 64]
     const size_t CS = 64;
     if constexpr (NC == 2) {
@@ -941,20 +996,24 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     }
 
     const bool prof = P.diag == 3;   // profiling aid: cycles of this wave in total / waiting at barriers -> ctrl_out[0], [1]
+    // issue priority where two waves share a SIMD (the partner there belongs to another workgroup): this wave is on the critical path while it
+    // computes tau (wave A waits for it at barrier X) and the joint acceleration (barrier E); elsewhere it has slack and yields
     long long pf_t0 = prof ? clock64() : 0, pf_wait = 0, pf_mark = 0;
     Diag DGtot = {0u, 0u, 0u, 0u};
     const float minv = P.cube_minv, iinv = P.cube_iinv;
     for (int sub = 0; sub < P.n_substeps; sub++) {
         Diag DG = {0u, 0u, 0u, 0u};
+        __builtin_amdgcn_s_setprio(3);
         // ---- smooth joint forces: recursive Newton-Euler bias (zero joint acceleration, base accelerating at -g), passive damping and the
         //      position actuators (ctrlrange == joint range via inheritrange; joint-level force clamp) -> tau -> wave A.  The inertia
         //      tensors are applied in the link frames (R Ic R^T v as three small products). ----
-        {
-            ArmFrames F;
-            arm_frames(q, F);
-            f3 z[6];
+        ArmFrames F;
+        arm_frames(q, F);
+        f3 z[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) z[j] = joint_axis(F, j);
+        for (int j = 0; j < 6; j++) z[j] = joint_axis(F, j);
+        const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};   // finger spheres (slots 0, 1 below)
+        {
             f3 com[6];
             com[0] = local_point(F, 0, C1x, C1y, C1z); com[1] = local_point(F, 1, C2x, C2y, C2z); com[2] = local_point(F, 2, C3x, C3y, C3z);
             com[3] = local_point(F, 3, C4x, C4y, C4z); com[4] = local_point(F, 4, C5x, C5y, C5z); com[5] = local_point(F, 5, C6x, C6y, C6z);
@@ -999,6 +1058,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         if (prof) pf_mark = clock64();
         wg_barrier();   // X: tau is in LDS for wave A; wave A's Cholesky factor of the joint-space inertia is in LDS
         if (prof) pf_wait += clock64() - pf_mark;
+        __builtin_amdgcn_s_setprio(0);
         Chol6 CL;
         {
             const float *pl = lds + LL::LFAC0 + lane;
@@ -1011,26 +1071,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             for (int i = 0; i < 6; i++) CL.id[i] = pl[(k++) * 64];
         }
         wg_barrier();   // X2: the factor has been read -- wave A may overwrite its LDS place with contact rows
-        // factor of M + h (damping + kv) I for the implicitfast solve at the end of the substep, M = L L^T rebuilt from the factor
-        Chol6 CL2;
-        {
-            float Lf[6][6], Mm[6][6];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j <= i; j++) Lf[i][j] = i == j ? rcp(CL.id[i]) : CL.L[i][j];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j <= i; j++) {
-                    float m = 0.f;
-#pragma unroll
-                    for (int k = 0; k <= j; k++) m = fmaf(Lf[i][k], Lf[j][k], m);
-                    Mm[i][j] = m + (i == j ? H * (DAMPING + KV) : 0.f);
-                }
-            chol6(Mm, CL2);
-        }
-
         CubeRot CR[NC];
         f3 ca[NC], cal[NC], cww[NC];
 #pragma unroll
@@ -1040,6 +1080,114 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             cal[c] = mk(0.f, 0.f, 0.f);
             cww[c] = axpy(cw[c].x, CR[c].X, axpy(cw[c].y, CR[c].Y, cw[c].z * CR[c].Z));
         }
+        // ---- finger spheres vs cube(s): slots 0, 1 (one contact per sphere, the deepest cube; rows g = L^-1 J^T -> LDS).  Their rows touch the
+        //      arm (through y, which visits this wave once per sweep when a sphere touches) and the cube they sit on. ----
+        ArmSlot2<NRW> AS01[2];
+        bool s01_any[2];
+        int s01_cube[2] = {0, 0};
+        float dy01[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sum of g_r f_r of the warm-start forces: wave A adds it to y
+        {
+        const float srad[2] = {SPH0r, SPH1r};
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            ArmSlot2<NRW> &T = AS01[sp];
+            f3 pos = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 1.f);
+            int cidx = 0, sel = 0;
+            float bestd = 1e30f;
+            bool near_any = false;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const f3 dd = sph[sp] - cp[c];
+                near_any = near_any || dot(dd, dd) < (srad[sp] + 1.7321f * CH) * (srad[sp] + 1.7321f * CH);
+            }
+            if (__any(near_any))   // broad phase (wave-uniform): a sphere farther than r + h sqrt(3) from every cube centre cannot touch
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const SBHit hit = sphere_box(sph[sp], srad[sp], cp[c], CR[c]);
+                if (hit.dist < bestd) { bestd = hit.dist; cidx = c; n = hit.n; pos = hit.pos; sel = 8 * c + hit.code; }  // deepest cube wins (tie: cube 0)
+            }
+            const float dist = bestd;
+            s01_cube[sp] = cidx;
+            T.act = dist < 0.f;
+            if (P.diag) {
+                sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : 16;   // branch of make_frame
+                diag_choice(DG, T.act, 12 + sp, sel);
+            }
+            s01_any[sp] = __any(T.act) != 0;
+#pragma unroll
+            for (int k = 0; k < NRW; k++) { T.aref[k] = 0.f; T.inv[k] = 0.f; }
+            T.Rn = 1.f; T.n = n; T.t1 = mk(0.f, 1.f, 0.f); T.t2 = mk(-1.f, 0.f, 0.f); T.rc = mk(0.f, 0.f, 0.f);
+            if (!s01_any[sp]) {
+#pragma unroll
+                for (int k = 0; k < NRW; k++) Wf01[sp][k] = 0.f;
+            } else {
+                make_frame(n, T.t1, T.t2);
+                f3 cube_p, cube_v, cube_w;
+                if (NC == 2 && cidx == 1) { cube_p = cp[NC - 1]; cube_v = cv[NC - 1]; cube_w = cww[NC - 1]; }
+                else { cube_p = cp[0]; cube_v = cv[0]; cube_w = cww[0]; }
+                T.rc = pos - cube_p;
+                const float imp = impedance(dist, D0_FC, DW_FC, 1.0f / W_FC);
+                const float Rn = fmaxf((1.f - imp) * rcp(imp) * ((sp == 0 ? INVW_TRAN_L5 : INVW_TRAN_L6) + minv), 1e-15f);
+                const float Rf = Rn * P.inv_impratio;
+                const float Rt = Rf * P.rt_fc;
+                T.Rn = Rn;
+                const int nj = sp == 0 ? 5 : 6;   // joints that move the sphere (link_5 / link_6)
+                f3 jc[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) jc[j] = j < nj ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < NRW; r++) {
+                    f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));   // row 3: rotation about n (torsion)
+                    if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }     // rows 4, 5: rotation about t1, t2 (rolling)
+                    float g[6];
+                    float vel = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        g[j] = r < 3 ? dot(jc[j], d) : (j < nj ? dot(z[j], d) : 0.f);
+                        vel = fmaf(g[j], qd[j], vel);
+                    }
+                    float velc, diagc;
+                    if (r < 3) {
+                        const f3 rxd = cross(T.rc, d);
+                        velc = dot(d, cube_v) + dot(rxd, cube_w);
+                        diagc = minv + iinv * dot(rxd, rxd);
+                    } else {
+                        velc = dot(d, cube_w);
+                        diagc = iinv;
+                    }
+                    vel -= velc;
+                    fsub(CL, g);
+                    float gg = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) gg = fmaf(g[j], g[j], gg);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float2v gp = {g[2 * k], g[2 * k + 1]};
+                        *reinterpret_cast<float2v *>(&lds[LL::G0 + (as2_row0<ROLL>(sp) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
+                    }
+                    float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) Rr = Rf * P.rr_fc;
+                    T.aref[r] = -B_FC * vel - (r == 0 ? K_FC * imp * dist : 0.f);
+                    T.inv[r] = T.act ? rcp(gg + diagc + Rr) : 0.f;   // (a row that is off: f = 0 and inv = 0 -> its updates are exactly 0)
+                    const float fw = T.act ? Wf01[sp][r] : 0.f;       // warm start: previous substep's force of this slot
+                    Wf01[sp][r] = fw;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) dy01[j] = fmaf(g[j], fw, dy01[j]);
+                    const f3 dl = r < 3 ? (-minv * fw) * d : mk(0.f, 0.f, 0.f);
+                    const f3 da = r < 3 ? (-iinv * fw) * cross(T.rc, d) : (-iinv * fw) * d;
+                    if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
+                    else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
+                }
+            }
+        }
+        }
+        const bool c01 = s01_any[0] || s01_any[1];
+        if (lane == 0) const_cast<int *>(xflag)[0] = c01 ? 1 : 0;
+        if (c01) {   // (wave A has read the pose before barrier X2: its first six fields carry dy01 until the sweeps start)
+#pragma unroll
+            for (int j = 0; j < 6; j++) xpose[j * 64] = dy01[j];
+        }
+
         // ---- collision: floor <-> cube (MuJoCo plane-box: penetrating vertices in index order, at most 4) ----
         FloorSlot FS[NC][4];
 #pragma unroll
@@ -1047,7 +1195,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 #pragma unroll
             for (int s = 0; s < 4; s++) { FS[c][s].act = false; FS[c][s].r = mk(0.f, 0.f, 0.f); FS[c][s].Rn = 1.f;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { FS[c][s].f[k] = 0.f; FS[c][s].aref[k] = 0.f; FS[c][s].inv[k] = 0.f; } }
+                for (int k = 0; k < 4; k++) { FS[c][s].aref[k] = 0.f; FS[c][s].inv[k] = 0.f; } }
             float sdist[4] = {0.f, 0.f, 0.f, 0.f};
             const f3 hx = CH * CR[c].X, hy = CH * CR[c].Y, hz = CH * CR[c].Z;
             f3 rv[8];
@@ -1105,15 +1253,16 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
                 T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
                 T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+                float (&Tf)[4] = Wfloor[c][s];   // the carried forces ARE this slot's forces from here on (zero if the slot is off)
 #pragma unroll
-                for (int k = 0; k < 4; k++) { T.f[k] = T.act ? Wfloor[c][s][k] : 0.f; }
+                for (int k = 0; k < 4; k++) { Tf[k] = T.act ? Tf[k] : 0.f; }
                 const f3 r = T.r;
-                ca[c].z = fmaf(minv, T.f[0], ca[c].z);
-                ca[c].y = fmaf(minv, T.f[1], ca[c].y);
-                ca[c].x = fmaf(-minv, T.f[2], ca[c].x);
-                cal[c].x = fmaf(iinv, r.y * T.f[0] - r.z * T.f[1], cal[c].x);
-                cal[c].y = fmaf(iinv, -r.x * T.f[0] - r.z * T.f[2], cal[c].y);
-                cal[c].z = fmaf(iinv, r.x * T.f[1] + r.y * T.f[2] + T.f[3], cal[c].z);
+                ca[c].z = fmaf(minv, Tf[0], ca[c].z);
+                ca[c].y = fmaf(minv, Tf[1], ca[c].y);
+                ca[c].x = fmaf(-minv, Tf[2], ca[c].x);
+                cal[c].x = fmaf(iinv, r.y * Tf[0] - r.z * Tf[1], cal[c].x);
+                cal[c].y = fmaf(iinv, -r.x * Tf[0] - r.z * Tf[2], cal[c].y);
+                cal[c].z = fmaf(iinv, r.x * Tf[1] + r.y * Tf[2] + Tf[3], cal[c].z);
             }
         }
 
@@ -1355,14 +1504,50 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
 
+        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.
+        //  - no finger sphere on a cube (the usual case; this wave has slack before barrier 1): Wm = (M + hD)^-1 L is built here and parked in
+        //    the idle LDS place of the rows of slots 0, 1; wave A computes qacc = Wm y itself at the end of its sweeps, no round trip;
+        //  - else (this wave is the busier one): only the second factor is built; y visits this wave at the end (barrier Y) and qacc goes back.
+        Chol6 CL2;
+        {
+            float Lf[6][6], Mm[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) Lf[i][j] = i == j ? rcp(CL.id[i]) : CL.L[i][j];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int k = 0; k <= j; k++) m = fmaf(Lf[i][k], Lf[j][k], m);
+                    Mm[i][j] = m + (i == j ? H * (DAMPING + KV) : 0.f);
+                }
+            chol6(Mm, CL2);
+            if (!c01) {
+                float *pw = lds + LL::G0 + lane;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of Wm
+                    float col[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) col[i] = i < j ? 0.f : Lf[i][j];
+                    fsub(CL2, col);
+                    bsub(CL2, col);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) pw[(i * 6 + j) * 64] = col[i];
+                }
+            }
+        }
         if (prof) pf_mark = clock64();
         wg_barrier();   // B1: wave A has set up its rows and decided whether this substep is coupled
         if (prof) pf_wait += clock64() - pf_mark;
-        const bool coupled = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // (scalar: the barriers below sit under this branch)
-        if (coupled) {   // warm-start forces of the arm<->cube slots act on the cubes too
+        const bool cube4 = __builtin_amdgcn_readfirstlane(xflag[1]) != 0;   // wave A: a gripper-body proxy touches a cube in some lane
+        const bool coupled = c01 || cube4;
+        if (cube4) {   // warm-start forces of the proxy slot act on the cube too
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const float *pa = xacc + (size_t)c * 6 * 64;
+                const float *pa = xpose + (size_t)(6 + c * 6) * 64;
                 ca[c] = ca[c] + mk(pa[0], pa[64], pa[128]); cal[c] = cal[c] + mk(pa[192], pa[256], pa[320]);
             }
         }
@@ -1374,25 +1559,26 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     FloorSlot &T = FS[c][s];
+                    float (&Tf)[4] = Wfloor[c][s];
                     const f3 r = T.r;
                     const float Rf = T.Rn * P.inv_impratio;
                     const float Rt = Rf * P.rt_cube;
-                    const float u0 = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - T.aref[0] + T.Rn * T.f[0];
-                    const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * T.f[1];
-                    const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * T.f[2];
-                    const float u3 = cal[c].z - T.aref[3] + Rt * T.f[3];
+                    const float u0 = ca[c].z + r.y * cal[c].x - r.x * cal[c].y - T.aref[0] + T.Rn * Tf[0];
+                    const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * Tf[1];
+                    const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * Tf[2];
+                    const float u3 = cal[c].z - T.aref[3] + Rt * Tf[3];
                     const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
-                    float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
-                    const float d0 = nf - T.f[0];
+                    float nf = fmaxf(Tf[0] - u0 * T.inv[0], 0.f);
+                    const float d0 = nf - Tf[0];
                     const float d1a = -(u1 + B01 * d0) * T.inv[1];
                     const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
                     const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
-                    const float fn = T.f[0] + d0;
-                    const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                    const float fn = Tf[0] + d0;
+                    const float g1 = Tf[1] + d1a, g2 = Tf[2] + d2a, g3 = Tf[3] + d3a;
                     const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
                     const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                    const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
-                    T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                    const float d1 = g1 * sc - Tf[1], d2 = g2 * sc - Tf[2], d3 = g3 * sc - Tf[3];
+                    Tf[0] = fn; Tf[1] += d1; Tf[2] += d2; Tf[3] += d3;
                     ca[c].z = fmaf(minv, d0, ca[c].z);
                     ca[c].y = fmaf(minv, d1, ca[c].y);
                     ca[c].x = fmaf(-minv, d2, ca[c].x);
@@ -1484,36 +1670,167 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 }
             }
         };
+        // ---- one Gauss-Seidel pass over the finger<->cube slots 0, 1: arm side through yv (the arm acceleration on its visit from wave A),
+        //      cube side tracked as scalars with closed-form couplings (see lcr_kernels.hip), summed force applied to the cube at the end ----
+        float yv[6];
+        auto finger_rows = [&]() {
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (!s01_any[s]) continue;
+                ArmSlot2<NRW> &T = AS01[s];
+                const float Rf = T.Rn * P.inv_impratio;
+                const float Rt = Rf * P.rt_fc;
+                float2v g[NRW][3];
+#pragma unroll
+                for (int r = 0; r < NRW; r++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        g[r][k] = *reinterpret_cast<const float2v *>(&lds[LL::G0 + (as2_row0<ROLL>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                float2v yp[3] = {{yv[0], yv[1]}, {yv[2], yv[3]}, {yv[4], yv[5]}};
+                float f_in[NRW];
+#pragma unroll
+                for (int r = 0; r < NRW; r++) f_in[r] = Wf01[s][r];
+                const bool second = NC == 2 && s01_cube[s] == 1;
+                const f3 a_lin = second ? ca[NC - 1] : ca[0], a_ang = second ? cal[NC - 1] : cal[0];
+                float vq[3], pq[3], wn, kq, w1 = 0.f, w2 = 0.f;
+                {
+                    const f3 Ac = a_lin + cross(a_ang, T.rc);
+                    vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
+                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
+                    wn = dot(T.n, a_ang);
+                    if (NRW == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
+                    kq = fmaf(iinv, dot(T.rc, T.rc), minv);
+                }
+                auto couple = [&](int j, float dlt) {
+                    if (j < 3) {
+                        const float c = iinv * pq[j] * dlt;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
+                        vq[j] = fmaf(-kq, dlt, vq[j]);
+                        if (j == 1) wn = fmaf(iinv * dlt, pq[2], wn);
+                        if (j == 2) wn = fmaf(-iinv * dlt, pq[1], wn);
+                        if (NRW == 6) {
+                            if (j == 0) { w1 = fmaf(-iinv * dlt, pq[2], w1); w2 = fmaf(iinv * dlt, pq[1], w2); }
+                            if (j == 1) w2 = fmaf(-iinv * dlt, pq[0], w2);
+                            if (j == 2) w1 = fmaf(iinv * dlt, pq[0], w1);
+                        }
+                    } else if (j == 3) {
+                        wn = fmaf(-iinv, dlt, wn);
+                        vq[1] = fmaf(iinv * dlt, pq[2], vq[1]);
+                        vq[2] = fmaf(-iinv * dlt, pq[1], vq[2]);
+                    } else if (j == 4) {
+                        w1 = fmaf(-iinv, dlt, w1);
+                        vq[0] = fmaf(-iinv * dlt, pq[2], vq[0]);
+                        vq[2] = fmaf(iinv * dlt, pq[0], vq[2]);
+                    } else {
+                        w2 = fmaf(-iinv, dlt, w2);
+                        vq[0] = fmaf(iinv * dlt, pq[1], vq[0]);
+                        vq[1] = fmaf(-iinv * dlt, pq[0], vq[1]);
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < NRW; r++) {
+                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                    const float gy = acc.x + acc.y;
+                    float jc_a = r < 3 ? -vq[r] : -wn;
+                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
+                    const float res = gy + jc_a - T.aref[r] + Rr * Wf01[s][r];
+                    float nf = Wf01[s][r] - res * T.inv[r];
+                    if (r == 0) nf = fmaxf(nf, 0.f);
+                    const float dlt = nf - Wf01[s][r];
+                    Wf01[s][r] += dlt;
+                    const float2v d2 = {dlt, dlt};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                    couple(r, dlt);
+                }
+                {   // cone projection (finger geoms: mu 1.5; torsional / rolling: max of finger and cube)
+                    const float fn = Wf01[s][0];
+                    float s2 = (Wf01[s][1] * Wf01[s][1] + Wf01[s][2] * Wf01[s][2]) * (1.f / (MU_FINGER * MU_FINGER)) + Wf01[s][3] * Wf01[s][3] * P.inv_mu_fct2;
+                    if constexpr (ROLL) s2 = fmaf(Wf01[s][4] * Wf01[s][4] + Wf01[s][5] * Wf01[s][5], P.inv_mu_fcr2, s2);
+                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+#pragma unroll
+                    for (int r = 1; r < NRW; r++) {
+                        const float dlt = Wf01[s][r] * sc - Wf01[s][r];
+                        Wf01[s][r] += dlt;
+                        const float2v d2 = {dlt, dlt};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                    }
+                }
+                yv[0] = yp[0].x; yv[1] = yp[0].y; yv[2] = yp[1].x; yv[3] = yp[1].y; yv[4] = yp[2].x; yv[5] = yp[2].y;
+                {
+                    const float e0 = Wf01[s][0] - f_in[0], e1 = Wf01[s][1] - f_in[1], e2 = Wf01[s][2] - f_in[2], e3 = Wf01[s][3] - f_in[3];
+                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
+                    const f3 dl_lin = (-minv) * Fd;
+                    f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
+                    if constexpr (ROLL) Td = axpy(Wf01[s][4] - f_in[4], T.t1, axpy(Wf01[s][5] - f_in[5], T.t2, Td));
+                    const f3 dl_ang = (-iinv) * Td;
+                    if (second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }
+                    else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
+                }
+            }
+        };
+        float *xcc_ = lds + LL::POSE0 + lane;   // hand-over place of the cube accelerations when a proxy touches a cube (pose area: idle during the sweeps)
+        auto write_cube_acc = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float *pa = xcc_ + (size_t)c * 6 * 64;
+                pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
+                pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
+            }
+        };
+        auto read_cube_acc = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float *pa = xcc_ + (size_t)c * 6 * 64;
+                ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
+            }
+        };
+        auto bar = [&]() {
+            if (prof) pf_mark = clock64();
+            wg_barrier();
+            if (prof) pf_wait += clock64() - pf_mark;
+        };
         if (!coupled) {
             for (int it = 0; it < P.pgs_iters; it++) cube_rows();
+        } else if (c01 && !cube4) {
+            for (int it = 0; it < P.pgs_iters; it++) {
+                cube_rows();
+                bar();   // S1: y <- wave A (after its limit rows)
+#pragma unroll
+                for (int j = 0; j < 6; j++) yv[j] = xacc[j * 64];
+                finger_rows();
+#pragma unroll
+                for (int j = 0; j < 6; j++) xacc[j * 64] = yv[j];
+                bar();   // S2: y -> wave A (slots 2-4)
+            }
+        } else if (!c01) {
+            for (int it = 0; it < P.pgs_iters; it++) {
+                cube_rows();
+                write_cube_acc();
+                bar();   // S1: ca / cal -> wave A (slot 4 on a cube)
+                bar();   // S2: ca / cal <- wave A
+                read_cube_acc();
+            }
         } else {
             for (int it = 0; it < P.pgs_iters; it++) {
                 cube_rows();
+                bar();   // S1
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    float *pa = xacc + (size_t)c * 6 * 64;
-                    pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
-                    pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
-                }
-                if (prof) pf_mark = clock64();
-                wg_barrier();   // -> wave A: arm slots of this sweep (incl. the arm<->cube rows)
-                wg_barrier();   // <- wave A
-                if (prof) pf_wait += clock64() - pf_mark;
+                for (int j = 0; j < 6; j++) yv[j] = xacc[j * 64];
+                finger_rows();
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const float *pa = xacc + (size_t)c * 6 * 64;
-                    ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
-                }
+                for (int j = 0; j < 6; j++) xacc[j * 64] = yv[j];
+                write_cube_acc();
+                bar();   // S2: y and ca / cal -> wave A
+                bar();   // S3: ca / cal <- wave A
+                read_cube_acc();
             }
         }
 
         // ---- keep the forces for the next substep's warm start (inactive slots hold zero) ----------------
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) Wfloor[c][s][k] = FS[c][s].f[k];
 #pragma unroll
         for (int s = 0; s < 4; s++) cc_prev[s] = cc_act[s];
         if constexpr (WALLS) {
@@ -1533,6 +1850,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
                 if (WALLS) m |= WS[s].act ? (1u << (8 + s)) : 0u;
             }
+            m |= AS01[0].act ? (1u << 12) : 0u; m |= AS01[1].act ? (1u << 13) : 0u;
             DGtot.mask |= m;
             DGtot.count += (unsigned)__popc(m);
             DGtot.choice += DG.choice * (unsigned)(2 * sub + 1);
@@ -1562,34 +1880,34 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 cq[c][0] = r0 * in; cq[c][1] = r1 * in; cq[c][2] = r2 * in; cq[c][3] = r3 * in;
             }
         }
-        publish_pose();   // (before barrier Y: this wave finishes its sweeps first, the integration is off the critical path)
-        // ---- implicitfast solve for the arm: (M + h (damping + kv) I) qacc = L y, y from wave A ----
-        if (prof) pf_mark = clock64();
-        wg_barrier();   // Y
-        if (prof) pf_wait += clock64() - pf_mark;
-        {
-            float yv[6], rhs[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) yv[j] = lds[LL::LFAC0 + lane + j * 64];
+        publish_pose();   // (this wave finishes its sweeps first: the integration is off the critical path)
+        if (c01) {        // y from wave A -> qacc
+            if (prof) pf_mark = clock64();
+            wg_barrier();   // Y
+            if (prof) pf_wait += clock64() - pf_mark;
+            float rhs[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                float s = rcp(CL.id[i]) * yv[i];  // L_ii y_i
+                float s = rcp(CL.id[i]) * lds[LL::LFAC0 + lane + i * 64];  // L_ii y_i
 #pragma unroll
-                for (int k = 0; k < i; k++) s = fmaf(CL.L[i][k], yv[k], s);
+                for (int k = 0; k < i; k++) s = fmaf(CL.L[i][k], lds[LL::LFAC0 + lane + k * 64], s);
                 rhs[i] = s;
             }
             fsub(CL2, rhs);
             bsub(CL2, rhs);
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                xacc[j * 64] = rhs[j];
-                qd[j] = fmaf(H, rhs[j], qd[j]);
-                q[j] = fmaf(H, qd[j], q[j]);
-            }
+            for (int j = 0; j < 6; j++) xacc[j * 64] = rhs[j];
         }
+        // (the implicitfast solve qacc = Wm y is wave A's: it has y; this wave reads qacc after barrier E)
         if (prof) pf_mark = clock64();
         wg_barrier();   // E
         if (prof) pf_wait += clock64() - pf_mark;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {   // this wave's copy of the arm state follows with the same qacc
+            const float qacc = xacc[j * 64];
+            qd[j] = fmaf(H, qacc, qd[j]);
+            q[j] = fmaf(H, qd[j], q[j]);
+        }
     }
     if (prof && valid) { P.ctrl_out[e] = (float)(clock64() - pf_t0); P.ctrl_out[(size_t)N + e] = (float)pf_wait; }
     // diagnostics words of this wave -> wave A (the ACC area is free now)
@@ -1608,6 +1926,10 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) wst(WARM_FLOOR + 16 * c + 4 * s + k, Wfloor[c][s][k]);
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int k = 0; k < NRW; k++) wst(WARM_ARM + 6 * s + k, Wf01[s][k]);
         if constexpr (WALLS) {
 #pragma unroll
             for (int s = 0; s < 4; s++)

@@ -24,6 +24,18 @@ N = 512
 MAX_DQ, MAX_DV = util.MAX_DQ, util.MAX_DV
 
 
+@pytest.fixture(autouse=True, params=["auto", "single"])
+def kernel_family(request, monkeypatch):
+    """every test of this module runs against both step-kernel families: "auto" = what lcr_create dispatches for the shard size (test sizes:
+    the two-cooperating-waves kernels of lcr_kernels2.hip; >= 65 536 envs: the one-wave kernels) and "single" = the one-wave-per-64-envs
+    kernels of lcr_kernels.hip forced at every size (LCR_STEP_KERNEL, read by lcr_create)"""
+    if request.param != "auto":
+        monkeypatch.setenv("LCR_STEP_KERNEL", request.param)
+    else:
+        monkeypatch.delenv("LCR_STEP_KERNEL", raising=False)
+    return request.param
+
+
 def _cmp_step(sim, o, rng, steps, atol_q=2e-5, atol_v=2e-3, frac=0.99, act_scale=1.0, max_dq=MAX_DQ, max_dv=MAX_DV):
     worst_q = worst_v = 0.0
     for t in range(steps):
@@ -677,6 +689,7 @@ def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which
     here) keep all g rows in LDS; larger ones keep the proxy slot's and the rolling rows in a global scratch array.  LCR_STACK_LDS=small
     forces the second variant at test sizes."""
     monkeypatch.setenv("LCR_STACK_LDS", "small")
+    monkeypatch.setenv("LCR_STEP_KERNEL", "single")   # (the storage variants belong to the one-wave kernels)
     if which == "rollout_joint":
         test_step_rollout_vs_oracle(hip_lib, monkeypatch, "stack", "joint", True)
     elif which == "rollout_ee":
@@ -696,6 +709,7 @@ def test_stack_variants_are_bit_identical(hip_lib, monkeypatch):
     batch gives the same trajectory whatever the shard size selects"""
     n = 512
     sims = []
+    monkeypatch.setenv("LCR_STEP_KERNEL", "single")
     for mode in ("small", "big"):
         monkeypatch.setenv("LCR_STACK_LDS", mode)
         sims.append(_vecsim("stack", n, observation_mode="state", base_seed=3))
@@ -831,6 +845,44 @@ def test_graft_entry_smoke(hip_lib):
     """the driver's end-to-end check, run here so that it cannot rot (round 2 shipped it red: stale harness)"""
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.parametrize("task,mode", [("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("pick_place", "ee"), ("stack", "joint"), ("push_loop", "joint"),
+                                       ("push_loop", "ee")])
+def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mode):
+    """the one-wave kernels and both variants of the two-cooperating-waves kernels (compiled for one / two waves per SIMD) step the same
+    states to the same result within fp32 rounding (they group the same arithmetic differently), take the same discrete decisions, and
+    the two-wave kernels give the same bits run after run (their LDS hand-overs between the arm wave and the cube wave are ordered by
+    barriers: a missing one shows up as run-to-run differences -- found once, in the two-waves-per-SIMD variant of PushCubeLoop)"""
+    n = 4096
+    sims = {}
+    for fam in ("single", "coop1", "coop2", "coop2b"):
+        monkeypatch.setenv("LCR_STEP_KERNEL", fam[:5])
+        sims[fam] = _vecsim(task, n, observation_mode="state", action_mode=mode, base_seed=5, diagnostics=True)
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for t in range(10):
+        a = rng.uniform(-1, 1, (n, sims["single"].action_dim)).astype(np.float32)
+        st0 = sims["single"].get_state()
+        for fam in ("coop1", "coop2", "coop2b"):
+            sims[fam].set_state(**st0)                      # re-synchronise incl. the carried forces
+        for sim in sims.values():
+            sim.step(a)
+        r = sims["single"].get_state()
+        c2, c2b = sims["coop2"].get_state(), sims["coop2b"].get_state()
+        for k in r:
+            np.testing.assert_array_equal(c2[k], c2b[k], err_msg=f"two-wave kernel not deterministic: {task} step {t} field {k}")
+        for fam in ("coop1", "coop2"):
+            c = sims[fam].get_state()
+            same = (sims[fam].choice.numpy() == sims["single"].choice.numpy()) & (sims[fam].active_count.numpy() == sims["single"].active_count.numpy())
+            assert same.mean() > 0.995, (fam, t, same.mean())
+            dq = np.abs(c["qpos"] - r["qpos"]).max(axis=0)[same]
+            worst = max(worst, float(dq.max()))
+            # same decisions: the difference is rounding (PushCubeLoop's 50 g cube with friction 1.5 amplifies it most)
+            assert dq.max() < (5e-3 if task == "push_loop" else 5e-5), (fam, t, float(dq.max()))
+    print(f"[families] {task} {mode}: worst |dq| between kernel families {worst:.2e}")
+    for sim in sims.values():
+        sim.close()
 
 
 def test_zz_outlier_census(hip_lib):

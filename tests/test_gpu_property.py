@@ -28,15 +28,25 @@ TASKS = ["reach", "lift", "push", "pick_place", "stack", "push_loop"]
     condim=st.sampled_from([None, 4, 6]),
     solve=st.sampled_from(["carry", "resync_cold", "compat_cold"]),
     arm_collision=st.booleans(),
+    family=st.sampled_from(["auto", "single", "coop2"]),
     seed=st.integers(min_value=0, max_value=2**40),
 )
-def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, solve, arm_collision, seed):
+def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, solve, arm_collision, family, seed):
     kw = dict(action_mode=mode, reward_type=reward, n_substeps=n_substeps, pgs_iters=pgs_iters, impratio=impratio,
               distance_threshold=thr, auto_reset=False, max_episode_steps=0, finger_cube_condim=condim, arm_collision=arm_collision,
               # "carry": the default product mode, each step starts from the oracle's carried forces; "resync_cold": default mode, forces
               # dropped by lcr_set_state; "compat_cold": LCR_COMPAT_COLD_SOLVE_EACH_STEP on both sides (the kernel then has no warm array)
               compat=2 if solve == "compat_cold" else 0)
-    sim, o = util.make_pair(task, n, **kw)
+    # step-kernel family: the shard-size dispatch (two-cooperating-waves kernels at these sizes), the one-wave kernels, or the two-wave
+    # variant compiled for two waves per SIMD (lcr_create reads LCR_STEP_KERNEL)
+    if family == "auto":
+        os.environ.pop("LCR_STEP_KERNEL", None)
+    else:
+        os.environ["LCR_STEP_KERNEL"] = family
+    try:
+        sim, o = util.make_pair(task, n, **kw)
+    finally:
+        os.environ.pop("LCR_STEP_KERNEL", None)
     rng = np.random.default_rng(seed % (2**32))
     seeds = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(seed)) % np.uint64(2**63)
     o.reset(seeds=seeds); sim.reset(seeds=seeds)
