@@ -17,6 +17,7 @@ TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_lo
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
 REWARD_TYPES = {"sparse": 0, "dense": 1}
+STEP_KERNELS = {"auto": 0, "single": 1, "coop": 2}   # lcr_config.step_kernel
 COMPAT_ZERO_QVEL_ON_RESET = 1
 COMPAT_COLD_SOLVE_EACH_STEP = 2   # contact solver starts every control step from zero forces (default: forces carried across steps)
 IMG_H, IMG_W = 240, 320
@@ -60,6 +61,8 @@ class LcrConfig(ctypes.Structure):
         ("pgs_tol", ctypes.c_double),
         ("diagnostics", ctypes.c_int32),
         ("finger_cube_condim", ctypes.c_int32),
+        ("step_kernel", ctypes.c_int32),
+        ("_reserved", ctypes.c_int32),
     ]
 
 

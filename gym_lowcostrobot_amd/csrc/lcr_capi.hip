@@ -156,6 +156,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
     if (cfg->pgs_iters < 0 && !(cfg->pgs_tol > 0)) return fail(LCR_ERR_INVALID, "pgs_tol must be positive in converged mode (pgs_iters < 0)");
     if (cfg->finger_cube_condim != 0 && cfg->finger_cube_condim != 4 && cfg->finger_cube_condim != 6) return fail(LCR_ERR_INVALID, "finger_cube_condim must be 4 or 6");
+    if (cfg->step_kernel < 0 || cfg->step_kernel > 2) return fail(LCR_ERR_INVALID, "step_kernel must be 0 (by shard size), 1 (one wave per 64 envs) or 2 (two cooperating waves)");
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
     int k = lcr_action_dim(cfg);
@@ -281,6 +282,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         {
             const size_t waves2 = 2 * ((N + 63) / 64), simds = 4 * (size_t)prop.multiProcessorCount;
             D.coop = waves2 <= simds ? 1 : 0;
+            if (cfg->step_kernel == 1) D.coop = 0;
+            else if (cfg->step_kernel == 2) D.coop = waves2 <= simds ? 1 : 2;
             if (const char *ov = getenv("LCR_STEP_KERNEL")) {
                 if (strcmp(ov, "single") == 0) D.coop = 0;
                 else if (strcmp(ov, "coop1") == 0) D.coop = 1;

@@ -72,6 +72,7 @@ class VecSim:
         pgs_tol=1e-6,
         diagnostics=False,
         finger_cube_condim=None,
+        step_kernel="auto",
     ):
         self.L = _capi.load()
         if action_mode not in ACTION_MODES:
@@ -107,6 +108,9 @@ class VecSim:
         cfg.diagnostics = int(diagnostics)   # True / 1: decision signature; 2, 3: per-wave cycle read-back (profiling aids)
         if finger_cube_condim is not None:   # default: lcr_config_default's choice for the task (6 for PushCubeLoop, else 4)
             cfg.finger_cube_condim = int(finger_cube_condim)
+        if step_kernel not in _capi.STEP_KERNELS:
+            raise ValueError(f"invalid step_kernel {step_kernel!r} (auto | single | coop)")
+        cfg.step_kernel = _capi.STEP_KERNELS[step_kernel]   # kernel family; pin it when results must be bit-identical across shardings
         self.cfg = cfg
         self.n = int(n_envs)
         self.device = int(device)

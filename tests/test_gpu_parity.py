@@ -139,13 +139,16 @@ def test_auto_reset_and_timelimit(hip_lib):
 
 @pytest.mark.parametrize("task,mode,M,steps", [("reach", "joint", 4096, 8), ("pick_place", "ee", 4096, 8), ("push_loop", "joint", 2048, 8),
                                                ("stack", "joint", 32768, 55)])
-def test_shard_invariance_and_determinism(hip_lib, task, mode, M, steps):
-    """env i's trajectory depends only on its GLOBAL id: one sim of 2M envs == two sims of M envs (bit-exact), across auto-resets.
-    (Stack: the 65 536-env batch runs the kernel variant with rows in global scratch, its two 32 768-env shards the all-LDS one.)"""
+def test_shard_invariance_and_determinism(hip_lib, kernel_family, task, mode, M, steps):
+    """env i's trajectory depends only on its GLOBAL id: one sim of 2M envs == two sims of M envs (bit-exact), across auto-resets, for a
+    pinned kernel family (lcr_config.step_kernel: the by-size default would run Stack's 65 536-env batch on the one-wave kernels and its
+    two 32 768-env shards on the two-wave kernels, which agree to rounding only).  Stack, one-wave family: the 65 536-env batch runs the
+    variant with rows in global scratch, its two shards the all-LDS one; two-wave family: the variants compiled for two / one wave per SIMD."""
     from gym_lowcostrobot_amd import VecSim
-    whole = VecSim(task, 2 * M, observation_mode="state", action_mode=mode, base_seed=11)
-    lo = VecSim(task, M, observation_mode="state", action_mode=mode, base_seed=11, env_id_offset=0)
-    hi = VecSim(task, M, observation_mode="state", action_mode=mode, base_seed=11, env_id_offset=M)
+    kw = dict(observation_mode="state", action_mode=mode, base_seed=11, step_kernel="single" if kernel_family == "single" else "coop")
+    whole = VecSim(task, 2 * M, **kw)
+    lo = VecSim(task, M, env_id_offset=0, **kw)
+    hi = VecSim(task, M, env_id_offset=M, **kw)
     aw, al, ah = whole.alloc_actions(), lo.alloc_actions(), hi.alloc_actions()
     for t in range(steps):
         whole.fill_random_actions(aw, 0, t); lo.fill_random_actions(al, 0, t); hi.fill_random_actions(ah, 0, t)
@@ -792,7 +795,7 @@ def test_checkpoint_roundtrip_is_bit_exact(hip_lib, task, mode):
     Reference: env.step never resets mjData.qacc_warmstart (reach_cube_env.py:276-279), so a faithful checkpoint has to carry it."""
     n = 512
     rng = np.random.default_rng(5)
-    kw = dict(action_mode=mode, auto_reset=True, max_episode_steps=7)
+    kw = dict(action_mode=mode, auto_reset=True, max_episode_steps=9)
     a_sim = _vecsim(task, n, observation_mode="state", **kw)
     b_sim = _vecsim(task, n, observation_mode="state", **kw)
     seeds = np.arange(n, dtype=np.uint64) + 9
@@ -805,7 +808,7 @@ def test_checkpoint_roundtrip_is_bit_exact(hip_lib, task, mode):
     b_sim.set_state(**ck)
     cold = _vecsim(task, n, observation_mode="state", **kw)
     cold.set_state(**{k: v for k, v in ck.items() if k != "warm"})
-    for t in range(6, 12):                                      # (crosses an auto-reset at elapsed == 7)
+    for t in range(6, 12):                                      # (crosses the auto-reset at elapsed == 9)
         a_sim.step(acts[t]); b_sim.step(acts[t]); cold.step(acts[t])
         sa, sb = a_sim.get_state(), b_sim.get_state()
         for k in sa:
@@ -832,7 +835,7 @@ def test_carried_forces_match_the_oracle(hip_lib, task, mode):
         a = (0.5 * rng.uniform(-1, 1, (n, sim.action_dim))).astype(np.float32)
         dq, dv, ok, st = util.parity_step(sim, o, a, where=("warm", task, t), carry=True)
         kw_, ow = sim.get_state()["warm"], util.warm_o2k(o)
-        assert np.abs(ow[:100]).max() > 0.1                    # resting cube: ~0.25 N per corner
+        assert np.abs(ow[:100]).max() > 0.02                   # resting cube: m g / 4 per corner (0.25 N; PushCubeLoop's 50 g cube 0.12 N)
         scale = 1.0 + np.abs(ow[:100]).max(axis=0)
         err = (np.abs(kw_[:100] - ow[:100]) / scale).max(axis=0)
         assert np.mean(err[ok] < 2e-3) >= 0.99, (t, np.sort(err[ok])[-5:])
@@ -857,7 +860,7 @@ def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mod
     n = 4096
     sims = {}
     for fam in ("single", "coop1", "coop2", "coop2b"):
-        monkeypatch.setenv("LCR_STEP_KERNEL", fam[:5])
+        monkeypatch.setenv("LCR_STEP_KERNEL", {"single": "single", "coop1": "coop1", "coop2": "coop2", "coop2b": "coop2"}[fam])
         sims[fam] = _vecsim(task, n, observation_mode="state", action_mode=mode, base_seed=5, diagnostics=True)
     rng = np.random.default_rng(1)
     worst = 0.0
@@ -870,8 +873,12 @@ def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mod
             sim.step(a)
         r = sims["single"].get_state()
         c2, c2b = sims["coop2"].get_state(), sims["coop2b"].get_state()
+        c1 = sims["coop1"].get_state()
         for k in r:
             np.testing.assert_array_equal(c2[k], c2b[k], err_msg=f"two-wave kernel not deterministic: {task} step {t} field {k}")
+            # the one- and two-waves-per-SIMD variants are the same source under different register budgets: same bits (this is what makes a
+            # pinned two-wave family bit-identical across shard sizes)
+            np.testing.assert_array_equal(c1[k], c2[k], err_msg=f"two-wave variants differ: {task} step {t} field {k}")
         for fam in ("coop1", "coop2"):
             c = sims[fam].get_state()
             same = (sims[fam].choice.numpy() == sims["single"].choice.numpy()) & (sims[fam].active_count.numpy() == sims["single"].active_count.numpy())
@@ -881,6 +888,7 @@ def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mod
             # same decisions: the difference is rounding (PushCubeLoop's 50 g cube with friction 1.5 amplifies it most)
             assert dq.max() < (5e-3 if task == "push_loop" else 5e-5), (fam, t, float(dq.max()))
     print(f"[families] {task} {mode}: worst |dq| between kernel families {worst:.2e}")
+    assert worst > 0.0          # (the families really are different kernels: identical bits would mean the override did not take)
     for sim in sims.values():
         sim.close()
 
@@ -891,6 +899,6 @@ def test_zz_outlier_census(hip_lib):
     S = util.STATS
     print(f"[parity outliers] env-steps compared {S['envs']} ({S['envs_carry']} of them started from carried constraint forces, {S['out_carry']} of the outliers), outside tolerance {S['out']} ({100.0 * S['out'] / max(S['envs'], 1):.3f} %): "
           f"{S['out_flip']} with a different discrete-decision signature, {S['out_illcond']} ill-conditioned for fp32 (the oracle's fp32 "
-          f"build leaves the tolerance too), {S['out'] - S['out_flip'] - S['out_illcond']} unexplained; worst |dq| {S['max_dq']:.2e}, worst |dqvel| {S['max_dv']:.2e}")
+          f"build leaves the tolerance too, or -- {S.get('out_family', 0)} of them -- the two kernel families disagree with each other), {S['out'] - S['out_flip'] - S['out_illcond']} unexplained; worst |dq| {S['max_dq']:.2e}, worst |dqvel| {S['max_dv']:.2e}")
     assert S["out"] == S["out_flip"] + S["out_illcond"]
     assert S["envs_carry"] > 0.3 * S["envs"]     # the product's default mode (forces carried across steps) is really covered

