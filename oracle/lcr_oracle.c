@@ -1426,6 +1426,9 @@ int orc_model_table(double *out) {
         out[n++] = T.cube_mass; out[n++] = T.cube_inertia; out[n++] = T.mu_cube[0]; out[n++] = T.mu_cube[2];
     }
     out[n++] = WALL_X; out[n++] = WALL_Y0; out[n++] = WALL_Y1; out[n++] = WALL_TOP;
+    /* finger geom class (follower.xml:15): solimp d0, dwidth-limit, width; friction (tangential, torsional, rolling) */
+    out[n++] = SOLIMP_FINGER[0]; out[n++] = SOLIMP_FINGER[1]; out[n++] = SOLIMP_FINGER[2];
+    out[n++] = MU_FINGER[0]; out[n++] = MU_FINGER[2]; out[n++] = MU_FINGER[3];
     for (int s = 0; s < NSPH; s++) { out[n++] = SPH_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = SPH_POS[s][k]; out[n++] = SPH_RAD[s]; }
     for (int s = 0; s < NLPX; s++) { out[n++] = LPX_LINK[s]; for (int k = 0; k < 3; k++) out[n++] = LPX_POS[s][k]; out[n++] = LPX_RAD[s]; out[n++] = LPX_CUBE[s]; }
     return n;

@@ -394,39 +394,54 @@ def _stl_vertices(path):
     return rec["v"].reshape(-1, 3).astype(np.float64)
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
 def mk_model():
+    """Numbers of the MJCF model that the build consumes and a test asserts (tests/test_model_constants.py, tools/gen_model_header.py,
+    oracle/render_oracle.py) -- nothing else: no materials, mesh file names, visual classes, groups or colours."""
     import xml.etree.ElementTree as ET
 
     out = {"_generated_by": "tests/golden/make_golden.py:mk_model", "_source": "gym_lowcostrobot/assets/low_cost_robot_6dof/*.xml, follower_meshes/*.stl"}
     root = ET.parse(os.path.join(ASSETS, "follower.xml")).getroot()
-    fol = {"compiler": _attrs(root.find("compiler")), "option": _attrs(root.find("option")), "defaults": {}, "bodies": [],
-           "meshes": {m.get("name"): m.get("file") for m in root.find("asset").findall("mesh")},
-           "excludes": [_attrs(e) for e in root.find("contact").findall("exclude")],
-           "actuators": [dict(_attrs(a), tag=a.tag) for a in root.find("actuator")]}
+    defaults, bodies = {}, []
     for d in root.find("default").findall("default"):
-        _defaults(d, "main", fol["defaults"])
+        _defaults(d, "main", defaults)
     for b in root.find("worldbody").findall("body"):
-        _body_tree(b, "world", fol["bodies"])
+        _body_tree(b, "world", bodies)
+    meshes = {m.get("name"): m.get("file") for m in root.find("asset").findall("mesh")}
+    fol = {"option": _pick(_attrs(root.find("option")), ("integrator", "cone", "impratio", "timestep")),
+           "defaults": {"follower": {"joint": _pick(defaults["follower"].get("joint"), ("armature", "damping", "actuatorfrcrange")),
+                                     "position": _pick(defaults["follower"].get("position"), ("kp", "kv", "inheritrange"))},
+                        "finger": {"geom": _pick(defaults["finger"].get("geom"), ("priority", "condim", "solimp", "friction"))}},
+           "bodies": [{"name": b["name"], "parent": b["parent"], **_pick(b, ("pos", "quat")),
+                       "inertial": _pick(b["inertial"], ("pos", "quat", "mass", "diaginertia")) if b["inertial"] else None,
+                       "joints": [_pick(j, ("name", "axis", "range")) for j in b["joints"]],
+                       "sites": [_pick(x, ("name", "pos")) for x in b["sites"]]} for b in bodies]}
     out["follower"] = fol
     out["scenes"] = {}
     for sc in SCENES:
         r = ET.parse(os.path.join(ASSETS, sc + ".xml")).getroot()
         wb = r.find("worldbody")
-        rec = {"option": _attrs(r.find("option")), "include_after_option": [c.tag for c in r].index("include") > [c.tag for c in r].index("option"),
-               "world_geoms": [_attrs(g) for g in wb.findall("geom")], "cameras": [_attrs(c) for c in wb.findall("camera")], "bodies": []}
+        sb = []
         for b in wb.findall("body"):
-            _body_tree(b, "world", rec["bodies"])
+            _body_tree(b, "world", sb)
+        geom_keys = ("name", "type", "size", "pos", "friction", "condim", "priority", "solref")
+        rec = {"include_after_option": [c.tag for c in r].index("include") > [c.tag for c in r].index("option"),
+               "world_geoms": [_pick(_attrs(g), geom_keys) for g in wb.findall("geom")],
+               "cameras": [_pick(_attrs(c), ("name", "pos", "xyaxes", "euler", "quat")) for c in wb.findall("camera")],
+               "bodies": [{"name": b["name"], **_pick(b, ("pos",)),
+                           "inertial": _pick(b["inertial"], ("mass", "diaginertia")) if b["inertial"] else None,
+                           "joints": [_pick(j, ("type",)) for j in b["joints"]],
+                           "geoms": [_pick(g, geom_keys) for g in b["geoms"]]} for b in sb]}
         out["scenes"][sc] = rec
-    aabb = {}
+    # hull extents of the four links that carry sphere proxies (DESIGN.md D3): bounding box and slab extents along the link's long axis (x)
     mdir = os.path.join(ASSETS, "follower_meshes")
-    for name, fn in fol["meshes"].items():
-        v = _stl_vertices(os.path.join(mdir, fn))
-        aabb[name] = {"min": [round(float(x), 6) for x in v.min(0)], "max": [round(float(x), 6) for x in v.max(0)], "n_vertices": int(len(v))}
-    out["mesh_aabb"] = aabb
-    # slab extents of the link hulls along the link's long axis (x): the data the sphere proxies of DESIGN.md D3 are fitted to
-    slabs = {}
+    aabb, slabs = {}, {}
     for name in ("link_3_collision", "link_4_collision", "link_5_collision", "link_6_collision"):
-        v = _stl_vertices(os.path.join(mdir, fol["meshes"][name]))
+        v = _stl_vertices(os.path.join(mdir, meshes[name]))
+        aabb[name] = {"min": [round(float(x), 6) for x in v.min(0)], "max": [round(float(x), 6) for x in v.max(0)]}
         edges = np.linspace(v[:, 0].min(), v[:, 0].max(), 9)
         rows = []
         for a, b in zip(edges[:-1], edges[1:]):
@@ -435,6 +450,7 @@ def mk_model():
                 rows.append({"x": [round(float(a), 5), round(float(b), 5)], "y": [round(float(w[:, 1].min()), 5), round(float(w[:, 1].max()), 5)],
                              "z": [round(float(w[:, 2].min()), 5), round(float(w[:, 2].max()), 5)]})
         slabs[name] = rows
+    out["mesh_aabb"] = aabb
     out["mesh_slabs_x"] = slabs
     return out
 

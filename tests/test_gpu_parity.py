@@ -378,7 +378,7 @@ def test_pinch_grasp_finger_cube_contacts(hip_lib, monkeypatch, task, carry):
     for t in range(6):
         a = rng.uniform(-0.1, 0.1, (n, sim.action_dim)).astype(np.float32); a[:, 5] = 0.2
         dq, dv, ok, st = util.parity_step(sim, o, a, 2e-5, 4e-3, where=("pinch", task, t))
-        assert ok.mean() >= 0.97, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
+        assert ok.mean() >= 0.99, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
     sim.close()
 
 
@@ -404,7 +404,9 @@ def test_rolling_rows_finger_cube_condim6(hip_lib, monkeypatch, task, carry):
             a[:, 5] = 0.2
         # (PushCubeLoop: torsional and rolling coefficients 1.5 make the pinched cube a stiff 12-row problem: twice the position tolerance)
         dq, dv, ok, st = util.parity_step(sim, o, a, 4e-5 if task == "push_loop" else 2e-5, 4e-3, where=("roll", task, t))
-        assert ok.mean() >= (0.9 if task == "push_loop" else 0.97), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])   # (every outlier is explained: parity_step)
+        # (every outlier is explained: parity_step; the pinched 50 g PushCubeLoop cube with torsional / rolling coefficients 1.5 is a stiff
+        #  12-row problem that 4 PGS sweeps leave far from converged: the documented exception)
+        assert ok.mean() >= (0.95 if task == "push_loop" else 0.99), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
         assert ((o.active_mask >> 12) & 3).astype(bool).mean() > 0.5 or t > 2   # finger<->cube slots really are active
     # the rolling rows change the result (else the test would not see them): same state, kernel without them
     sim4, o4 = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, finger_cube_condim=4)
@@ -466,7 +468,7 @@ def test_push_loop_parity(hip_lib, monkeypatch, carry):
         # 50 g cubes thrown at the rails at ~1 m/s: a rail-vertex flip moves more than the default outlier bound
         dq, dv, ok, st = util.parity_step(sim, o, a, 2e-5, 4e-3, max_dq=5e-2, max_dv=5.0, where=("loop", t))
         out = sim.outputs()
-        assert ok.mean() >= 0.98, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
+        assert ok.mean() >= 0.99, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
         same = out["is_success"] == o.is_success.astype(bool)
         assert same.mean() > 0.995
         np.testing.assert_array_equal(st["current_goal"][same], o.goal[same])
@@ -617,7 +619,7 @@ def test_link_proxy_contacts(hip_lib, monkeypatch, task, bit, near, mode, carry)
         # selected states press up to three arm contacts (both finger tips + a link proxy: 11 rows on 6 dofs) on the floor at
         # once; 4 PGS sweeps leave such sets far from converged and the rounding of the two formulations differs more: 4e-5
         dq, dv, ok, st = util.parity_step(sim, o, a, 4e-5, 4e-3, where=("link", task, bit, t))
-        assert ok.mean() >= 0.97, (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
+        assert ok.mean() >= 0.99, (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
         seen += int(((o.active_mask >> bit) & 1).sum())
         assert np.array_equal((sim.active_mask.numpy() >> bit) & 1, (o.active_mask >> bit) & 1) or ok.mean() < 1.0
     assert seen >= n        # the slot under test was really exercised
@@ -638,7 +640,7 @@ def test_converged_solver_mode(hip_lib, monkeypatch, task, carry):
     for t in range(6):
         a = rng.uniform(-1, 1, (n, sim.action_dim)).astype(np.float32)
         dq, dv, ok, st = util.parity_step(sim, o, a, 5e-5, 1e-2, where=("converged", task, t))
-        assert ok.mean() >= 0.97, (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
+        assert ok.mean() >= 0.99, (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
         ks, os_ = sim.max_sweeps.numpy(), o.max_sweeps
         assert (ks >= os_ - 1).all() and ks.max() <= 50      # a lane sweeps at least as long as its own criterion asks (wave-uniform exit)
     assert o.max_sweeps.max() > 4                            # the fixed default of 4 sweeps would have stopped earlier
@@ -781,7 +783,7 @@ def test_constraint_forces_carried_across_control_steps(hip_lib, task):
             o.step(a, threads=0); sim.step(a)
             st = util.pull_state(sim)
             dq = np.abs(st["qpos"] - o.qpos[:, : sim.nq]).max(axis=1)
-            assert np.mean(dq <= 2e-5 * (t + 1)) >= 0.97 and np.median(dq) < 2e-6, (compat, t, np.median(dq), np.sort(dq)[-4:])
+            assert np.mean(dq <= 2e-5 * (t + 1)) >= 0.99 and np.median(dq) < 2e-6, (compat, t, np.median(dq), np.sort(dq)[-4:])
         finals[compat] = st["qpos"].copy()
         sim.close()
     d = np.abs(finals[0] - finals[_capi.COMPAT_COLD_SOLVE_EACH_STEP]).max(axis=1)

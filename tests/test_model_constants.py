@@ -47,6 +47,10 @@ def test_oracle_tables_equal_the_mjcf_numbers():
     assert t["armature"] == d["joint"]["armature"] and t["damping"] == d["joint"]["damping"]      # :7
     assert [-t["frcrange"], t["frcrange"]] == d["joint"]["actuatorfrcrange"]
     assert t["kp"] == d["position"]["kp"] and t["kv"] == d["position"]["kv"] and d["position"]["inheritrange"] == 1  # :8
+    fg = G["follower"]["defaults"]["finger"]["geom"]   # :15 class="finger": priority 1, condim 6, solimp "0.015 1 0.036", friction 1.5
+    assert fg["priority"] == 1 and fg["condim"] == 6 and fg["friction"] == 1.5 == t["finger"]["mu_tan"]
+    assert fg["solimp"] == [t["finger"]["solimp_d0"], t["finger"]["solimp_dmax"], t["finger"]["solimp_width"]]
+    assert (t["finger"]["mu_tors"], t["finger"]["mu_roll"]) == (0.005, 0.0001)      # MuJoCo geom friction defaults (torsional, rolling): MJ-DOC
     opt = G["follower"]["option"]
     assert t["timestep"] == opt["timestep"] and opt["integrator"] == "implicitfast" and opt["cone"] == "elliptic" and opt["impratio"] == 100  # :3
     assert BODIES["base_link"]["quat"] == [-0.707, 0.0, 0.0, 0.707]              # :51
