@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
 ABI_VERSION = 3
-NWARM = 104   # LCR_NWARM: floats per env of carried constraint forces (layout: include/lcr.h)
+NWARM = 124   # LCR_NWARM: floats per env of carried constraint forces (layout: include/lcr.h)
 TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
@@ -62,7 +62,7 @@ class LcrConfig(ctypes.Structure):
         ("diagnostics", ctypes.c_int32),
         ("finger_cube_condim", ctypes.c_int32),
         ("step_kernel", ctypes.c_int32),
-        ("_reserved", ctypes.c_int32),
+        ("cc_points", ctypes.c_int32),
     ]
 
 

@@ -33,9 +33,9 @@ def _newer(target, deps):
 UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
          ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels.hip", "lcr_kernels_walls.o", ["-DLCR_PART=1"]),
          ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
-         # the two-cooperating-waves family (lcr_kernels2.hip): 10 one cube, 11 PushCubeLoop, 12 StackTwoCubes
+         # the two-cooperating-waves family (lcr_kernels2.hip): 10 one cube, 11 PushCubeLoop, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point manifold
          ("lcr_kernels2.hip", "lcr_kernels2.o", ["-DLCR_PART=10"]), ("lcr_kernels2.hip", "lcr_kernels2_walls.o", ["-DLCR_PART=11"]),
-         ("lcr_kernels2.hip", "lcr_kernels2_stack.o", ["-DLCR_PART=12"])]
+         ("lcr_kernels2.hip", "lcr_kernels2_stack.o", ["-DLCR_PART=12"]), ("lcr_kernels2.hip", "lcr_kernels2_stack_cc8.o", ["-DLCR_PART=13"])]
 
 
 def build(force=False, verbose=False):

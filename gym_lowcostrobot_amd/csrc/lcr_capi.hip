@@ -156,6 +156,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->n_substeps <= 0) return fail(LCR_ERR_INVALID, "n_substeps must be positive");
     if (cfg->pgs_iters < 0 && !(cfg->pgs_tol > 0)) return fail(LCR_ERR_INVALID, "pgs_tol must be positive in converged mode (pgs_iters < 0)");
     if (cfg->finger_cube_condim != 0 && cfg->finger_cube_condim != 4 && cfg->finger_cube_condim != 6) return fail(LCR_ERR_INVALID, "finger_cube_condim must be 4 or 6");
+    if (cfg->cc_points != 0 && cfg->cc_points != 4 && cfg->cc_points != 8) return fail(LCR_ERR_INVALID, "cc_points must be 4 or 8");
+    if (cfg->cc_points == 8 && cfg->pgs_iters < 0) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 is implemented by the two-wave kernels, the converged solver mode (pgs_iters < 0) by the one-wave kernels");
     if (cfg->step_kernel < 0 || cfg->step_kernel > 2) return fail(LCR_ERR_INVALID, "step_kernel must be 0 (by shard size), 1 (one wave per 64 envs) or 2 (two cooperating waves)");
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
@@ -284,11 +286,13 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             D.coop = waves2 <= simds ? 1 : 0;
             if (cfg->step_kernel == 1) D.coop = 0;
             else if (cfg->step_kernel == 2) D.coop = waves2 <= simds ? 1 : 2;
+            D.cc8 = (cfg->task == LCR_TASK_STACK && cfg->cc_points == 8) ? 1 : 0;
             if (const char *ov = getenv("LCR_STEP_KERNEL")) {
                 if (strcmp(ov, "single") == 0) D.coop = 0;
                 else if (strcmp(ov, "coop1") == 0) D.coop = 1;
                 else if (strcmp(ov, "coop2") == 0) D.coop = 2;
             }
+            if (D.cc8 && !D.coop) D.coop = waves2 <= simds ? 1 : 2;   // the eight-point manifold lives in the two-wave kernels only
         }
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

@@ -4,7 +4,7 @@
 
 #define LCR_OBS_DIM 18
 
-constexpr int LCR_DEV_NWARM = 104;   // floats per env in LcrDev::warm (layout: lcr_kernels.hip WARM_*; = LCR_NWARM of include/lcr.h)
+constexpr int LCR_DEV_NWARM = 124;   // floats per env in LcrDev::warm (layout: lcr_kernels.hip WARM_*; = LCR_NWARM of include/lcr.h)
 
 struct LcrDev {
     int n;            // envs on this device
@@ -60,6 +60,7 @@ struct LcrDev {
     float inv_mu_fcr2;   // finger<->cube: 1 / mu_roll^2
     int roll;            // 1: finger<->cube slots carry the two rolling rows
     float *warm;         // [LCR_NWARM][n] constraint forces carried from one control step to the next (warm start), or null
+    int cc8;             // Stack: eight-point cube<->cube manifold (lcr_config.cc_points = 8; two-wave kernels only)
     int coop;            // 0: one wave per 64 envs (lcr_kernels.hip); 1 / 2: two cooperating waves per 64 envs (lcr_kernels2.hip) compiled for
                          // one / two waves per SIMD (<= 512 / <= 256 registers per lane)
     int big_lds;         // Stack: the shard has at most three waves per CU -> the variant that keeps every g row in LDS (46 / 52 KiB per wave)
@@ -78,6 +79,7 @@ int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void 
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_step2_walls(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
+int lcr_launch_step2_stack_cc8(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,
                      unsigned long long base_seed, void *stream);
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,

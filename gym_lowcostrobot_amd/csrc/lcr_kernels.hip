@@ -783,7 +783,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
                 const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                 T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
-                track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
+                track(d0, d1, d2, d3, T.f[0], T.f[1], T.f[2], T.f[3]);   // (converged mode: net change of the sweep, after the cone projection)
                 // a += M^-1 J^T delta
                 ca[c].z = fmaf(minv, d0, ca[c].z);
                 ca[c].y = fmaf(minv, d1, ca[c].y);
@@ -833,7 +833,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
                     const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
                     const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
-                    track(d0, d1a, d2a, d3a, fn, f[1] + e1, f[2] + e2, f[3] + e3);
+                    track(d0, e1, e2, e3, fn, f[1] + e1, f[2] + e2, f[3] + e3);
                     ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
                     ccl[(size_t)(s * CC_REC + 5) * CS] = f[2] + e2; ccl[(size_t)(s * CC_REC + 6) * CS] = f[3] + e3;
                     // a += M^-1 J^T delta: the force change F acts at the contact point on cube 1 and, negated, on cube 0
@@ -874,7 +874,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
                     const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
                     T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
-                    track(d0, d1a, d2a, d3a, T.f[0], T.f[1], T.f[2], T.f[3]);
+                    track(d0, d1, d2, d3, T.f[0], T.f[1], T.f[2], T.f[3]);
                     const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
                     const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
                     const float ab = iinv * sg * (r.z * d0 - r.x * d2);
@@ -964,9 +964,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         vq[1] = fmaf(-iinv_e * dlt, pq[0], vq[1]);   // t1.(t2 x rc) =  p_0
                     }
                 };
-                float dtr[NRW];
-#pragma unroll
-                for (int r = 0; r < NRW; r++) dtr[r] = 0.f;
 #pragma unroll
                 for (int r = 0; r < nrow; r++) {
                     const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
@@ -979,7 +976,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (r == 0) nf = fmaxf(nf, 0.f);
                     float dlt = nf - T.f[r];
                     T.f[r] += dlt;
-                    dtr[r] = dlt;
                     {
                         const float2v d2 = {dlt, dlt};
 #pragma unroll
@@ -1005,8 +1001,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         // (the tracked scalars are not needed any more: the next slot starts from the updated accelerations)
                     }
                 }
-                track(dtr[0], dtr[1], dtr[2], dtr[3], T.f[0], T.f[1], T.f[2], T.f[3]);
-                if constexpr (ROLL) { if (nrow == 6) track(dtr[4], dtr[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
+                // (converged mode: the NET force change of this sweep, after the cone projection -- a sliding contact at its projected fixed
+                //  point has a non-zero raw tangential update every sweep, which is then scaled back)
+                track(T.f[0] - f_in[0], T.f[1] - f_in[1], T.f[2] - f_in[2], T.f[3] - f_in[3], T.f[0], T.f[1], T.f[2], T.f[3]);
+                if constexpr (ROLL) { if (nrow == 6) track(T.f[4] - f_in[4], T.f[5] - f_in[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
                 f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
                 if (may_cube) {
                     const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
@@ -1519,7 +1517,7 @@ int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void 
     const hipStream_t st = (hipStream_t)stream;
     if (P.coop && P.pgs_iters >= 0 && P.diag != 2) {   // two cooperating waves per 64 envs (no converged mode, no per-wave cycle read-back)
         if (P.walls) return lcr_launch_step2_walls(P, action_dev, ee_mode, P.coop, stream);
-        if (P.task == 4) return lcr_launch_step2_stack(P, action_dev, ee_mode, P.coop, stream);
+        if (P.task == 4) return P.cc8 ? lcr_launch_step2_stack_cc8(P, action_dev, ee_mode, P.coop, stream) : lcr_launch_step2_stack(P, action_dev, ee_mode, P.coop, stream);
         return lcr_launch_step2_one_cube(P, action_dev, ee_mode, P.coop, stream);
     }
     if (P.walls) return lcr_launch_step_walls(P, action_dev, ee_mode, st);

@@ -45,15 +45,17 @@ namespace {
 //  PARK: 16 fields              aref / inv of the finger<->floor slots (wave A only; read once per sweep as 16-B vectors)
 //  further hand-overs reuse these areas in phases where they are idle: Cholesky factor L (B -> A at barrier X) in the g rows of slots
 //  3, 4; scaled arm acceleration y (A -> B at barrier Y) in POSE; joint acceleration qacc (B -> A at barrier E) in ACC
-template <int NC, bool ROLL> struct Lds2 {
+template <int NC, bool ROLL, bool CC8 = false> struct Lds2 {
     static constexpr int GR = ROLL ? 24 : 20;
     static constexpr int G0 = 0;
     static constexpr int CC0 = GR * LDS_ROW;
-    static constexpr int POSE0 = CC0 + (NC == 2 ? LDS_CC_FLOATS : 0);
+    static constexpr int POSE0 = CC0 + (NC == 2 ? (CC8 ? 2 : 1) * LDS_CC_FLOATS : 0);   // (CC8: eight cube<->cube contact records)
     static constexpr int ACC0 = POSE0 + NC * 13 * 64;
     static constexpr int FLAG0 = ACC0 + NC * 6 * 64;
     static constexpr int PARK0 = FLAG0 + 64;                 // aref[4] | inv[4] of the finger<->floor slots 2, 3 as 16-B vectors: [slot][aref|inv][lane][4]
-    static constexpr int TOTAL = PARK0 + 2 * 2 * 64 * 4;
+    static constexpr bool HAS_PARK = !CC8;                   // (eight cube<->cube records: no room, the constants stay in wave A's registers --
+                                                             //  that variant runs one wave per SIMD: 2 x 79.7 KiB per CU)
+    static constexpr int TOTAL = PARK0 + (HAS_PARK ? 2 * 2 * 64 * 4 : 0);
     // hand-over of the Cholesky factor (21 + 6 floats per lane, wave B -> wave A at barrier X): aliases the g rows of slots 3 and 4,
     // which wave A writes only after it has read the factor
     static constexpr int LFAC0 = G0 + (ROLL ? 16 : 12) * LDS_ROW;
@@ -73,9 +75,9 @@ DEV void wg_barrier() { __syncthreads(); }   // s_waitcnt + s_barrier: LDS (and 
 // ================================================================================================
 // wave A: the arm
 // ================================================================================================
-template <int NC, bool EE, bool WALLS, bool ROLL>
+template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8>
 DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *lds, const int lane, const int e, const bool valid) {
-    using LL = Lds2<NC, ROLL>;
+    using LL = Lds2<NC, ROLL, CC8>;
     using namespace lcrm;
     constexpr int NRW = ROLL ? 6 : 4;
     const int N = P.n;
@@ -459,7 +461,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                         else { dca[0] = dca[0] + dl; dcal[0] = dcal[0] + da; }
                     }
                 }
-                if (s == 2 || s == 3) {   // park the per-substep constants of the finger<->floor slots (read back once per sweep)
+                if (LL::HAS_PARK && (s == 2 || s == 3)) {   // park the per-substep constants of the finger<->floor slots (read back once per sweep)
                     float4v *pk = reinterpret_cast<float4v *>(lds + LL::PARK0) + (size_t)((s - 2) * 2) * 64 + lane;
                     pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
                     pk[64] = float4v{T.inv[0], T.inv[1], T.inv[2], T.inv[3]};
@@ -572,7 +574,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 float arefv[NRW], invv[NRW];
 #pragma unroll
                 for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; }
-                if (s == 2 || s == 3) {
+                if (LL::HAS_PARK && (s == 2 || s == 3)) {
                     const float4v *pk = reinterpret_cast<const float4v *>(lds + LL::PARK0) + (size_t)((s - 2) * 2) * 64 + lane;
                     const float4v a4 = pk[0], i4 = pk[64];
                     arefv[0] = a4.x; arefv[1] = a4.y; arefv[2] = a4.z; arefv[3] = a4.w;
@@ -916,9 +918,12 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 // ================================================================================================
 // wave B: the cubes
 // ================================================================================================
-template <int NC, bool EE, bool WALLS, bool ROLL>
+template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8>
 DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, const bool valid) {
-    using LL = Lds2<NC, ROLL>;
+    using LL = Lds2<NC, ROLL, CC8>;
+    // cube<->cube manifold points kept (Stack): 4 = the extremes along the diagonals of the reference face; CC8 (lcr_config.cc_points = 8,
+    // as many as MuJoCo's mjc_BoxBox may return): also the extremes along its two axes -- narrows deviation D5
+    constexpr int NCC = CC8 ? 8 : 4;
     using namespace lcrm;
     const int N = P.n;
     // this wave's copy of the arm configuration (for the joint-space inertia): it starts from the configuration wave A leaves behind
@@ -959,7 +964,9 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     const bool carry = P.warm != nullptr;
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
     float Wfloor[NC][4][4], Wwall[4][4];
-    bool cc_prev[4] = {false, false, false, false};
+    bool cc_prev[NCC];
+#pragma unroll
+    for (int s = 0; s < NCC; s++) cc_prev[s] = false;
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -980,10 +987,10 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     const size_t CS = 64;
     if constexpr (NC == 2) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            cc_prev[s] = wld(WARM_CCPREV + s) != 0.f;
+        for (int s = 0; s < NCC; s++) {
+            cc_prev[s] = wld(s < 4 ? WARM_CCPREV + s : WARM_CCPREV2 + (s - 4)) != 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(WARM_CC + 4 * s + r);
+            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld((s < 4 ? WARM_CC + 4 * s : WARM_CC2 + 4 * (s - 4)) + r);
         }
     }
     publish_pose();
@@ -1267,7 +1274,9 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         }
 
         // ---- collision: cube <-> cube (Stack); records in LDS (this wave only) ----
-        bool cc_act[4] = {false, false, false, false};
+        bool cc_act[NCC];
+#pragma unroll
+        for (int s = 0; s < NCC; s++) cc_act[s] = false;
         bool cc_any = false;
         f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
         if constexpr (NC == 2) {
@@ -1287,10 +1296,10 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
             const bool touching = best < 0.f;
             int cnt = 0;
-            f3 cpos[4];
-            float cdist[4] = {0.f, 0.f, 0.f, 0.f};
+            f3 cpos[NCC];
+            float cdist[NCC];
 #pragma unroll
-            for (int s = 0; s < 4; s++) cpos[s] = mk(0.f, 0.f, 0.f);
+            for (int s = 0; s < NCC; s++) { cpos[s] = mk(0.f, 0.f, 0.f); cdist[s] = 0.f; }
             if (__any(touching)) {
                 const bool Ais0 = bax < 3;
                 const int k = Ais0 ? bax : bax - 3;
@@ -1321,12 +1330,14 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     f3 d = V[i] - cA;
                     Vu[i] = dot(d, u); Vv[i] = dot(d, v); Vd[i] = dot(d, m) - CH;
                 }
-                float skey[4] = {0.f, 0.f, 0.f, 0.f};
-                int sidx[4] = {-1, -1, -1, -1};
-                auto consider = [&](bool ok, int cand, f3 Pp, float dist, float cu, float cv_) {
-                    const float key[4] = {cu + cv_, -cu + cv_, -cu - cv_, cu - cv_};
+                float skey[NCC];
+                int sidx[NCC];
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < NCC; s++) { skey[s] = 0.f; sidx[s] = -1; }
+                auto consider = [&](bool ok, int cand, f3 Pp, float dist, float cu, float cv_) {
+                    const float key[8] = {cu + cv_, -cu + cv_, -cu - cv_, cu - cv_, cu, cv_, -cu, -cv_};   // diagonals of the reference face, then its axes
+#pragma unroll
+                    for (int s = 0; s < NCC; s++) {
                         bool t = ok && (sidx[s] < 0 || key[s] > skey[s]);
                         skey[s] = t ? key[s] : skey[s];
                         sidx[s] = t ? cand : sidx[s];
@@ -1367,20 +1378,20 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < NCC; s++) {
                     bool dup = false;
 #pragma unroll
                     for (int s2 = 0; s2 < s; s2++) dup = dup || (sidx[s2] == sidx[s]);
                     cc_act[s] = sidx[s] >= 0 && !dup;
                     cnt += cc_act[s] ? 1 : 0;
-                    if (P.diag) diag_choice(DG, cc_act[s], 8 + s, sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0.f ? 1 : 0));
+                    if (P.diag) diag_choice(DG, cc_act[s], s < 4 ? 8 + s : 24 + (s - 4), sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0.f ? 1 : 0));
                 }
             }
             cc_any = __any(cnt > 0) != 0;
             if (cc_any) {
                 make_frame(ccn, cct1, cct2);
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < NCC; s++) {
                     const f3 r0 = cpos[s] - cp[0], r1 = cpos[s] - cp[1];
                     float imp = impedance(cdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
                     float Rn = fmaxf((1.f - imp) * rcp(imp) * (2.f * minv), 1e-15f);
@@ -1590,7 +1601,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             if constexpr (NC == 2) {
                 if (cc_any) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
+                    for (int s = 0; s < NCC; s++) {
                         const f3 pos = mk(ccl[(size_t)(s * CC_REC + 0) * CS], ccl[(size_t)(s * CC_REC + 1) * CS], ccl[(size_t)(s * CC_REC + 2) * CS]);
                         const f3 r0 = pos - cp[0], r1 = pos - cp[1];
                         const float Rn = ccl[(size_t)(s * CC_REC + 15) * CS];
@@ -1832,7 +1843,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 
         // ---- keep the forces for the next substep's warm start (inactive slots hold zero) ----------------
 #pragma unroll
-        for (int s = 0; s < 4; s++) cc_prev[s] = cc_act[s];
+        for (int s = 0; s < NCC; s++) cc_prev[s] = cc_act[s];
         if constexpr (WALLS) {
 #pragma unroll
             for (int s = 0; s < 4; s++)
@@ -1849,6 +1860,10 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             for (int s = 0; s < 4; s++) {
                 if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
                 if (WALLS) m |= WS[s].act ? (1u << (8 + s)) : 0u;
+            }
+            if constexpr (CC8) {
+#pragma unroll
+                for (int s = 4; s < 8; s++) m |= cc_act[s] ? (1u << (24 + (s - 4))) : 0u;
             }
             m |= AS01[0].act ? (1u << 12) : 0u; m |= AS01[1].act ? (1u << 13) : 0u;
             DGtot.mask |= m;
@@ -1938,10 +1953,10 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         }
         if constexpr (NC == 2) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                wst(WARM_CCPREV + s, cc_prev[s] ? 1.f : 0.f);
+            for (int s = 0; s < NCC; s++) {
+                wst(s < 4 ? WARM_CCPREV + s : WARM_CCPREV2 + (s - 4), cc_prev[s] ? 1.f : 0.f);
 #pragma unroll
-                for (int r = 0; r < 4; r++) wst(WARM_CC + 4 * s + r, cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
+                for (int r = 0; r < 4; r++) wst((s < 4 ? WARM_CC + 4 * s : WARM_CC2 + 4 * (s - 4)) + r, cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
             }
         }
     }
@@ -1951,21 +1966,21 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 // the kernel: workgroup = 2 waves x 64 lanes over 64 envs.  OCC = waves per SIMD the register budget must allow
 // (1: up to 512 registers per lane -- shards that put at most one wave on a SIMD; 2: <= 256)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool WALLS, bool ROLL, int OCC>
+template <int NC, bool EE, bool WALLS, bool ROLL, int OCC, bool CC8>
 __global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[Lds2<NC, ROLL>::TOTAL];
+    __shared__ float lds[Lds2<NC, ROLL, CC8>::TOTAL];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
     const int e = valid ? e_raw : P.n - 1;   // tail lanes shadow the last env, their stores are masked
 #if defined(LCR2_ONLY_ARM)        // (register-budget study only: one role compiled alone; such a kernel must not be launched)
-    arm_program<NC, EE, WALLS, ROLL>(P, action, lds, lane, e, valid);
+    arm_program<NC, EE, WALLS, ROLL, CC8>(P, action, lds, lane, e, valid);
 #elif defined(LCR2_ONLY_CUBE)
-    cube_program<NC, EE, WALLS, ROLL>(P, lds, lane, e, valid);
+    cube_program<NC, EE, WALLS, ROLL, CC8>(P, lds, lane, e, valid);
 #else
-    if (wave == 0) arm_program<NC, EE, WALLS, ROLL>(P, action, lds, lane, e, valid);
-    else cube_program<NC, EE, WALLS, ROLL>(P, lds, lane, e, valid);
+    if (wave == 0) arm_program<NC, EE, WALLS, ROLL, CC8>(P, action, lds, lane, e, valid);
+    else cube_program<NC, EE, WALLS, ROLL, CC8>(P, lds, lane, e, valid);
 #endif
 }
 
@@ -1979,10 +1994,10 @@ static int check_launch2() {
     return err == hipSuccess ? 0 : (int)err;
 }
 
-template <int NC, bool WALLS>
+template <int NC, bool WALLS, bool CC8>
 static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode, int occ, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
-#define LCR2_GO(EE, ROLL, OCC) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, WALLS, ROLL, OCC>), dim3(blocks), dim3(128), 0, st, P, action_dev)
+#define LCR2_GO(EE, ROLL, OCC) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, WALLS, ROLL, OCC, CC8>), dim3(blocks), dim3(128), 0, st, P, action_dev)
     if (occ >= 2) {
         if (ee_mode) { if (P.roll) LCR2_GO(true, true, 2); else LCR2_GO(true, false, 2); }
         else { if (P.roll) LCR2_GO(false, true, 2); else LCR2_GO(false, false, 2); }
@@ -1996,16 +2011,21 @@ static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode,
 
 #if LCR_HAS_PART(10)
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<1, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+    return launch2_family<1, false, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
 }
 #endif
 #if LCR_HAS_PART(11)
 int lcr_launch_step2_walls(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<1, true>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+    return launch2_family<1, true, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
 }
 #endif
 #if LCR_HAS_PART(12)
 int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<2, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+    return launch2_family<2, false, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+}
+#endif
+#if LCR_HAS_PART(13)
+int lcr_launch_step2_stack_cc8(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {   // eight-point cube<->cube manifold
+    return launch2_family<2, false, true>(P, action_dev, ee_mode, 1, (hipStream_t)stream);   // (74-80 KiB of LDS per workgroup: one wave per SIMD at most)
 }
 #endif

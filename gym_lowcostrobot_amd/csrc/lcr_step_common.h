@@ -248,7 +248,7 @@ template <bool ROLL> constexpr int as_rows(int s) { return (ROLL && s < 2) ? 6 :
 template <bool ROLL, int NC, bool BIG> constexpr int as_row0(int s) { return (ROLL && (NC == 1 || BIG)) ? (s < 2 ? 6 * s : 12 + 4 * (s - 2)) : 4 * s; }
 constexpr int AS_TOTAL_ROWS = 20;
 // layout of LcrDev::warm ([LCR_NWARM][N] floats): the Warm fields of one env between two control steps
-constexpr int WARM_FLOOR = 0, WARM_ARM = 32, WARM_LIM = 62, WARM_WALL = 68, WARM_CC = 84, WARM_CCPREV = 100;   // LCR_DEV_NWARM = 104 (lcr_device.h) = LCR_NWARM (include/lcr.h, where the layout is part of the ABI)
+constexpr int WARM_FLOOR = 0, WARM_ARM = 32, WARM_LIM = 62, WARM_WALL = 68, WARM_CC = 84, WARM_CCPREV = 100, WARM_CC2 = 104, WARM_CCPREV2 = 120;   // (.._CC2: cube<->cube slots 4-7 of the eight-point manifold)   // LCR_DEV_NWARM = 124 (lcr_device.h) = LCR_NWARM (include/lcr.h, where the layout is part of the ABI)
 template <int NC, int NRW>
 struct Warm {
     float floor[NC][4][4];

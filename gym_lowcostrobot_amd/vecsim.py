@@ -73,6 +73,7 @@ class VecSim:
         diagnostics=False,
         finger_cube_condim=None,
         step_kernel="auto",
+        cc_points=None,
     ):
         self.L = _capi.load()
         if action_mode not in ACTION_MODES:
@@ -111,6 +112,8 @@ class VecSim:
         if step_kernel not in _capi.STEP_KERNELS:
             raise ValueError(f"invalid step_kernel {step_kernel!r} (auto | single | coop)")
         cfg.step_kernel = _capi.STEP_KERNELS[step_kernel]   # kernel family; pin it when results must be bit-identical across shardings
+        if cc_points is not None:   # StackTwoCubes: 4 (default) or 8 cube<->cube manifold points
+            cfg.cc_points = int(cc_points)
         self.cfg = cfg
         self.n = int(n_envs)
         self.device = int(device)

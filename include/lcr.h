@@ -101,7 +101,10 @@ typedef struct lcr_config {
                                   per 64 envs always; 2 = two cooperating waves always.  The families regroup the same arithmetic and agree to
                                   fp32 rounding (~1e-7 per control step), not bit for bit: a job that must give identical bits under
                                   different shardings pins 1 or 2 (results are bit-identical across shardings within a family). */
-    int32_t _reserved;
+    int32_t cc_points;         /* StackTwoCubes: cube<->cube manifold points kept per substep.  4 (default, 0 = default): the extremes along the diagonals
+                                  of the reference face; 8: also the extremes along its two axes -- as many points as MuJoCo's box-box
+                                  collider may return (stack_two_cubes.xml:25-35; narrows deviation D5).  8 runs on the
+                                  two-cooperating-waves kernels whatever step_kernel says. */
 } lcr_config;
 
 typedef struct lcr_sim lcr_sim;
@@ -208,11 +211,13 @@ int lcr_get_outputs(lcr_sim *sim, lcr_out_view *out);
  *   rows 68..83  rails (PushCubeLoop) [slot s][row k]               at 68 + 4 s + k
  *   rows 84..99  cube<->cube (Stack)  [slot s][row k]               at 84 + 4 s + k
  *   rows 100..103 cube<->cube slot s was active in the last substep (0.0 / 1.0)
+ *   rows 104..119 cube<->cube slots 4..7 of the eight-point manifold (cc_points = 8) [slot s - 4][row k]  at 104 + 4 (s - 4) + k
+ *   rows 120..123 their "was active" flags
  * lcr_get_state + lcr_set_state with all arrays including `warm` is an exact checkpoint: the next lcr_step is bit-identical to
  * the one the un-checkpointed sim would have made.  lcr_set_state with qpos or qvel but warm == NULL clears the carried forces
  * (cold solve in the first substep of the next step); with LCR_COMPAT_COLD_SOLVE_EACH_STEP nothing is carried: get returns zeros,
  * set ignores `warm`. */
-#define LCR_NWARM 104
+#define LCR_NWARM 124
 int lcr_get_state(lcr_sim *sim, double *qpos /*[nq][N]*/, double *qvel /*[nv][N]*/, double *ee_lag /*[3][N]*/,
                   float *target /*[3][N]*/, int32_t *elapsed /*[N]*/, uint64_t *rng /*[4][N]*/,
                   int32_t *current_goal /*[N]*/, double *sim_time /*[N]*/, float *warm /*[LCR_NWARM][N]*/);

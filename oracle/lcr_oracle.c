@@ -974,6 +974,8 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         for (int it = 0; it < max_it; it++) {
             lastchange = 0;
             double fmaxabs = 0;
+            real f_start[MAX_ROWS];   /* stopping test of the converged mode: NET change of a row over the sweep (after the cone projection) */
+            for (int i = 0; i < nr; i++) f_start[i] = f[i];
             for (int i = 0; i < nr; i++) {
                 real res = bvec[i] + Rr[i] * f[i];
                 for (int j = 0; j < nr; j++) res += A[(size_t)i * nr + j] * f[j];
@@ -981,7 +983,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                 real nf = f[i] - res / (A[(size_t)i * nr + i] + Rr[i]);
                 if (kind[i] != 2 && nf < 0) nf = 0; /* unilateral rows */
                 f[i] = nf;
-                if (fabs((double)(nf - old)) > lastchange) lastchange = fabs((double)(nf - old));
+                (void)old;
                 if (kind[i] == 2 && i == blk0[i] + blkdim[i] - 1) {
                     /* last friction row of this contact: project onto the elliptic cone (D2) */
                     const int i0 = blk0[i], dm = blkdim[i];
@@ -996,7 +998,10 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                 }
             }
             sweeps++;
-            for (int i = 0; i < nr; i++) if (fabs((double)f[i]) > fmaxabs) fmaxabs = fabs((double)f[i]);
+            for (int i = 0; i < nr; i++) {
+                if (fabs((double)f[i]) > fmaxabs) fmaxabs = fabs((double)f[i]);
+                if (fabs((double)(f[i] - f_start[i])) > lastchange) lastchange = fabs((double)(f[i] - f_start[i]));
+            }
             if (adaptive && lastchange <= P->pgs_tol * (1.0 + fmaxabs)) break;
         }
         for (int i = 0; i < nr; i++)

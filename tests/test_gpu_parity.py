@@ -165,13 +165,15 @@ def test_shard_invariance_and_determinism(hip_lib, kernel_family, task, mode, M,
         s.close()
 
 
+@pytest.mark.parametrize("cc_points", [4, 8])
 @pytest.mark.parametrize("carry", [False, True], ids=["cold", "carry"])
-def test_stack_cube_on_cube_contacts(hip_lib, monkeypatch, carry):
-    """blue cube dropped onto / resting on / offset on the red cube: cube<->cube rows active in every env"""
+def test_stack_cube_on_cube_contacts(hip_lib, monkeypatch, carry, cc_points):
+    """blue cube dropped onto / resting on / offset on the red cube: cube<->cube rows active in every env.  cc_points = 8: the eight-point
+    manifold (extremes along the reference face's diagonals and axes; lcr_config.cc_points, two-wave kernels) against the oracle's"""
     monkeypatch.setattr(util, "CARRY_DEFAULT", carry)   # both sides start each step from the oracle's carried forces / from zero forces
     rng = np.random.default_rng(11)
     n = 256
-    sim, o = util.make_pair("stack", n, auto_reset=False, max_episode_steps=0)
+    sim, o = util.make_pair("stack", n, auto_reset=False, max_episode_steps=0, cc_points=cc_points)
     o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
     o.qpos[:, 6:9] = [0.25, 0.25, 0.0149]  # resting penetration (exactly-touching z=0.015 is a knife edge of dist<0)
     o.qpos[:, 9:13] = [1, 0, 0, 0]
@@ -186,6 +188,10 @@ def test_stack_cube_on_cube_contacts(hip_lib, monkeypatch, carry):
     _cmp_step(sim, o, rng, 8, act_scale=0.2)
     rows, cons, _ = o.diag()
     assert cons >= 5  # 4 floor + at least one cube-cube contact on env 0
+    if cc_points == 8:   # yawed stacks have overlap polygons with more than four vertices: the extra slots (bits 24-27) really are used
+        extra = ((o.active_mask >> 24) & 15) != 0
+        assert extra.mean() > 0.2, extra.mean()
+        np.testing.assert_array_equal(((sim.active_mask.numpy() >> 24) & 15) != 0, extra)
     # physical sanity (oracle side == HIP side within tolerance): blue cubes still rest on their red cubes (a few that
     # were dropped with a 12 mm offset plus lateral velocity may legitimately tip over)
     on_top = (o.qpos[:, 15] > 0.043) & (o.qpos[:, 15] < 0.047)
@@ -634,7 +640,7 @@ def test_converged_solver_mode(hip_lib, monkeypatch, task, carry):
     monkeypatch.setattr(util, "CARRY_DEFAULT", carry)   # both sides start each step from the oracle's carried forces / from zero forces
     rng = np.random.default_rng(9)
     n = 256
-    sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, pgs_iters=-1, pgs_tol=1e-5)
+    sim, o = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, pgs_iters=-1, pgs_tol=1e-6)
     seeds = np.arange(n, dtype=np.uint64) + 77
     o.reset(seeds=seeds); sim.reset(seeds=seeds)
     for t in range(6):
@@ -700,7 +706,7 @@ def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which
     elif which == "rollout_ee":
         test_step_rollout_vs_oracle(hip_lib, monkeypatch, "stack", "ee", False)
     elif which == "cube_on_cube":
-        test_stack_cube_on_cube_contacts(hip_lib, monkeypatch, True)
+        test_stack_cube_on_cube_contacts(hip_lib, monkeypatch, True, 4)
     elif which == "rolling_rows":
         test_rolling_rows_finger_cube_condim6(hip_lib, monkeypatch, "stack", True)
     elif which == "link_proxy":

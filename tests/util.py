@@ -35,7 +35,7 @@ def warm_o2k(o):
     """oracle warm records -> the [LCR_NWARM][n] float32 block of lcr_set_state (layout: include/lcr.h)"""
     w = warm_view(o).astype(np.float64)
     lim, slot = w[:, :12], w[:, 12:].reshape(o.n, 28, 6)
-    k = np.zeros((104, o.n), np.float32)
+    k = np.zeros((124, o.n), np.float32)
     for c in range(2):
         for s4 in range(4):
             k[16 * c + 4 * s4: 16 * c + 4 * s4 + 4] = slot[:, 4 * c + s4, :4].T
@@ -48,6 +48,8 @@ def warm_o2k(o):
         if o.task == orc.TASKS["stack"]:
             k[84 + 4 * s4: 84 + 4 * s4 + 4] = slot[:, 8 + s4, :4].T
             k[100 + s4] = 1.0                             # "was active": an inactive slot carries zeros, which warm-start like no force
+            k[104 + 4 * s4: 104 + 4 * s4 + 4] = slot[:, 24 + s4, :4].T   # eight-point manifold (cc_points = 8): oracle slots 24..27
+            k[120 + s4] = 1.0
     return k
 
 
@@ -81,7 +83,7 @@ def make_pair(task, n, **kw):
 
     okw = {}
     for k in ("action_mode", "reward_type", "block_gripper", "n_substeps", "max_episode_steps", "pgs_iters",
-              "auto_reset", "compat", "distance_threshold", "impratio", "arm_collision", "pgs_tol"):
+              "auto_reset", "compat", "distance_threshold", "impratio", "arm_collision", "pgs_tol", "cc_points"):
         if k in kw:
             v = kw[k]
             if k == "action_mode":
