@@ -297,7 +297,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "lcr_step_kernel" if args.obs == "state" else "lcr_step_kernel + lcr_render_obs_kernel",
+                "kernel": sim.step_kernel_name if args.obs == "state" else sim.step_kernel_name + " + lcr_render_obs_kernel",
+                "kernel_family": sim.step_kernel_family,
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_env_step": alg_bytes,
                 "traffic_note": "traffic counts solver state the SURVEY.md 8(d) formula does not: the constraint forces carried from one control step to the "

@@ -30,7 +30,7 @@ SYMBOLS = [
     "lcr_create", "lcr_destroy", "lcr_set_stream", "lcr_sync", "lcr_reset", "lcr_step", "lcr_step_host",
     "lcr_get_obs", "lcr_get_outputs", "lcr_fetch_host", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
     "lcr_memcpy_h2d", "lcr_memcpy_d2h", "lcr_timer_begin", "lcr_timer_end", "lcr_fill_random_actions",
-    "lcr_calibrate_copy", "lcr_render", "lcr_render_state",
+    "lcr_calibrate_copy", "lcr_render", "lcr_render_state", "lcr_step_kernel_family",
 ]
 
 
@@ -163,6 +163,7 @@ def load():
     L.lcr_create.argtypes = [ctypes.POINTER(LcrConfig), ctypes.POINTER(vp)]
     L.lcr_destroy.argtypes = [vp]
     L.lcr_destroy.restype = None
+    L.lcr_step_kernel_family.argtypes = [vp]
     L.lcr_set_stream.argtypes = [vp, vp]
     L.lcr_sync.argtypes = [vp]
     L.lcr_reset.argtypes = [vp, vp, vp]

@@ -378,6 +378,11 @@ void lcr_destroy(lcr_sim *s) {
     if (!(s)) return fail(LCR_ERR_INVALID, "sim is NULL"); \
     HIPCHK(hipSetDevice((s)->cfg.device))
 
+int lcr_step_kernel_family(lcr_sim *s) {
+    if (!s) return fail(LCR_ERR_INVALID, "sim is NULL");
+    return (s->dev.coop && s->dev.pgs_iters >= 0 && s->dev.diag != 2) ? s->dev.coop : 0;
+}
+
 int lcr_set_stream(lcr_sim *s, void *hip_stream) {
     SIMCHK(s);
     s->stream = (hipStream_t)hip_stream;

@@ -123,6 +123,10 @@ class VecSim:
         h = ctypes.c_void_p()
         check(self.L.lcr_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.handle = h
+        fam = self.L.lcr_step_kernel_family(self.handle)
+        self.step_kernel_family = {0: "one wave per 64 envs (lcr_step_kernel)", 1: "two cooperating waves per 64 envs (lcr_step2_kernel, one wave per SIMD)",
+                                   2: "two cooperating waves per 64 envs (lcr_step2_kernel, two waves per SIMD)"}[fam]
+        self.step_kernel_name = "lcr_step_kernel" if fam == 0 else "lcr_step2_kernel"
         ov, out = LcrObsView(), LcrOutView()
         check(self.L.lcr_get_obs(self.handle, ctypes.byref(ov)))
         check(self.L.lcr_get_outputs(self.handle, ctypes.byref(out)))

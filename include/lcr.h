@@ -176,6 +176,10 @@ int lcr_nv(int task); /* 12, stack 18 */
 int lcr_create(const lcr_config *cfg, lcr_sim **out);
 void lcr_destroy(lcr_sim *sim); /* == close() reach_cube_env.py:357-363 */
 
+/* Which step-kernel family this handle runs (decided at lcr_create from lcr_config.step_kernel and the shard size): 0 = one wave per 64 envs
+ * (lcr_step_kernel), 1 / 2 = two cooperating waves per 64 envs (lcr_step2_kernel) compiled for one / two waves per SIMD. */
+int lcr_step_kernel_family(lcr_sim *sim);
+
 /* HIP stream (hipStream_t passed as void*) all later work is enqueued on; NULL = default stream. */
 int lcr_set_stream(lcr_sim *sim, void *hip_stream);
 int lcr_sync(lcr_sim *sim); /* hipStreamSynchronize on the handle's stream */

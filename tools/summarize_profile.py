@@ -52,7 +52,7 @@ def main():
         p = os.path.join(src, d, "p_counter_collection.csv")
         if not os.path.exists(p):
             continue
-        m, n, meta = pmc_means(p, "lcr_step_kernel")
+        m, n, meta = pmc_means(p, "lcr_step")   # lcr_step_kernel (one wave per 64 envs) or lcr_step2_kernel (two cooperating waves)
         step.update(m)
         if meta:
             out["step_kernel_resources_rocprofv3"] = meta   # NB: rocprofv3 halves the register counts (see <round>_codeobj.json for the real ones)
@@ -66,9 +66,10 @@ def main():
     # kernel duration from the trace
     with open(os.path.join(src, "trace", "t_kernel_stats.csv")) as f:
         for r in csv.DictReader(f):
-            if "lcr_step_kernel" in r["Name"]:
+            if "lcr_step" in r["Name"]:
                 out["step_kernel_avg_ns"] = float(r["AverageNs"])
                 out["step_kernel_calls"] = int(r["Calls"])
+                out["step_kernel_name"] = r["Name"]
             if "lcr_render_obs_kernel" in r["Name"]:
                 out["render_kernel_avg_ns"] = float(r["AverageNs"])
     # calibration: FETCH_SIZE / WRITE_SIZE are reported in KiB-units of the L2<->fabric request counters
