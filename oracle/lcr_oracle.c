@@ -93,7 +93,7 @@ static const double SPH_RAD[NSPH] = {0.0065, 0.0065};
  * < 0.1 %; the one that is not served keeps its warm start for the next substep in which it is the deepest.)
  * {link index 0..5, centre in link frame, radius, collides with cubes} */
 #define NLPX 5
-#define NLGRP 1
+#define NLGRP 3   /* contact groups the proxies may form: 1 in the product (one shared contact, = the kernels); 3 in the study of deviation D3 (orc_params.proxy_groups) */
 static const int LPX_LINK[NLPX] = {2, 2, 3, 4, 5};
 static const double LPX_POS[NLPX][3] = {
     {-0.0100, 0.0145, 0.0030},  /* elbow end of link_3            (link_3_collision x[-0.111,0.009] y[-0.004,0.033] z[-0.009,0.015]) */
@@ -106,6 +106,7 @@ static const double LPX_POS[NLPX][3] = {
  * fixed finger between the link_5 body and the finger-tip sphere needs no proxy of its own, and the grasp gap stays free) */
 static const double LPX_RAD[NLPX] = {0.0120, 0.0120, 0.0105, 0.0150, 0.0078};
 static const int LPX_GROUP[NLPX] = {0, 0, 0, 0, 0};
+static const int LPX_GROUP3[NLPX] = {0, 1, 2, 2, 2};   /* study: one contact per end of link_3 and one for the wrist / gripper body (tools/proxy_groups_effect.py) */
 static const int LPX_CUBE[NLPX] = {0, 0, 0, 1, 1};
 /* link geoms: MuJoCo geom defaults friction (1, 0.005, 0.0001), condim 3, priority 0.  vs floor (priority 0, friction 0.1):
  * max rule -> mu 1, condim 3, default solref/solimp.  vs cube (priority 1): the cube's condim 4, friction, solimp win (P9). */
@@ -524,10 +525,10 @@ static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
     return 1;
 }
 /* arm-link proxies (group g = 0): the deepest penetration among them against the floor and (gripper body) the cubes */
-static int collide_link_group(const kin_t *K, int g, contact_t *out) {
+static int collide_link_group(const kin_t *K, int g, int ngroups, contact_t *out) {
     int have = 0;
     for (int s = 0; s < NLPX; s++) {
-        if (LPX_GROUP[s] != g) continue;
+        if ((ngroups == 3 ? LPX_GROUP3[s] : LPX_GROUP[s]) != g) continue;
         contact_t tmp;
         if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
             tmp.mu = MU_LINK_FLOOR; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 3;
@@ -542,7 +543,7 @@ static int collide_link_group(const kin_t *K, int g, contact_t *out) {
                     if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
                 }
     }
-    if (have) out->slot = 16 + g;
+    if (have) out->slot = g < 2 ? 16 + g : 28;   /* (bits 18-23 of the decision mask are the joint limits, 24-27 the extra cube<->cube points) */
     return have;
 }
 /* (D7) PushCubeLoop rails (push_cube_loop.xml:44-47): the four wall boxes are restated as their inner faces -- vertical
@@ -789,7 +790,7 @@ typedef struct {
 } lag_t;
 /* constraint forces carried from one substep to the next WITHIN a control step (zero at its start, so that a
  * control step stays a pure function of (qpos, qvel, action)); MuJoCo warm-starts its solver likewise */
-typedef struct { real lim[12]; real slot[28][6]; } warm_t;   /* slots 24..27: the extra cube<->cube points of the D5 study */
+typedef struct { real lim[12]; real slot[30][6]; } warm_t;   /* slots 24..27: the extra cube<->cube points of the D5 study */
 int orc_warm_bytes(void) { return (int)sizeof(warm_t); } /* stride of orc_io.warm */
 
 static void substep(const orc_params *P, const task_model *T, real *qpos, real *qvel, const real *ctrl, lag_t *lag,
@@ -868,8 +869,8 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     for (int s = 0; s < NSPH; s++)
         if (collide_plane_sphere(&K, s, con + ncon)) ncon++;
     if (P->arm_collision)
-        for (int g = 0; g < NLGRP; g++)
-            if (collide_link_group(&K, g, con + ncon)) ncon++;
+        for (int g = 0; g < (P->proxy_groups == 3 ? 3 : 1); g++)
+            if (collide_link_group(&K, g, P->proxy_groups == 3 ? 3 : 1, con + ncon)) ncon++;
 
     /* -- constraint rows: joint limits first, then contacts (n, t1, t2 [, torsion]) */
     real J[MAX_ROWS * ORC_NV_MAX], aref[MAX_ROWS], Rr[MAX_ROWS];
@@ -1064,6 +1065,7 @@ void orc_default_params(orc_params *p, int task) {
     p->compat = 0;
     p->auto_reset = 1;
     p->warm_start = 1;
+    p->proxy_groups = 1;
     p->arm_collision = 1;
     p->pgs_tol = 1e-6;
     p->cc_points = 4;

@@ -35,6 +35,7 @@ class OrcParams(ctypes.Structure):
         ("arm_collision", ctypes.c_int32),
         ("pgs_tol", ctypes.c_double),
         ("condim6", ctypes.c_int32),
+        ("proxy_groups", ctypes.c_int32),
         ("cc_points", ctypes.c_int32),
     ]
 

@@ -13,10 +13,10 @@ def f32r(x):
 
 
 def warm_view(o):
-    """the oracle's carried constraint forces as an (n, 180) array of its scalar type: [0:12] limit rows (2 j + side), then 28 slots x 6 rows
+    """the oracle's carried constraint forces as an (n, 192) array of its scalar type: [0:12] limit rows (2 j + side), then 30 slots x 6 rows
     (warm_t of oracle/lcr_oracle.c; slot ids: 0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor, 16 link proxies)"""
     dt = np.float32 if o.L is orc.lib(True) else np.float64
-    return o.warm.view(dt)[:, :180]
+    return o.warm.view(dt)[:, :192]
 
 
 def sync_oracle_to_f32(o, carry=False):
@@ -34,7 +34,7 @@ _ARM_SLOT = (12, 13, 14, 15, 16)   # oracle slot id of the kernel's arm-coupled 
 def warm_o2k(o):
     """oracle warm records -> the [LCR_NWARM][n] float32 block of lcr_set_state (layout: include/lcr.h)"""
     w = warm_view(o).astype(np.float64)
-    lim, slot = w[:, :12], w[:, 12:].reshape(o.n, 28, 6)
+    lim, slot = w[:, :12], w[:, 12:].reshape(o.n, 30, 6)
     k = np.zeros((124, o.n), np.float32)
     for c in range(2):
         for s4 in range(4):

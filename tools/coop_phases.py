@@ -35,4 +35,12 @@ print(f"  arm wave : total {a_tot.mean():.0f} / {a_tot.max():.0f}   waiting {a_w
 print(f"  arm wave waits: at X (inertia factor) {a_wx.mean():.0f} / {a_wx.max():.0f}   Y..E (joint acceleration) {a_we.mean():.0f} / {a_we.max():.0f}   other (barrier 1, coupled sweeps) {np.mean(a_wait - a_wx - a_we):.0f}")
 print(f"  cube wave: total {b_tot.mean():.0f} / {b_tot.max():.0f}   waiting {b_wait.mean():.0f} / {b_wait.max():.0f}   busy {np.mean(b_tot - b_wait):.0f} / {np.max(b_tot - b_wait):.0f}")
 print(f"  coupled substeps per step: mean {cpl.mean():.2f}, workgroups with any {np.mean(cpl > 0):.3f}; arm total where uncoupled {a_tot[cpl == 0].mean():.0f} / coupled {a_tot[cpl > 0].mean() if (cpl > 0).any() else 0:.0f}")
+# the slowest workgroups of the last step (they set the launch time): where do their cycles go?
+a_tot, a_wait, a_pre, cpl, b_tot, b_wait, a_wx, a_we = rows[-1]
+order = np.argsort(-a_tot)[:8]
+print("  slowest workgroups of one step: arm total / waiting (X, E, other) / X..B1 own / coupled substeps / cube busy")
+for i in order:
+    print(f"    wg {i:5d}: {a_tot[i]:.0f} / {a_wait[i]:.0f} ({a_wx[i]:.0f}, {a_we[i]:.0f}, {a_wait[i] - a_wx[i] - a_we[i]:.0f}) / {a_pre[i]:.0f} / {cpl[i]:.0f} / {b_tot[i] - b_wait[i]:.0f}")
+q = np.percentile(a_tot, [50, 90, 99, 100])
+print(f"  arm total percentiles 50/90/99/100: {q[0]:.0f} {q[1]:.0f} {q[2]:.0f} {q[3]:.0f}")
 sim.close()
