@@ -908,5 +908,8 @@ def test_zz_outlier_census(hip_lib):
     print(f"[parity outliers] env-steps compared {S['envs']} ({S['envs_carry']} of them started from carried constraint forces, {S['out_carry']} of the outliers), outside tolerance {S['out']} ({100.0 * S['out'] / max(S['envs'], 1):.3f} %): "
           f"{S['out_flip']} with a different discrete-decision signature, {S['out_illcond']} ill-conditioned for fp32 (the oracle's fp32 "
           f"build leaves the tolerance too, or -- {S.get('out_family', 0)} of them -- the two kernel families disagree with each other), {S['out'] - S['out_flip'] - S['out_illcond']} unexplained; worst |dq| {S['max_dq']:.2e}, worst |dqvel| {S['max_dv']:.2e}")
+    print(f"[parity outliers] of the {S.get('ill_conv_checked', 0)} ill-conditioned env-steps re-run from the same state with the converged solver on both "
+          f"sides (pgs_iters = -1, tol 1e-7), {S.get('ill_conv_agree', 0)} then agree within the tolerance; in {S.get('ill_conv_capped', 0)} of the others "
+          f"the oracle's PGS hit its 50-sweep cap without converging (stiff contact sets: no converged reference exists for them)")
     assert S["out"] == S["out_flip"] + S["out_illcond"]
     assert S["envs_carry"] > 0.3 * S["envs"]     # the product's default mode (forces carried across steps) is really covered

@@ -7,7 +7,7 @@ import torch
 from gym_lowcostrobot_amd import VecSim
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-n = 65536
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536     # (32 768: the two-wave kernels; 65 536: the one-wave kernels)
 for task, mode in (("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("pick_place", "ee"), ("stack", "joint"), ("push_loop", "joint")):
     sim = VecSim(task, n, action_mode=mode)
     act = sim.alloc_actions()
@@ -20,5 +20,5 @@ for task, mode in (("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("p
         g = (trunc != 0) & (term == 0) & (age < 50)
         early += int(g.sum())
         age[dres != 0] = 0
-    print(f"{task:10s} {mode:5s} env-steps {n * steps:.2e}  guard-ended episodes {early}")
+    print(f"{task:10s} {mode:5s} {sim.step_kernel_name:17s} env-steps {n * steps:.2e}  guard-ended episodes {early}", flush=True)
     sim.close()
