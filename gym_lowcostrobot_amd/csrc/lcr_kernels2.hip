@@ -72,6 +72,56 @@ template <bool ROLL> constexpr int as2_row0(int s) { return ROLL ? (s < 2 ? 6 * 
 
 DEV void wg_barrier() { __syncthreads(); }   // s_waitcnt + s_barrier: LDS (and global) writes before it are visible to the partner wave after it
 
+// smooth joint forces: recursive Newton-Euler bias (zero joint acceleration, base accelerating at -g), passive damping and the position
+// actuators (ctrlrange == joint range via inheritrange; joint-level force clamp).  The inertia tensors are applied in the link frames
+// (R Ic R^T v as three small products): no world inertias are formed.
+DEV void rne_tau(const ArmFrames &F, const f3 (&z)[6], const float (&q)[6], const float (&qd)[6], const float (&ctrl)[6], float (&tau)[6]) {
+    using namespace lcrm;
+    f3 com[6];
+    com[0] = local_point(F, 0, C1x, C1y, C1z); com[1] = local_point(F, 1, C2x, C2y, C2z); com[2] = local_point(F, 2, C3x, C3y, C3z);
+    com[3] = local_point(F, 3, C4x, C4y, C4z); com[4] = local_point(F, 4, C5x, C5y, C5z); com[5] = local_point(F, 5, C6x, C6y, C6z);
+    const float mass[6] = {M1, M2, M3, M4, M5, M6};
+    const float IC[6][6] = {{I1_xx, I1_xy, I1_xz, I1_yy, I1_yz, I1_zz}, {I2_xx, I2_xy, I2_xz, I2_yy, I2_yz, I2_zz}, {I3_xx, I3_xy, I3_xz, I3_yy, I3_yz, I3_zz},
+                            {I4_xx, I4_xy, I4_xz, I4_yy, I4_yz, I4_zz}, {I5_xx, I5_xy, I5_xz, I5_yy, I5_yz, I5_zz}, {I6_xx, I6_xy, I6_xz, I6_yy, I6_yz, I6_zz}};
+    auto inertia_apply = [&](int i, f3 v) -> f3 {
+        const f3 l = mk(dot(F.X[i], v), dot(F.Y[i], v), dot(F.Z[i], v));
+        const float ax = fmaf(IC[i][0], l.x, fmaf(IC[i][1], l.y, IC[i][2] * l.z));
+        const float ay = fmaf(IC[i][1], l.x, fmaf(IC[i][3], l.y, IC[i][4] * l.z));
+        const float az = fmaf(IC[i][2], l.x, fmaf(IC[i][4], l.y, IC[i][5] * l.z));
+        return axpy(ax, F.X[i], axpy(ay, F.Y[i], az * F.Z[i]));
+    };
+    f3 w = mk(0.f, 0.f, 0.f), wd = mk(0.f, 0.f, 0.f), a = mk(0.f, 0.f, GRAV), pprev = mk(0.f, 0.f, 0.f);
+    f3 Fi[6], Ni[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        f3 r = F.p[i] - pprev;
+        a = a + cross(wd, r) + wxwxr(w, r, dot(w, w));
+        f3 zq = qd[i] * z[i];
+        wd = wd + cross(w, zq);
+        w = w + zq;
+        f3 rc = com[i] - F.p[i];
+        f3 ac = a + cross(wd, rc) + wxwxr(w, rc, dot(w, w));
+        Fi[i] = mass[i] * ac;
+        Ni[i] = inertia_apply(i, wd) + cross(w, inertia_apply(i, w));
+        pprev = F.p[i];
+    }
+    f3 f = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        f3 nn = Ni[i] + cross(com[i] - F.p[i], Fi[i]);
+        if (i < 5) nn = nn + n + cross(F.p[i + 1] - F.p[i], f);
+        f = f + Fi[i];
+        n = nn;
+        const float bias = dot(z[i], n);
+        const float c = clampf(ctrl[i], JLO[i], JHI[i]);
+        const float fa = clampf(fmaf(KP, c - q[i], -KV * qd[i]), -FRC, FRC);
+        tau[i] = fa - DAMPING * qd[i] - bias;
+    }
+}
+// who computes tau: the cube wave.  (Measured for StackTwoCubes, where the cube wave is the longer chain: tau on the arm wave instead
+// gives 0.637 against 0.628 ms at 32 768 envs -- the slowest workgroups there are bounded by the cube wave's sweeps, not by its prologue.)
+template <int NC> constexpr bool rne_on_arm() { return false; }
+
 // ================================================================================================
 // wave A: the arm
 // ================================================================================================
@@ -80,6 +130,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     using LL = Lds2<NC, ROLL, CC8>;
     using namespace lcrm;
     constexpr int NRW = ROLL ? 6 : 4;
+    constexpr bool RNE_ON_ARM = rne_on_arm<NC>();
     const int N = P.n;
     float q[6], qd[6];
 #pragma unroll
@@ -256,13 +307,15 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 #pragma unroll
             for (int i = 0; i < 6; i++) pl[(k++) * 64] = CL.id[i];
         }
+        float tau_own[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (RNE_ON_ARM) rne_tau(F, z, q, qd, ctrl, tau_own);
         if (prof) pf_mark = clock64();
         wg_barrier();   // X: L is in LDS for wave B; wave B's tau (bias + actuation + damping) is in LDS for this wave
         if (prof) { pf_wait += clock64() - pf_mark; pf_wx += clock64() - pf_mark; }
         // y = L^T a  (scaled arm acceleration);  y_smooth = L^-1 tau
         float y[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) y[j] = lds[LL::G0 + lane + j * 64];   // tau from wave B
+        for (int j = 0; j < 6; j++) y[j] = RNE_ON_ARM ? tau_own[j] : lds[LL::G0 + lane + j * 64];   // tau: this wave's (two cubes) or wave B's
         fsub(CL, y);
         read_pose();    // cube pose and velocity at the top of this substep (wave B published it before barrier Y of the previous one)
         wg_barrier();   // X2: wave B has read L (its LDS place is reused for contact rows from here on); this wave has read the pose
@@ -924,6 +977,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     // cube<->cube manifold points kept (Stack): 4 = the extremes along the diagonals of the reference face; CC8 (lcr_config.cc_points = 8,
     // as many as MuJoCo's mjc_BoxBox may return): also the extremes along its two axes -- narrows deviation D5
     constexpr int NCC = CC8 ? 8 : 4;
+    constexpr bool RNE_ON_ARM = rne_on_arm<NC>();
     using namespace lcrm;
     const int N = P.n;
     // this wave's copy of the arm configuration (for the joint-space inertia): it starts from the configuration wave A leaves behind
@@ -1011,56 +1065,19 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     for (int sub = 0; sub < P.n_substeps; sub++) {
         Diag DG = {0u, 0u, 0u, 0u};
         __builtin_amdgcn_s_setprio(3);
-        // ---- smooth joint forces: recursive Newton-Euler bias (zero joint acceleration, base accelerating at -g), passive damping and the
-        //      position actuators (ctrlrange == joint range via inheritrange; joint-level force clamp) -> tau -> wave A.  The inertia
-        //      tensors are applied in the link frames (R Ic R^T v as three small products). ----
+        // ---- forward kinematics (this wave's own: cheaper than moving 72 floats through LDS) and, unless the arm wave keeps it (two cubes:
+        //      this wave is the busier one there), the smooth joint forces tau -> wave A ----
         ArmFrames F;
         arm_frames(q, F);
         f3 z[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) z[j] = joint_axis(F, j);
         const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};   // finger spheres (slots 0, 1 below)
-        {
-            f3 com[6];
-            com[0] = local_point(F, 0, C1x, C1y, C1z); com[1] = local_point(F, 1, C2x, C2y, C2z); com[2] = local_point(F, 2, C3x, C3y, C3z);
-            com[3] = local_point(F, 3, C4x, C4y, C4z); com[4] = local_point(F, 4, C5x, C5y, C5z); com[5] = local_point(F, 5, C6x, C6y, C6z);
-            const float mass[6] = {M1, M2, M3, M4, M5, M6};
-            const float IC[6][6] = {{I1_xx, I1_xy, I1_xz, I1_yy, I1_yz, I1_zz}, {I2_xx, I2_xy, I2_xz, I2_yy, I2_yz, I2_zz}, {I3_xx, I3_xy, I3_xz, I3_yy, I3_yz, I3_zz},
-                                    {I4_xx, I4_xy, I4_xz, I4_yy, I4_yz, I4_zz}, {I5_xx, I5_xy, I5_xz, I5_yy, I5_yz, I5_zz}, {I6_xx, I6_xy, I6_xz, I6_yy, I6_yz, I6_zz}};
-            auto inertia_apply = [&](int i, f3 v) -> f3 {
-                const f3 l = mk(dot(F.X[i], v), dot(F.Y[i], v), dot(F.Z[i], v));
-                const float ax = fmaf(IC[i][0], l.x, fmaf(IC[i][1], l.y, IC[i][2] * l.z));
-                const float ay = fmaf(IC[i][1], l.x, fmaf(IC[i][3], l.y, IC[i][4] * l.z));
-                const float az = fmaf(IC[i][2], l.x, fmaf(IC[i][4], l.y, IC[i][5] * l.z));
-                return axpy(ax, F.X[i], axpy(ay, F.Y[i], az * F.Z[i]));
-            };
-            f3 w = mk(0.f, 0.f, 0.f), wd = mk(0.f, 0.f, 0.f), a = mk(0.f, 0.f, GRAV), pprev = mk(0.f, 0.f, 0.f);
-            f3 Fi[6], Ni[6];
+        if constexpr (!RNE_ON_ARM) {
+            float tau[6];
+            rne_tau(F, z, q, qd, ctrl, tau);
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                f3 r = F.p[i] - pprev;
-                a = a + cross(wd, r) + wxwxr(w, r, dot(w, w));
-                f3 zq = qd[i] * z[i];
-                wd = wd + cross(w, zq);
-                w = w + zq;
-                f3 rc = com[i] - F.p[i];
-                f3 ac = a + cross(wd, rc) + wxwxr(w, rc, dot(w, w));
-                Fi[i] = mass[i] * ac;
-                Ni[i] = inertia_apply(i, wd) + cross(w, inertia_apply(i, w));
-                pprev = F.p[i];
-            }
-            f3 f = mk(0.f, 0.f, 0.f), n = mk(0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 5; i >= 0; i--) {
-                f3 nn = Ni[i] + cross(com[i] - F.p[i], Fi[i]);
-                if (i < 5) nn = nn + n + cross(F.p[i + 1] - F.p[i], f);
-                f = f + Fi[i];
-                n = nn;
-                const float bias = dot(z[i], n);
-                const float c = clampf(ctrl[i], JLO[i], JHI[i]);
-                const float fa = clampf(fmaf(KP, c - q[i], -KV * qd[i]), -FRC, FRC);
-                lds[LL::G0 + lane + i * 64] = fa - DAMPING * qd[i] - bias;   // tau_i -> wave A (g rows of slot 0: idle between wave A's last sweep and its next row set-up)
-            }
+            for (int i = 0; i < 6; i++) lds[LL::G0 + lane + i * 64] = tau[i];   // -> wave A (g rows of slot 0: idle between wave A's last sweep and its next row set-up)
         }
         if (prof) pf_mark = clock64();
         wg_barrier();   // X: tau is in LDS for wave A; wave A's Cholesky factor of the joint-space inertia is in LDS
