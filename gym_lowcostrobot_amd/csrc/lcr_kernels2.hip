@@ -5,24 +5,31 @@
 // launch lasts as long as the serial instruction chain of its slowest wave.  A shard of 32 768 envs (BASELINE configs 4 and 5) even
 // leaves half the SIMDs without a wave.  Here a workgroup is two waves that share the 64 envs -- lane l of both waves is env l:
 //
-//   wave A ("arm")   forward kinematics, joint-space inertia + Cholesky, RNE bias, actuation, every contact row that couples into the
-//                    arm (finger spheres, arm-link proxies, joint limits), implicitfast solve + integration of the arm; the action
-//                    head (incl. the IK loop of ee mode) and the fused tail (reward, termination, TimeLimit, auto-reset, write-back);
-//   wave B ("cubes") cube kinematics, floor<->cube / cube<->cube / rail contacts and their rows, integration of the cubes.
+//   wave A ("arm")   forward kinematics, joint-space inertia + Cholesky factor L (-> wave B), y = L^-1 tau, the contact rows that touch
+//                    only the arm (finger spheres <-> floor, arm-link proxies: slots 2-4; joint limits) and their sweeps, qacc = Wm y,
+//                    integration of the arm; the action head (incl. the IK loop of ee mode) and the fused tail (reward, termination,
+//                    TimeLimit, auto-reset, write-back);
+//   wave B ("cubes") its own forward kinematics, RNE bias + actuation + damping = tau (-> wave A), the finger spheres <-> cube slots 0, 1
+//                    (it has the cube state, the kinematics and L), floor <-> cube / cube <-> cube / rail contacts, their rows and
+//                    sweeps, Wm = (M + hD)^-1 L (-> wave A), integration of the cubes and of its copy of the arm state.
 //
-// The two constraint sets touch disjoint unknowns (arm acceleration y vs cube accelerations ca / cal) unless a finger sphere or a gripper
-// proxy touches a cube, so their Gauss-Seidel sweeps are INDEPENDENT chains in almost every (wave, substep) pair and run concurrently --
-// the result is the same as the sequential order limits -> floor -> cube<->cube -> rails -> arm slots of the oracle.  When some lane of
-// the 64 does have an arm<->cube contact ("coupled", wave-uniform per substep), the sweeps are serialised in exactly that order with
-// the cube accelerations handed over through LDS twice per sweep.  Per substep the waves meet at two barriers (uncoupled):
+// The two constraint sets touch disjoint unknowns (the arm's scaled acceleration y vs the cube accelerations ca / cal) unless a finger sphere
+// or a gripper-body proxy touches a cube, so their Gauss-Seidel sweeps are INDEPENDENT chains in almost every (workgroup, substep) pair and
+// run concurrently -- the result is the same as the oracle's sequential order limits -> floor -> cube<->cube -> rails -> slots 0-4.  When some
+// lane of the 64 couples them (wave-uniform flags exchanged at barrier 1: c01 = a finger sphere on a cube, cube4 = a proxy on a cube) the
+// sweep is serialised in exactly that order: y visits wave B between the limit rows and slots 2-4, the cube accelerations visit wave A for
+// slot 4.  Barriers per substep (uncoupled: five):
 //
-//   A: cube pose <- LDS | FK, RNE bias, actuation  -X-  y0 = L^-1 tau | arm collision + rows | flag  -B1-  sweeps (arm chain) | y -> LDS  -Y-             -E-  integrate arm
-//   B: FK, inertia M, L = chol(M) -> LDS           -X-  chol(M + hD) | cube collision + rows      -B1-  sweeps (cube chain)             -Y-  qacc, integrate  -E-
-// (wave B owns the joint-space inertia: it repeats the forward kinematics, factors M and M + h(damping + kv) and, at the end of the
-//  substep, turns wave A's y into the joint acceleration -- wave A never holds a 6x6 matrix across its sweeps)
+//   A: FK, M, L -> LDS          -X-  y0 = L^-1 tau; pose <- LDS  -X2-  rows of slots 2-4, limits | cube4  -B1-  sweeps: limits, 2-4      | qacc = Wm y -> LDS  -E-  integrate arm
+//   B: FK, tau -> LDS           -X-  L <- LDS                    -X2-  slots 0, 1; Wm -> LDS; cube rows | c01 -B1-  sweeps: floor, cc, rails | integrate cubes, pose -> LDS  -E-  integrate arm copy
 //
-// At 32 768 envs per GPU the 1024 waves occupy all 1024 SIMDs (one each, up to 512 registers per lane); at 65 536 envs two waves share
-// a SIMD (<= 256 registers per lane, variant OCC = 2) and issue at twice the rate of a lone wave.
+// Every LDS hand-over and the barrier that orders it is listed in DESIGN.md section 3.1b; the rule when changing this file: a place may be
+// rewritten only after a barrier that its reader has also passed AFTER reading (tests/test_gpu_parity.py::test_kernel_families_agree_and_are_race_free
+// caught the one violation there was -- it shows up as run-to-run differences).
+//
+// At 32 768 envs per GPU the 1024 waves occupy all 1024 SIMDs (one each, up to 512 registers per lane: variant OCC = 1, what lcr_create
+// dispatches for such shards); at 65 536 envs two waves share a SIMD (<= 256 registers per lane, variant OCC = 2: same source, same bits,
+// not yet faster than the one-wave kernels there -- DESIGN.md section 5).
 //
 // Reference map: identical to lcr_kernels.hip (apply_action reach_cube_env.py:223-273, 20 x mj_step :276-279, reward / termination
 // :313-348 and the per-task files, reset :297-311); the arithmetic of every block is the one of lcr_kernels.hip, regrouped by owner.
@@ -36,15 +43,17 @@
 namespace {
 
 // ---- LDS layout of a workgroup: float index = field * 64 + lane (bank = lane mod 32: conflict-free) ----
-//  [0, GR * LDS_ROW)            g rows of the arm slots            (wave A only)
-//  [.., + CCF)                  Stack: cube<->cube contact records (wave B only)
-//  POSE: NC * 13 fields         cube pose and velocity at the top of a substep: cp3 cq4 cv3 cw3      (B -> A, after barrier E)
-//  ACC : NC * 6 fields          cube accelerations ca, cal: warm-start share of the arm<->cube slots (A -> B at barrier 1) and the
-//                               hand-over of the coupled sweeps (B -> A -> B); after the last substep: B's diagnostics words
-//  FLAG: 1 field                [0]: "coupled" of this substep (A -> B); after the last substep: do_reset per lane (A -> B)
-//  PARK: 16 fields              aref / inv of the finger<->floor slots (wave A only; read once per sweep as 16-B vectors)
-//  further hand-overs reuse these areas in phases where they are idle: Cholesky factor L (B -> A at barrier X) in the g rows of slots
-//  3, 4; scaled arm acceleration y (A -> B at barrier Y) in POSE; joint acceleration qacc (B -> A at barrier E) in ACC
+//  [0, GR * LDS_ROW)            g rows of the arm-coupled slots: slots 0, 1 written and read by wave B, slots 2-4 by wave A
+//  [.., + CC records)           Stack: cube<->cube contact records (wave B only; four, or eight with CC8)
+//  POSE: NC * 13 fields         cube pose and velocity at the top of a substep: cp3 cq4 cv3 cw3 (B -> A; written before barrier E, read before X2)
+//  ACC : NC * 6 fields          y in coupled sweeps (A <-> B), qacc (A -> B at barrier E); after the last substep: B's diagnostics words
+//  FLAG: 1 field                [0] c01 (B -> A), [1] cube4 (A -> B) at barrier 1; after the last substep: do_reset per lane (A -> B)
+//  PARK: 16 fields              aref / inv of the finger<->floor slots 2, 3 (wave A only; read once per sweep as 16-B vectors)
+//  hand-overs that reuse these areas in phases where they are idle: ctrl + post-IK q (A -> B, once) and tau (B -> A at barrier X) in the
+//  rows of slot 0; the Cholesky factor L (A -> B at X, read before X2) in the rows of slots 3, 4; Wm (B -> A at barrier 1) in the rows of
+//  slots 0, 1 when those are unused (else wave B keeps both factors and y / qacc make a round trip: barriers Y, E); the warm-start share of
+//  slots 0, 1 in y (B -> A) and of slot 4 in the cube accelerations (A -> B) in POSE[0..5] / POSE[6..] at barrier 1; the cube accelerations
+//  of cube4 sweeps in POSE
 template <int NC, bool ROLL, bool CC8 = false> struct Lds2 {
     static constexpr int GR = ROLL ? 24 : 20;
     static constexpr int G0 = 0;
