@@ -37,6 +37,7 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.max_episode_steps == 50                        # gym_lowcostrobot/__init__.py:12
         assert cfg.impratio == 100.0
         assert cfg.finger_cube_condim == (6 if task in ("push_loop", "stack") else 4)   # rolling rows where they matter
+        assert cfg.step_kernel == 0 and cfg.cc_points == 0          # kernel family by shard size; default cube<->cube manifold (4 points)
         k = hip_lib.lcr_action_dim(ctypes.byref(cfg))
         assert k == (5 if task in ("reach", "push", "push_loop") else 6)  # block_gripper defaults reach:82 / lift:82
         cfg.action_mode = _capi.ACTION_MODES["ee"]
@@ -64,6 +65,15 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
     cfg.finger_cube_condim = 5
     assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
     assert b"finger_cube_condim" in hip_lib.lcr_last_error()
+    for field, bad, msg in (("step_kernel", 3, b"step_kernel"), ("cc_points", 6, b"cc_points")):
+        hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS["stack"])
+        setattr(cfg, field, bad)
+        assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
+        assert msg in hip_lib.lcr_last_error()
+    hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS["stack"])
+    cfg.cc_points, cfg.pgs_iters = 8, -1          # the eight-point manifold lives in the two-wave kernels, the converged mode in the one-wave kernels
+    assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_UNSUPPORTED
+    assert hip_lib.lcr_step_kernel_family(None) == _capi.LCR_ERR_INVALID
     hip_lib.lcr_config_default(ctypes.byref(cfg), 0)
     cfg.action_mode = 7
     assert hip_lib.lcr_action_dim(ctypes.byref(cfg)) == _capi.LCR_ERR_INVALID
