@@ -361,7 +361,7 @@ def main():
                 out["cpu_baseline"]["mujoco_opportunistic"] = mujoco_opportunistic.run(300)
             except Exception as e:
                 out["cpu_baseline"]["mujoco_opportunistic"] = {"status": "reference MuJoCo unavailable", "error": repr(e)}
-        try:  # a real .hdf5 episode file only when h5py happens to be importable on this box
+        try:  # a real .hdf5 episode file through h5py or, without it, the HDF5 C library (recorder.backend())
             from gym_lowcostrobot_amd import recorder
 
             out["hdf5"] = recorder.hdf5_selftest()

@@ -8,8 +8,10 @@
         observations/qvel           (T, 6) float32               <- obs["arm_qvel"]
         action                      (T, k) float32
 
-h5py is used when it is importable; in images without it (this project's build image and GPU boxes) the same arrays go
-to "{...}.npz" under the same dataset names, so downstream code only switches the loader.
+Back ends, first one available: h5py (what the reference uses); the HDF5 C library itself through ctypes (`_hdf5c.py`:
+h5py is a wrapper of the same library, the files are the same -- this project's build image and GPU boxes have libhdf5 1.10
+under /opt/conda but no h5py); if neither loads the same arrays go to "{...}.npz" under the same dataset names, so
+downstream code only switches the loader.  `backend()` says which one is in use.
 
 `RecordHDF5Wrapper` wraps ONE gymnasium-style env (the reference's usage, examples/hdf5_record.py:9-21);
 `VecRecorder` records a chosen subset of a batched VecSim, one file per (env, episode).
@@ -19,12 +21,21 @@ import warnings
 
 import numpy as np
 
+from . import _hdf5c
+
 try:  # pragma: no cover - depends on the environment
     import h5py
 except Exception:
     h5py = None
 
 DATASETS = ("observations/images/front", "observations/images/top", "observations/qpos", "observations/qvel", "action")
+
+
+def backend():
+    """"h5py ..." / "libhdf5 ..." (real .hdf5 files) or "npz" (fallback)"""
+    if h5py is not None:
+        return f"h5py {h5py.__version__}"
+    return _hdf5c.version() or "npz"
 
 
 def write_episode(path_hdf5, observations, actions):
@@ -42,6 +53,8 @@ def write_episode(path_hdf5, observations, actions):
             for k, v in data.items():
                 f.create_dataset(k, data=v)
         return path_hdf5
+    if _hdf5c.available():
+        return _hdf5c.write_file(path_hdf5, data)
     path = os.path.splitext(path_hdf5)[0] + ".npz"
     np.savez(path, **data)
     return path
@@ -51,15 +64,17 @@ def load_episode(path):
     if path.endswith(".npz"):
         with np.load(path) as z:
             return {k: z[k] for k in z.files}
-    with h5py.File(path, "r") as f:  # pragma: no cover
-        return {k: f[k][()] for k in DATASETS if k in f}
+    if h5py is not None:  # pragma: no cover
+        with h5py.File(path, "r") as f:
+            return {k: f[k][()] for k in DATASETS if k in f}
+    return _hdf5c.read_file(path, DATASETS)
 
 
 def hdf5_selftest():
-    """Opportunistic check of the real file format: when h5py imports, write a two-frame episode as .hdf5, read it back and compare
+    """Check of the real file format: with h5py or libhdf5 available, write a two-frame episode as .hdf5, read it back and compare
     dataset by dataset; otherwise say that no .hdf5 byte was written (the .npz fallback carries the same dataset names)."""
-    if h5py is None:
-        return {"status": "h5py not importable on this box: no .hdf5 file written (episodes fall back to .npz with the HDF5 dataset names)"}
+    if h5py is None and not _hdf5c.available():
+        return {"status": "neither h5py nor libhdf5 on this box: no .hdf5 file written (episodes fall back to .npz with the HDF5 dataset names)"}
     import tempfile
 
     rng = np.random.default_rng(0)
@@ -74,7 +89,7 @@ def hdf5_selftest():
         ok = ok and np.array_equal(back["observations/qpos"], np.stack([o["arm_qpos"] for o in obs])) and np.array_equal(back["action"], np.stack(act))
         ok = ok and np.array_equal(back["observations/images/front"], np.stack([o["image_front"] for o in obs]))
         size = os.path.getsize(path)
-    return {"status": "hdf5 written and read back" if ok else "hdf5 round trip MISMATCH", "bytes": size, "h5py": h5py.__version__}
+    return {"status": "hdf5 written and read back" if ok else "hdf5 round trip MISMATCH", "bytes": size, "backend": backend()}
 
 
 class RecordHDF5Wrapper:
@@ -91,8 +106,8 @@ class RecordHDF5Wrapper:
         self.episode_id = 0
         self.files = []
         self._obs, self._act, self._path = [], [], None
-        if h5py is None and not disable_logger:
-            warnings.warn("h5py is not installed: episodes are written as .npz with the HDF5 dataset names")
+        if backend() == "npz" and not disable_logger:
+            warnings.warn("neither h5py nor libhdf5 found: episodes are written as .npz with the HDF5 dataset names")
 
     def __getattr__(self, name):
         return getattr(self.env, name)
