@@ -273,6 +273,26 @@ def test_recorder_writes_a_real_hdf5_file(tmp_path):
     dump = subprocess.run([h5dump, "-d", "/observations/qpos", "-m", "%.9g", path], capture_output=True, text=True, check=True).stdout
     vals = [float(x) for ln in dump.splitlines() if ln.strip().startswith("(") for x in ln.split(":", 1)[1].replace(",", " ").split()]
     np.testing.assert_allclose(np.array(vals, np.float32).reshape(T, 6), np.stack([o["arm_qpos"] for o in obs]), rtol=0, atol=0)
+    # a real h5py (another interpreter of this image has one) writes the same episode with the reference's calls
+    # (record_hdf5.py:52-61: file.create_dataset(name, data=...)); h5diff finds no difference between its file and ours
+    py = next((c for c in ("/opt/conda/bin/python3.9", "/opt/conda/bin/python3") if os.path.exists(c)), None)
+    h5diff = _h5tool("h5diff")
+    if py is None or h5diff is None or subprocess.run([py, "-c", "import h5py, numpy"], capture_output=True, env={}).returncode != 0:
+        pytest.skip("no second interpreter with h5py: cross-check against h5py's own file skipped")
+    np.savez(tmp_path / "episode.npz", **{k.replace("/", "__"): v for k, v in back.items()})
+    ref = str(tmp_path / "written_by_h5py.hdf5")
+    code = ("import h5py, numpy as np, sys\n"
+            "z = np.load(sys.argv[1])\n"
+            "with h5py.File(sys.argv[2], 'w') as f:\n"
+            "    for k in ('observations__images__front', 'observations__images__top', 'observations__qpos', 'observations__qvel', 'action'):\n"
+            "        f.create_dataset(k.replace('__', '/'), data=z[k])\n"
+            "with h5py.File(sys.argv[3], 'r') as f:\n"
+            "    print(sorted((k, f[k].shape, str(f[k].dtype)) for k in ('action', 'observations/qpos', 'observations/images/top')))\n")
+    r = subprocess.run([py, "-c", code, str(tmp_path / "episode.npz"), ref, path], capture_output=True, text=True, env={})
+    assert r.returncode == 0, r.stderr
+    assert "('action', (3, 5), 'float32')" in r.stdout and "('observations/images/top', (3, 240, 320, 3), 'uint8')" in r.stdout   # h5py reads OUR file
+    d = subprocess.run([h5diff, "-v", path, ref], capture_output=True, text=True)
+    assert d.returncode == 0 and "0 differences found" in d.stdout, d.stdout + d.stderr
 
 
 def test_record_wrapper_file_names_and_npz_fallback(tmp_path, monkeypatch):
