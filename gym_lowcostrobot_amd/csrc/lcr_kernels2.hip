@@ -533,19 +533,21 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         }
         // ---- joint limits: rows +-e_j.  g_j = L^-1 (sg e_j), regulariser and reference acceleration once per substep ----
         bool lim_act[6];
-        bool any_lim = false;
+        unsigned lim_wave = 0u;   // bit j: joint j is beyond a limit in SOME lane (wave-uniform).  Under random actions that is joint 0 in ~40 % of the
+                                  // waves and the others almost never; a joint no lane needs contributes exact zeros, so its rows are skipped.
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             lim_act[j] = (q[j] < JLO[j]) || (q[j] > JHI[j]);
             if (P.diag) diag_choice(DG, lim_act[j], 18 + j, q[j] < JLO[j] ? 0 : 1);
             Wlim[j] = lim_act[j] ? Wlim[j] : 0.f;
-            any_lim = any_lim || lim_act[j];
+            lim_wave |= __any(lim_act[j]) ? (1u << j) : 0u;
         }
-        const bool wave_lim = __any(any_lim) != 0;
+        const bool wave_lim = lim_wave != 0u;
         float glim[6][6], lim_aref[6], lim_R[6], lim_inv[6];
         if (wave_lim) {
 #pragma unroll
             for (int j = 0; j < 6; j++) {
+                if (!((lim_wave >> j) & 1u)) continue;
                 const bool lower = q[j] < JLO[j];
                 const float sg = lower ? 1.f : -1.f;
                 const float pos = lower ? q[j] - JLO[j] : JHI[j] - q[j];
@@ -592,6 +594,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
             if (wave_lim) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
+                    if (!((lim_wave >> j) & 1u)) continue;
                     float gy = 0.f;
 #pragma unroll
                     for (int k = 0; k < 6; k++) gy = fmaf(glim[j][k], y[k], gy);
