@@ -406,6 +406,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         f3 vw[8];
         float worst = 1.f;
         bool lo_x = false, lo_y = false;
+        const bool inpen = cube_in_pen(S.cp[0]);   // (a cube outside the rails' outer rectangle touches no rail)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
@@ -413,9 +414,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             const f3 p = vw[i] + S.cp[0];
             const bool low = p.z < WALL_TOP;
             const float dmin = fminf(fminf(p.x + WALL_X, WALL_X - p.x), fminf(p.y - WALL_Y0, WALL_Y1 - p.y));
-            worst = fminf(worst, low ? dmin : 1.f);
-            lo_x = lo_x || (low && p.x + WALL_X < 0.f);
-            lo_y = lo_y || (low && p.y - WALL_Y0 < 0.f);
+            worst = fminf(worst, (low && inpen) ? dmin : 1.f);
+            lo_x = lo_x || (low && inpen && p.x + WALL_X < 0.f);
+            lo_y = lo_y || (low && inpen && p.y - WALL_Y0 < 0.f);
         }
         wall_any = __any(worst < 0.f) != 0;
         if (wall_any) {
@@ -434,7 +435,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int i = 0; i < 8; i++) {
                     const f3 p = vw[i] + S.cp[0];
                     const float dist = fmaf(sg, pr == 0 ? p.x : p.y, off);
-                    const bool pen = dist < 0.f && p.z < WALL_TOP;
+                    const bool pen = dist < 0.f && p.z < WALL_TOP && inpen;
                     const bool first = pen && (!h1 || dist < d1);
                     const bool second = pen && !first && (!h2 || dist < d2);
                     if (P.diag) { i2 = first ? i1 : (second ? i : i2); i1 = first ? i : i1; }

@@ -39,6 +39,7 @@ constexpr float MU_FINGER = 1.5f, MU_TORS = 0.005f;  // finger geom (follower.xm
 constexpr float RT_FF = (MU_FINGER * MU_FINGER) / (MU_TORS * MU_TORS);
 // PushCubeLoop rails (push_cube_loop.xml:44-47): inner faces of the four wall boxes and their top
 constexpr float WALL_X = 0.115f, WALL_Y0 = 0.10f, WALL_Y1 = 0.17f, WALL_TOP = 0.012f;
+constexpr float WALL_THICK = 0.02f;   // the rail boxes are 2 x 0.01 thick (push_cube_loop.xml:45-48): their outer faces lie WALL_THICK beyond the inner ones
 constexpr float INVW_DOF[6] = {lcrm::INVW_DOF1, lcrm::INVW_DOF2, lcrm::INVW_DOF3, lcrm::INVW_DOF4, lcrm::INVW_DOF5, lcrm::INVW_DOF6};
 
 // MuJoCo impedance curve, power 2, midpoint 0.5 (see oracle kbi()): y = 2x^2 for x <= 0.5, 1 - 2(1-x)^2 above.  Branch-free:
@@ -53,6 +54,13 @@ DEV float impedance(float dist, float d0, float dw, float inv_width) {
 }
 
 // contact frame from unit normal (MuJoCo mju_makeFrame): t1, t2
+// (D7) PushCubeLoop rails act as the inner faces of the four wall boxes on the cube vertices below the wall top -- as long as the cube CENTRE is inside the
+// outer rectangle of the rails (inner faces + the boxes' thickness).  A cube that was knocked over a rail lies outside the pen untouched, as next to the
+// reference's wall boxes, instead of being "deep inside" a half-space (which ejected it at up to 1 200 m/s: 0.5 % of the env-states of a random-policy run
+// had the cube out there).  The penetration a rail can see is thereby bounded by thickness + half a cube diagonal.
+DEV bool cube_in_pen(f3 c) {
+    return fabsf(c.x) < WALL_X + WALL_THICK && c.y > WALL_Y0 - WALL_THICK && c.y < WALL_Y1 + WALL_THICK;
+}
 DEV void make_frame(f3 n, f3 &t1, f3 &t2) {
     f3 y = (n.y < 0.5f && n.y > -0.5f) ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f);
     float d = dot(n, y);

@@ -129,6 +129,7 @@ static const double MU_LOOP[5] = {1.5, 1.5, 1.5, 1.5, 1.5};   /* push_cube_loop.
 #define WALL_Y0 0.10
 #define WALL_Y1 0.17
 #define WALL_TOP 0.012
+#define WALL_THICK 0.02   /* the rail boxes are 2 x 0.01 thick: outer faces WALL_THICK beyond the inner ones (push_cube_loop.xml:45-48 size) */
 
 typedef struct {
     int ncube;
@@ -547,12 +548,20 @@ static int collide_link_group(const kin_t *K, int g, int ngroups, contact_t *out
     return have;
 }
 /* (D7) PushCubeLoop rails (push_cube_loop.xml:44-47): the four wall boxes are restated as their inner faces -- vertical
- * half-spaces that only act below the wall top (z < 0.012).  The pen is wider than the cube in x and in y, so the cube
+ * half-spaces that only act below the wall top (z < 0.012) and only while the cube CENTRE is inside the outer rectangle of the rails
+ * (inner faces + box thickness 0.02; round 3: before, a cube knocked over a rail was "deep inside" a half-space -- 0.5 % of the
+ * env-states of a random-policy run, with cube speeds up to 1 200 m/s in the tail; now it rests outside the pen as next to the reference's boxes).
+ * The pen is wider than the cube in x and in y, so the cube
  * can reach at most one x rail and one y rail: contact slots 8,9 belong to the x pair (the x = -0.115 rail if any vertex
  * is beyond it, else the x = +0.115 rail), slots 10,11 to the y pair (y = 0.10 rail if touched, else y = 0.17); each
  * pair keeps its two deepest vertices (ties: lower vertex index first).  Frame normal points from the wall into the pen. */
+static int cube_in_pen(const real *c) {   /* cube centre inside the outer rectangle of the rails (inner faces + box thickness) */
+    return c[0] < (real)WALL_X + (real)WALL_THICK && -c[0] < (real)WALL_X + (real)WALL_THICK
+        && c[1] > (real)WALL_Y0 - (real)WALL_THICK && c[1] < (real)WALL_Y1 + (real)WALL_THICK;
+}
 static int collide_walls(const kin_t *K, contact_t *out) {
     int n = 0;
+    if (!cube_in_pen(K->cp[0])) return 0;
     real P[8][3];
     for (int i = 0; i < 8; i++) {
         real v[3] = {(i & 1) ? (real)CUBE_HALF : (real)-CUBE_HALF, (i & 2) ? (real)CUBE_HALF : (real)-CUBE_HALF,
@@ -1413,7 +1422,7 @@ void orc_last_diag(int *n_rows, int *n_contacts, double *pgs_residual) {
 
 /* the oracle's own L0 tables, flattened, for the test that compares them with tests/golden/model_golden.json:
  * per link i (6): pos3, axis3, ipos3, iquat4, mass, diaginertia3, range2 = 19 doubles; then site3, armature, damping, kp, kv,
- * frcrange, timestep, cube_half; then per task (6): cube mass, cube inertia, mu_tan, mu_tors; then walls (4);
+ * frcrange, timestep, cube_half; then per task (6): cube mass, cube inertia, mu_tan, mu_tors; then walls (5: inner faces x, y0, y1, top, thickness);
  * then NSPH x (link, pos3, rad) and NLPX x (link, pos3, rad, group).  Returns the number of doubles written. */
 int orc_model_table(double *out) {
     int n = 0;
@@ -1432,7 +1441,7 @@ int orc_model_table(double *out) {
         task_model T = get_task_model(t);
         out[n++] = T.cube_mass; out[n++] = T.cube_inertia; out[n++] = T.mu_cube[0]; out[n++] = T.mu_cube[2];
     }
-    out[n++] = WALL_X; out[n++] = WALL_Y0; out[n++] = WALL_Y1; out[n++] = WALL_TOP;
+    out[n++] = WALL_X; out[n++] = WALL_Y0; out[n++] = WALL_Y1; out[n++] = WALL_TOP; out[n++] = WALL_THICK;
     /* finger geom class (follower.xml:15): solimp d0, dwidth-limit, width; friction (tangential, torsional, rolling) */
     out[n++] = SOLIMP_FINGER[0]; out[n++] = SOLIMP_FINGER[1]; out[n++] = SOLIMP_FINGER[2];
     out[n++] = MU_FINGER[0]; out[n++] = MU_FINGER[2]; out[n++] = MU_FINGER[3];

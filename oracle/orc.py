@@ -229,7 +229,7 @@ def model_table():
     for k in ("armature", "damping", "kp", "kv", "frcrange", "timestep", "cube_half"):
         t[k] = take(1)[0]
     t["tasks"] = [dict(zip(("cube_mass", "cube_inertia", "mu_tan", "mu_tors"), take(4))) for _ in range(6)]
-    t["walls"] = dict(zip(("x", "y0", "y1", "top"), take(4)))
+    t["walls"] = dict(zip(("x", "y0", "y1", "top", "thick"), take(5)))
     t["finger"] = dict(zip(("solimp_d0", "solimp_dmax", "solimp_width", "mu_tan", "mu_tors", "mu_roll"), take(6)))
     t["spheres"] = [{"link": int(take(1)[0]), "pos": take(3), "rad": take(1)[0]} for _ in range(2)]
     rest = list(it)

@@ -81,6 +81,11 @@ def test_scene_constants_equal_the_scene_files():
     assert abs(walls["top_wall"]["pos"][1] + walls["top_wall"]["size"][1] - w["y0"]) < 1e-12
     assert abs(walls["bottom_wall"]["pos"][1] - walls["bottom_wall"]["size"][1] - w["y1"]) < 1e-12
     assert abs(walls["left_wall"]["pos"][2] + walls["left_wall"]["size"][2] - w["top"]) < 1e-12
+    # (D7, round 3) the rails act only while the cube centre is inside their OUTER rectangle: inner faces + the boxes' thickness
+    assert all(abs(2 * walls[k]["size"][0 if k in ("left_wall", "right_wall") else 1] - w["thick"]) < 1e-12 for k in walls)
+    assert abs(walls["right_wall"]["pos"][0] + walls["right_wall"]["size"][0] - (w["x"] + w["thick"])) < 1e-12
+    assert abs(walls["top_wall"]["pos"][1] - walls["top_wall"]["size"][1] - (w["y0"] - w["thick"])) < 1e-12
+    assert abs(walls["bottom_wall"]["pos"][1] + walls["bottom_wall"]["size"][1] - (w["y1"] + w["thick"])) < 1e-12
 
 
 def test_header_is_regenerated_from_the_golden_file(tmp_path, monkeypatch):

@@ -354,6 +354,21 @@ def test_loop_rails_and_goal_switch():
     assert o.goal[0] == 1 and o.qpos[0, 6] < 0
 
 
+def test_loop_cube_outside_the_rails_is_left_alone():
+    """(D7) the rails act while the cube centre is inside their outer rectangle (push_cube_loop.xml:45-48: boxes 0.02 thick around the pen).  A cube
+    that was knocked over a rail rests outside, as it would next to the reference's wall boxes; as half-spaces the rails saw it 'deep inside' and
+    threw it back at hundreds of m/s.  Straddling a rail with the centre still inside: pushed back in."""
+    o = orc.Oracle("push_loop", 3, auto_reset=0, max_episode_steps=0)
+    o.reset(seeds=[0, 1, 2])
+    o.qpos[:, 6:9] = [[0.20, 0.135, 0.0149], [0.0, 0.30, 0.0149], [0.128, 0.135, 0.0149]]   # beyond the right rail / beyond the far rail / straddling the right rail
+    o.qvel[:] = 0
+    start = o.qpos[:, 6:9].copy()
+    for _ in range(10):
+        o.step(np.zeros((3, 5), np.float32))
+    assert np.abs(o.qpos[:2, 6:8] - start[:2, :2]).max() < 1e-5 and np.abs(o.qvel[:2, 6:9]).max() < 1e-3      # outside: at rest where it lay
+    assert o.qpos[2, 6] < 0.11 and np.abs(o.qvel[2, 6:9]).max() < 0.5                                          # straddling: back inside, no ejection
+
+
 # ---------------------------------------------------------------- analytic known answers of the restated MuJoCo pipeline
 def test_kat_free_fall_semi_implicit_euler():
     """no contact: v_n = -g h n and z_n = z0 - g h^2 n(n+1)/2 exactly (velocity first, then position)"""
