@@ -93,7 +93,13 @@ def hdf5_selftest():
 
 
 class RecordHDF5Wrapper:
-    """Single-env recorder with the reference's constructor arguments (record_hdf5.py:66-73)."""
+    """Single-env recorder with the reference's constructor arguments (record_hdf5.py:66-73).
+
+    `length = 0`: one file per episode, a new one after every terminated / truncated step and after every reset() (record_hdf5.py:131-134).
+    `length > 0`: the first `length` frames after a reset() go to that episode's file (the reference writes the file at the same moment,
+    record_hdf5.py:127-129, `recorded_frames` starting at 1) and recording then pauses until the next reset().  REF-QUIRK not reproduced: the
+    reference keeps capturing after that write and overwrites the SAME file with every following block of `length` frames, and its close()
+    raises on `np.stack([])` when no frame is pending; here the file keeps its first `length` frames and close() with nothing pending is a no-op."""
 
     def __init__(self, env, hdf5_folder, length=0, name_prefix="hdf5_record", disable_logger=False):
         self.env = env

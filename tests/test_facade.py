@@ -226,6 +226,37 @@ def test_vec_recorder_writes_reference_layout(hip_lib, tmp_path):
             assert fh.read(8) == b"\x89HDF\r\n\x1a\n"          # the HDF5 superblock signature
 
 
+@pytest.mark.gpu
+def test_reference_hdf5_record_example_flow(hip_lib, tmp_path):
+    """the reference's examples/hdf5_record.py, line by line (imports :5-6, env and wrapper :10-11, the loop :15-19, close :21), shortened:
+    it must run unchanged against this package and leave episode files in the reference's layout"""
+    from gym_lowcostrobot.envs.reach_cube_env import ReachCubeEnv
+    from gym_lowcostrobot.envs.wrappers.record_hdf5 import RecordHDF5Wrapper
+    from gym_lowcostrobot_amd import recorder
+
+    env = ReachCubeEnv(render_mode=None, action_mode="ee")
+    env = RecordHDF5Wrapper(env, hdf5_folder=str(tmp_path / "data"), length=40, name_prefix="reach")
+    env.reset()
+    adim = env.action_space.shape[0]
+    resets = 1
+    for _ in range(130):
+        action = env.action_space.sample()
+        observation, reward, terminated, truncated, info = env.step(action)
+        if terminated:
+            env.reset()
+            resets += 1
+    env.close()
+    files = sorted(os.listdir(tmp_path / "data"))
+    assert len(files) == resets and files[0].startswith("reach-episode-0.")
+    ep = recorder.load_episode(str(tmp_path / "data" / files[0]))
+    T = ep["action"].shape[0]
+    assert 1 <= T <= 40 and ep["action"].shape == (T, adim) and adim in (3, 4) and ep["observations/qpos"].shape == (T, 6)
+    assert ep["observations/images/front"].shape == (T, 240, 320, 3) and ep["observations/images/front"].dtype == np.uint8   # default observation_mode "image"
+    assert ep["observations/images/top"].std() > 5
+    if recorder.backend() != "npz":
+        assert files[0].endswith(".hdf5")
+
+
 def _h5tool(name):
     import shutil
 
