@@ -254,6 +254,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     }
     wg_barrier();   // E0: wave B has published the initial cube pose
     __builtin_amdgcn_s_setprio(2);   // where two waves share a SIMD the arm wave is the longer chain: it wins the issue arbitration
+    bool hot = false;                 // this workgroup has had a coupled substep in this step
 
     // profiling aid (lcr_config.diagnostics = 3): cycles of this wave in total / waiting at barriers / before barrier 1, coupled substeps
     const bool prof = P.diag == 3;
@@ -583,6 +584,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         if (prof) pf_wait += clock64() - pf_mark;
         const bool c01 = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // wave B: a finger sphere touches a cube in some lane
         const bool coupled = c01 || cube4;
+        if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }   // (see wave B)
         if (prof) pf_coupled += coupled ? 1u : 0u;
         if (c01) {   // warm-start forces of the finger<->cube slots act on the arm too: wave B's sum of g_r f_r
 #pragma unroll
@@ -1074,6 +1076,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     long long pf_t0 = prof ? clock64() : 0, pf_wait = 0, pf_mark = 0;
     Diag DGtot = {0u, 0u, 0u, 0u};
     const float minv = P.cube_minv, iinv = P.cube_iinv;
+    bool hot = false;   // this workgroup has had a coupled substep in this step
     for (int sub = 0; sub < P.n_substeps; sub++) {
         Diag DG = {0u, 0u, 0u, 0u};
         __builtin_amdgcn_s_setprio(3);
@@ -1094,7 +1097,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         if (prof) pf_mark = clock64();
         wg_barrier();   // X: tau is in LDS for wave A; wave A's Cholesky factor of the joint-space inertia is in LDS
         if (prof) pf_wait += clock64() - pf_mark;
-        __builtin_amdgcn_s_setprio(0);
+        if (!hot) __builtin_amdgcn_s_setprio(0);
         Chol6 CL;
         {
             const float *pl = lds + LL::LFAC0 + lane;
@@ -1585,6 +1588,9 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         if (prof) pf_wait += clock64() - pf_mark;
         const bool cube4 = __builtin_amdgcn_readfirstlane(xflag[1]) != 0;   // wave A: a gripper-body proxy touches a cube in some lane
         const bool coupled = c01 || cube4;
+        // A workgroup with coupled substeps is the one a launch waits for (its two chains run in series): from its first coupled substep on both its
+        // waves take the top issue priority for the rest of the step, so that where two waves share a SIMD the partner fills the gaps instead of halving them.
+        if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }
         if (cube4) {   // warm-start forces of the proxy slot act on the cube too
 #pragma unroll
             for (int c = 0; c < NC; c++) {
