@@ -322,12 +322,16 @@ def main():
                 pj = json.load(f)
             pmc = pj["step_kernel_pmc_per_launch"]
             if pj.get("workload") == args.workload and args.obs == "state" and pj.get("kernel_sha16") == sha and n == 65536:
+                two_wave = sim.step_kernel_name == "lcr_step2_kernel"
                 out["valu"] = {
                     "source": os.path.basename(pm),
-                    "valu_insts_per_wave_per_launch": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
+                    # VALU instructions per 64 envs (one wave-instruction serves 64 lanes = 64 envs; the two-wave kernels spend two waves on them)
+                    "valu_insts_per_64_envs_per_launch": pmc["SQ_INSTS_VALU"] / ((n + 63) // 64),
+                    "waves_per_64_envs": pmc["SQ_WAVES"] / ((n + 63) // 64),
                     "valu_busy_frac_of_wave_cycles": pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"],
                     "wait_frac_of_wave_cycles": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
-                    "note": "one wave per SIMD at 65 536 envs; a single wave issues one VALU instruction per ~5.2 cycles (tools/ubench/valu_issue.hip)",
+                    "note": ("two cooperating waves per 64 envs, two waves per SIMD at 65 536 envs: they interleave where a lone wave cannot issue (tools/ubench/valu_issue.hip)"
+                             if two_wave else "one wave per SIMD at 65 536 envs; a single wave issues one VALU instruction per ~5.2 cycles (tools/ubench/valu_issue.hip)"),
                 }
                 # flops: executed by the kernel (measured VALU instructions x flop weight of its instruction
                 # mix) and, for reference, the census of the CPU oracle's dense formulation (tools/count_flops.py)
@@ -337,9 +341,10 @@ def main():
                 # flop weight of a VALU instruction: from the SAME round's static instruction mix (profiles/rNN_isa_mix.json)
                 with open(pm.replace("_pmc.json", "_isa_mix.json")) as f:
                     mixj = json.load(f)
-                mix = [v["flop_per_valu"] for k, v in mixj.items() if "lcr_step" in k and "flop_per_valu" in v][0]
-                out["valu"]["flop_per_valu_source"] = os.path.basename(pm.replace("_pmc.json", "_isa_mix.json"))
-                kflops = out["valu"]["valu_insts_per_wave_per_launch"] * mix     # per lane == per env-step
+                want = "lcr_step2_kernel" if two_wave else "lcr_step_kernel"
+                mix = [v["flop_per_valu"] for k, v in mixj.items() if want in k and "flop_per_valu" in v][0]
+                out["valu"]["flop_per_valu_source"] = os.path.basename(pm.replace("_pmc.json", "_isa_mix.json")) + f" ({want})"
+                kflops = out["valu"]["valu_insts_per_64_envs_per_launch"] * mix     # per lane == per env-step
                 out["valu"].update({
                     "kernel_flops_per_env_step_est": kflops,
                     "kernel_tflops_est": kflops * steps_per_s / 1e12,

@@ -214,7 +214,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     size_t o_goal = off; off += al(sizeof(int) * N);
     size_t o_time = off; off += al(sizeof(double) * N);
     size_t o_diag = off; if (cfg->diagnostics) off += 4 * al(sizeof(unsigned) * N) + al(sizeof(float) * 6 * N);
-    size_t o_scr = off; if (cfg->task == LCR_TASK_STACK) off += al(sizeof(float) * (cfg->finger_cube_condim == 4 ? 24 : 48) * N);   // Stack (one-wave kernels): g rows of the arm-link proxy slot (+ the rolling rows of the finger slots)
+    // scratch: Stack on the one-wave kernels keeps the g rows of the arm-link proxy slot (+ the rolling rows of the finger slots) here, 24 / 48 floats per env;
+    // the two-wave kernels compiled for two waves per SIMD hand Wm = (M + hD)^-1 L from the cube wave to the arm wave through it in substeps with a finger on
+    // a cube, 36 floats per lane of every (64-lane) workgroup
+    size_t o_scr = off; off += al(sizeof(float) * 48 * (((N + 63) / 64) * 64));
     const bool carry_warm = !(cfg->compat & LCR_COMPAT_COLD_SOLVE_EACH_STEP);
     size_t o_warm = off; if (carry_warm) off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
@@ -278,12 +281,14 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         if (const char *ov = getenv("LCR_STACK_LDS")) { if (cfg->task == LCR_TASK_STACK) D.big_lds = strcmp(ov, "big") == 0 ? 1 : (strcmp(ov, "small") == 0 ? 0 : D.big_lds); }
         D.walls = loop ? 1 : 0;
         // step-kernel family.  Shards whose 2 x ceil(N / 64) waves fit the chip's SIMDs one each (<= 32 768 envs on an MI355X: BASELINE configs 4
-        // and 5) run the two-cooperating-waves kernels (lcr_kernels2.hip, variant compiled for one wave per SIMD); larger shards run the
-        // one-wave-per-64-envs kernels until the two-waves-per-SIMD variant is faster (measured: DESIGN.md section 5).
-        // LCR_STEP_KERNEL=single|coop1|coop2 overrides (tests and profiling exercise every family at small sizes).
+        // and 5) run the two-cooperating-waves kernels (lcr_kernels2.hip, variant compiled for one wave per SIMD).  Larger shards: the variant
+        // compiled for two waves per SIMD where it is the faster one -- measured (DESIGN.md section 5, 65 536 envs, random policy): ReachCube 0.265 ms
+        // against 0.290 ms on the one-wave-per-64-envs kernels; the tasks with more finger<->cube coupling 0.37-0.39 against 0.34 (a coupled workgroup
+        // runs its two waves in series and at top priority: that works while its SIMD partners are mostly uncoupled) -- else the one-wave kernels.
+        // lcr_config.step_kernel pins a family; LCR_STEP_KERNEL=single|coop1|coop2 overrides (tests and profiling exercise every family at small sizes).
         {
             const size_t waves2 = 2 * ((N + 63) / 64), simds = 4 * (size_t)prop.multiProcessorCount;
-            D.coop = waves2 <= simds ? 1 : 0;
+            D.coop = waves2 <= simds ? 1 : (cfg->task == LCR_TASK_REACH ? 2 : 0);
             if (cfg->step_kernel == 1) D.coop = 0;
             else if (cfg->step_kernel == 2) D.coop = waves2 <= simds ? 1 : 2;
             D.cc8 = (cfg->task == LCR_TASK_STACK && cfg->cc_points == 8) ? 1 : 0;
@@ -334,7 +339,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.max_sweeps = cfg->diagnostics ? (unsigned *)(base + o_diag + 2 * al(sizeof(unsigned) * N)) : nullptr;
     D.choice = cfg->diagnostics ? (unsigned *)(base + o_diag + 3 * al(sizeof(unsigned) * N)) : nullptr;
     D.ctrl_out = cfg->diagnostics ? (float *)(base + o_diag + 4 * al(sizeof(unsigned) * N)) : nullptr;
-    D.scratch = cfg->task == LCR_TASK_STACK ? (float *)(base + o_scr) : nullptr;
+    D.scratch = (float *)(base + o_scr);
     D.warm = carry_warm ? (float *)(base + o_warm) : nullptr;
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;

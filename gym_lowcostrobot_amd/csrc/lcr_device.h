@@ -51,7 +51,7 @@ struct LcrDev {
     float *term_quat; // [8][n]  cube quaternion(s) of the terminal state (valid where did_reset)
     unsigned *active_mask, *active_count, *max_sweeps, *choice;  // [n] each, diagnostics of the last step (diag != 0)
     float *ctrl_out;  // [6][n] actuator targets of the last step (diag != 0)
-    float *scratch;   // Stack: g rows of the arm-link proxy slot, [12][n] float2
+    float *scratch;   // one-wave Stack kernels: g rows of the arm-link proxy slot, [12][n] float2; two-wave kernels at two waves per SIMD: Wm records, [groups][64][36]
     // image observations
     unsigned char *img_front, *img_top;  // [n][240][320][3] or null
     unsigned char *img_bg;               // [2][240][320][3] env-independent background of camera_front / camera_top, or null

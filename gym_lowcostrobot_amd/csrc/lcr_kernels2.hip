@@ -28,8 +28,8 @@
 // caught the one violation there was -- it shows up as run-to-run differences).
 //
 // At 32 768 envs per GPU the 1024 waves occupy all 1024 SIMDs (one each, up to 512 registers per lane: variant OCC = 1, what lcr_create
-// dispatches for such shards); at 65 536 envs two waves share a SIMD (<= 256 registers per lane, variant OCC = 2: same source, same bits,
-// not yet faster than the one-wave kernels there -- DESIGN.md section 5).
+// dispatches for such shards); at 65 536 envs two waves share a SIMD (<= 256 registers per lane, variant OCC = 2: same source, same bits;
+// faster than the one-wave kernels for Reach only -- DESIGN.md section 5).
 //
 // Reference map: identical to lcr_kernels.hip (apply_action reach_cube_env.py:223-273, 20 x mj_step :276-279, reward / termination
 // :313-348 and the per-task files, reset :297-311); the arithmetic of every block is the one of lcr_kernels.hip, regrouped by owner.
@@ -51,10 +51,10 @@ namespace {
 //  PARK: 16 fields              aref / inv of the finger<->floor slots 2, 3 (wave A only; read once per sweep as 16-B vectors)
 //  hand-overs that reuse these areas in phases where they are idle: ctrl + post-IK q (A -> B, once) and tau (B -> A at barrier X) in the
 //  rows of slot 0; the Cholesky factor L (A -> B at X, read before X2) in the rows of slots 3, 4; Wm (B -> A at barrier 1) in the rows of
-//  slots 0, 1 when those are unused (else wave B keeps both factors and y / qacc make a round trip: barriers Y, E); the warm-start share of
+//  slots 0, 1 when those are unused (a finger on a cube: WM0, or a global scratch record where LDS is full -- struct comment); the warm-start share of
 //  slots 0, 1 in y (B -> A) and of slot 4 in the cube accelerations (A -> B) in POSE[0..5] / POSE[6..] at barrier 1; the cube accelerations
 //  of cube4 sweeps in POSE
-template <int NC, bool ROLL, bool CC8 = false> struct Lds2 {
+template <int NC, bool ROLL, bool CC8 = false, bool WMLDS = false> struct Lds2 {
     static constexpr int GR = ROLL ? 24 : 20;
     static constexpr int G0 = 0;
     static constexpr int CC0 = GR * LDS_ROW;
@@ -64,7 +64,10 @@ template <int NC, bool ROLL, bool CC8 = false> struct Lds2 {
     static constexpr int PARK0 = FLAG0 + 64;                 // aref[4] | inv[4] of the finger<->floor slots 2, 3 as 16-B vectors: [slot][aref|inv][lane][4]
     static constexpr bool HAS_PARK = !CC8;                   // (eight cube<->cube records: no room, the constants stay in wave A's registers --
                                                              //  that variant runs one wave per SIMD: 2 x 79.7 KiB per CU)
-    static constexpr int TOTAL = PARK0 + (HAS_PARK ? 2 * 2 * 64 * 4 : 0);
+    // Wm = (M + hD)^-1 L in a substep with a finger on a cube (the rows of slots 0, 1 are in use then): the one-wave-per-SIMD build has LDS to spare
+    // (two workgroups per CU) and keeps a 36-field place for it; the two-waves-per-SIMD build and CC8 go through a global scratch record instead
+    static constexpr int WM0 = PARK0 + (HAS_PARK ? 2 * 2 * 64 * 4 : 0);
+    static constexpr int TOTAL = WM0 + (WMLDS ? 36 * 64 : 0);
     // hand-over of the Cholesky factor (21 + 6 floats per lane, wave B -> wave A at barrier X): aliases the g rows of slots 3 and 4,
     // which wave A writes only after it has read the factor
     static constexpr int LFAC0 = G0 + (ROLL ? 16 : 12) * LDS_ROW;
@@ -134,9 +137,9 @@ template <int NC> constexpr bool rne_on_arm() { return false; }
 // ================================================================================================
 // wave A: the arm
 // ================================================================================================
-template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8>
+template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8, bool GW>
 DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *lds, const int lane, const int e, const bool valid) {
-    using LL = Lds2<NC, ROLL, CC8>;
+    using LL = Lds2<NC, ROLL, CC8, !GW>;
     using namespace lcrm;
     constexpr int NRW = ROLL ? 6 : 4;
     constexpr bool RNE_ON_ARM = rne_on_arm<NC>();
@@ -327,7 +330,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 #pragma unroll
         for (int j = 0; j < 6; j++) y[j] = RNE_ON_ARM ? tau_own[j] : lds[LL::G0 + lane + j * 64];   // tau: this wave's (two cubes) or wave B's
         fsub(CL, y);
-        read_pose();    // cube pose and velocity at the top of this substep (wave B published it before barrier Y of the previous one)
+        read_pose();    // cube pose and velocity at the top of this substep (wave B published it before barrier E of the previous one)
         wg_barrier();   // X2: wave B has read L (its LDS place is reused for contact rows from here on); this wave has read the pose
                         //     (wave B reuses the first fields of the pose area for the finger<->cube slots' warm-start share of y)
         CubeRot CR[NC];
@@ -823,8 +826,8 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 
         // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y, i.e. qacc = Wm y with wave B's Wm = (M + hD)^-1 L ----
         float qacc[6];
-        if (!c01) {   // wave B parked Wm = (M + hD)^-1 L in the idle LDS place of the rows of slots 0, 1 before barrier 1
-            const float *pw = lds + LL::G0 + lane;
+        if (!(GW && c01)) {   // wave B parked Wm = (M + hD)^-1 L before barrier 1: in the idle LDS place of the rows of slots 0, 1, or (a finger on a cube) in its own
+            const float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 float s = 0.f;
@@ -832,22 +835,25 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 for (int k = 0; k < 6; k++) s = fmaf(pw[(i * 6 + k) * 64], y[k], s);
                 qacc[i] = s;
             }
+        } else {              // ... or, column-major, in this lane's global scratch record (same sums in the same order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 36;
+            float wm[36];
 #pragma unroll
-            for (int j = 0; j < 6; j++) xacc[j * 64] = qacc[j];   // wave B integrates its copy of the arm state with the same values
-            if (prof) pf_mark = clock64();
-            wg_barrier();   // E: wave B has integrated the cubes and published their new pose
-            if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
-        } else {      // y visits wave B (it holds both factors), qacc comes back
-            float *py = lds + LL::LFAC0 + lane;   // (the contact rows there are dead after the last sweep; wave A rewrites the place only after barrier E)
+            for (int k = 0; k < 36; k++) wm[k] = gw[k];
 #pragma unroll
-            for (int j = 0; j < 6; j++) py[j * 64] = y[j];
-            if (prof) pf_mark = clock64();
-            wg_barrier();   // Y
-            wg_barrier();   // E
-            if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
+            for (int i = 0; i < 6; i++) {
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 6; j++) qacc[j] = xacc[j * 64];
+                for (int k = 0; k < 6; k++) s = fmaf(wm[k * 6 + i], y[k], s);
+                qacc[i] = s;
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 6; j++) xacc[j * 64] = qacc[j];   // wave B integrates its copy of the arm state with the same values
+        if (prof) pf_mark = clock64();
+        wg_barrier();   // E: wave B has integrated the cubes and published their new pose
+        if (prof) { pf_wait += clock64() - pf_mark; pf_we += clock64() - pf_mark; }
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             qd[j] = fmaf(H, qacc[j], qd[j]);
@@ -985,9 +991,9 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 // ================================================================================================
 // wave B: the cubes
 // ================================================================================================
-template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8>
+template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8, bool GW>
 DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, const bool valid) {
-    using LL = Lds2<NC, ROLL, CC8>;
+    using LL = Lds2<NC, ROLL, CC8, !GW>;
     // cube<->cube manifold points kept (Stack): 4 = the extremes along the diagonals of the reference face; CC8 (lcr_config.cc_points = 8,
     // as many as MuJoCo's mjc_BoxBox may return): also the extremes along its two axes -- narrows deviation D5
     constexpr int NCC = CC8 ? 8 : 4;
@@ -1548,13 +1554,12 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
 
-        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.
-        //  - no finger sphere on a cube (the usual case; this wave has slack before barrier 1): Wm = (M + hD)^-1 L is built here and parked in
-        //    the idle LDS place of the rows of slots 0, 1; wave A computes qacc = Wm y itself at the end of its sweeps, no round trip;
-        //  - else (this wave is the busier one): only the second factor is built; y visits this wave at the end (barrier Y) and qacc goes back.
+        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.  Wm = (M + hD)^-1 L is
+        // built here and handed to wave A, which computes qacc = Wm y itself at the end of its sweeps: no round trip, and neither factor outlives this block.
         Chol6 CL2;
+        float Lf[6][6];
         {
-            float Lf[6][6], Mm[6][6];
+            float Mm[6][6];
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -1569,20 +1574,31 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     Mm[i][j] = m + (i == j ? H * (DAMPING + KV) : 0.f);
                 }
             chol6(Mm, CL2);
-            if (!c01) {
-                float *pw = lds + LL::G0 + lane;
+        }
+        // Wm -> wave A: in the idle LDS place of the rows of slots 0, 1; with a finger on a cube those rows are in use and Wm goes to its own LDS place
+        // (build for one wave per SIMD) or, column-major, to this lane's global scratch record (144 B; the build for two waves per SIMD has no LDS left,
+        // and keeping the factors beyond this point would cost this wave the registers it does not have at the 256-register cap)
+        auto build_wm = [&]() {
+            float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
+            float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 36;
 #pragma unroll
-                for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of Wm
-                    float col[6];
+            for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of Wm
+                float col[6];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) col[i] = i < j ? 0.f : Lf[i][j];
-                    fsub(CL2, col);
-                    bsub(CL2, col);
+                for (int i = 0; i < 6; i++) col[i] = i < j ? 0.f : Lf[i][j];
+                fsub(CL2, col);
+                bsub(CL2, col);
+                if (GW && c01) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) gw[j * 6 + i] = col[i];
+                } else {
 #pragma unroll
                     for (int i = 0; i < 6; i++) pw[(i * 6 + j) * 64] = col[i];
                 }
             }
-        }
+            if (GW && c01) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
+        };
+        build_wm();   // (measured: moving this into the second sweep, where this wave waits for wave A, is slower -- 80 more live registers)
         if (prof) pf_mark = clock64();
         wg_barrier();   // B1: wave A has set up its rows and decided whether this substep is coupled
         if (prof) pf_wait += clock64() - pf_mark;
@@ -1932,23 +1948,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
         publish_pose();   // (this wave finishes its sweeps first: the integration is off the critical path)
-        if (c01) {        // y from wave A -> qacc
-            if (prof) pf_mark = clock64();
-            wg_barrier();   // Y
-            if (prof) pf_wait += clock64() - pf_mark;
-            float rhs[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                float s = rcp(CL.id[i]) * lds[LL::LFAC0 + lane + i * 64];  // L_ii y_i
-#pragma unroll
-                for (int k = 0; k < i; k++) s = fmaf(CL.L[i][k], lds[LL::LFAC0 + lane + k * 64], s);
-                rhs[i] = s;
-            }
-            fsub(CL2, rhs);
-            bsub(CL2, rhs);
-#pragma unroll
-            for (int j = 0; j < 6; j++) xacc[j * 64] = rhs[j];
-        }
         // (the implicitfast solve qacc = Wm y is wave A's: it has y; this wave reads qacc after barrier E)
         if (prof) pf_mark = clock64();
         wg_barrier();   // E
@@ -2004,19 +2003,20 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool WALLS, bool ROLL, int OCC, bool CC8>
 __global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[Lds2<NC, ROLL, CC8>::TOTAL];
+    constexpr bool GW = OCC == 2 || CC8;   // where Wm travels in substeps with a finger on a cube: global scratch record (true) or its own LDS place
+    __shared__ float lds[Lds2<NC, ROLL, CC8, !GW>::TOTAL];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
     const int e = valid ? e_raw : P.n - 1;   // tail lanes shadow the last env, their stores are masked
 #if defined(LCR2_ONLY_ARM)        // (register-budget study only: one role compiled alone; such a kernel must not be launched)
-    arm_program<NC, EE, WALLS, ROLL, CC8>(P, action, lds, lane, e, valid);
+    arm_program<NC, EE, WALLS, ROLL, CC8, GW>(P, action, lds, lane, e, valid);
 #elif defined(LCR2_ONLY_CUBE)
-    cube_program<NC, EE, WALLS, ROLL, CC8>(P, lds, lane, e, valid);
+    cube_program<NC, EE, WALLS, ROLL, CC8, GW>(P, lds, lane, e, valid);
 #else
-    if (wave == 0) arm_program<NC, EE, WALLS, ROLL, CC8>(P, action, lds, lane, e, valid);
-    else cube_program<NC, EE, WALLS, ROLL, CC8>(P, lds, lane, e, valid);
+    if (wave == 0) arm_program<NC, EE, WALLS, ROLL, CC8, GW>(P, action, lds, lane, e, valid);
+    else cube_program<NC, EE, WALLS, ROLL, CC8, GW>(P, lds, lane, e, valid);
 #endif
 }
 

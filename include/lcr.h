@@ -96,8 +96,9 @@ typedef struct lcr_config {
                                   rolling rows (8-12 % faster).  lcr_config_default: 6 for PushCubeLoop (coefficient 1.5 m) and
                                   StackTwoCubes (light cubes), 4 for the other tasks (effect below the parity tolerance: deviation D4,
                                   DESIGN.md).  0 = the task's default */
-    int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by shard size (two cooperating waves per 64 envs while the shard's
-                                  waves fit the GPU's SIMDs one each -- <= 32 768 envs on an MI355X -- else one wave per 64 envs); 1 = one wave
+    int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by shard size and task (two cooperating waves per 64 envs while the shard's
+                                  waves fit the GPU's SIMDs one each -- <= 32 768 envs on an MI355X; larger shards: two cooperating waves, two per
+                                  SIMD, for ReachCube, where that is the faster kernel, else one wave per 64 envs); 1 = one wave
                                   per 64 envs always; 2 = two cooperating waves always.  The families regroup the same arithmetic and agree to
                                   fp32 rounding (~1e-7 per control step), not bit for bit: a job that must give identical bits under
                                   different shardings pins 1 or 2 (results are bit-identical across shardings within a family). */
