@@ -6,12 +6,12 @@
 // leaves half the SIMDs without a wave.  Here a workgroup is two waves that share the 64 envs -- lane l of both waves is env l:
 //
 //   wave A ("arm")   forward kinematics, joint-space inertia + Cholesky factor L (-> wave B), y = L^-1 tau, the contact rows that touch
-//                    only the arm (finger spheres <-> floor, arm-link proxies: slots 2-4; joint limits) and their sweeps, qacc = Wm y,
+//                    only the arm (finger spheres <-> floor, arm-link proxies: slots 2-4; joint limits) and their sweeps, qacc = G^-T (V y),
 //                    integration of the arm; the action head (incl. the IK loop of ee mode) and the fused tail (reward, termination,
 //                    TimeLimit, auto-reset, write-back);
 //   wave B ("cubes") its own forward kinematics, RNE bias + actuation + damping = tau (-> wave A), the finger spheres <-> cube slots 0, 1
 //                    (it has the cube state, the kinematics and L), floor <-> cube / cube <-> cube / rail contacts, their rows and
-//                    sweeps, Wm = (M + hD)^-1 L (-> wave A), integration of the cubes and of its copy of the arm state.
+//                    sweeps, the implicit-damping factor G ((M + hD) = G G^T) and V = G^-1 L (-> wave A), integration of the cubes and of its copy of the arm state.
 //
 // The two constraint sets touch disjoint unknowns (the arm's scaled acceleration y vs the cube accelerations ca / cal) unless a finger sphere
 // or a gripper-body proxy touches a cube, so their Gauss-Seidel sweeps are INDEPENDENT chains in almost every (workgroup, substep) pair and
@@ -20,8 +20,8 @@
 // sweep is serialised in exactly that order: y visits wave B between the limit rows and slots 2-4, the cube accelerations visit wave A for
 // slot 4.  Barriers per substep (uncoupled: five):
 //
-//   A: FK, M, L -> LDS          -X-  y0 = L^-1 tau; pose <- LDS  -X2-  rows of slots 2-4, limits | cube4  -B1-  sweeps: limits, 2-4      | qacc = Wm y -> LDS  -E-  integrate arm
-//   B: FK, tau -> LDS           -X-  L <- LDS                    -X2-  slots 0, 1; Wm -> LDS; cube rows | c01 -B1-  sweeps: floor, cc, rails | integrate cubes, pose -> LDS  -E-  integrate arm copy
+//   A: FK, M, L -> LDS          -X-  y0 = L^-1 tau; pose <- LDS  -X2-  rows of slots 2-4, limits | cube4  -B1-  sweeps: limits, 2-4      | qacc = G^-T V y -> LDS  -E-  integrate arm
+//   B: FK, tau -> LDS           -X-  L <- LDS                    -X2-  slots 0, 1; V, G -> LDS; cube rows | c01 -B1-  sweeps: floor, cc, rails | integrate cubes, pose -> LDS  -E-  integrate arm copy
 //
 // Every LDS hand-over and the barrier that orders it is listed in DESIGN.md section 3.1b; the rule when changing this file: a place may be
 // rewritten only after a barrier that its reader has also passed AFTER reading (tests/test_gpu_parity.py::test_kernel_families_agree_and_are_race_free
@@ -50,7 +50,7 @@ namespace {
 //  FLAG: 1 field                [0] c01 (B -> A), [1] cube4 (A -> B) at barrier 1; after the last substep: do_reset per lane (A -> B)
 //  PARK: 16 fields              aref / inv of the finger<->floor slots 2, 3 (wave A only; read once per sweep as 16-B vectors)
 //  hand-overs that reuse these areas in phases where they are idle: ctrl + post-IK q (A -> B, once) and tau (B -> A at barrier X) in the
-//  rows of slot 0; the Cholesky factor L (A -> B at X, read before X2) in the rows of slots 3, 4; Wm (B -> A at barrier 1) in the rows of
+//  rows of slot 0; the Cholesky factor L (A -> B at X, read before X2) in the rows of slots 3, 4; V and G (B -> A at barrier 1) in the rows of
 //  slots 0, 1 when those are unused (a finger on a cube: WM0, or a global scratch record where LDS is full -- struct comment); the warm-start share of
 //  slots 0, 1 in y (B -> A) and of slot 4 in the cube accelerations (A -> B) in POSE[0..5] / POSE[6..] at barrier 1; the cube accelerations
 //  of cube4 sweeps in POSE
@@ -64,10 +64,10 @@ template <int NC, bool ROLL, bool CC8 = false, bool WMLDS = false> struct Lds2 {
     static constexpr int PARK0 = FLAG0 + 64;                 // aref[4] | inv[4] of the finger<->floor slots 2, 3 as 16-B vectors: [slot][aref|inv][lane][4]
     static constexpr bool HAS_PARK = !CC8;                   // (eight cube<->cube records: no room, the constants stay in wave A's registers --
                                                              //  that variant runs one wave per SIMD: 2 x 79.7 KiB per CU)
-    // Wm = (M + hD)^-1 L in a substep with a finger on a cube (the rows of slots 0, 1 are in use then): the one-wave-per-SIMD build has LDS to spare
-    // (two workgroups per CU) and keeps a 36-field place for it; the two-waves-per-SIMD build and CC8 go through a global scratch record instead
+    // V = G^-1 L and G ((M + hD) = G G^T) in a substep with a finger on a cube (the rows of slots 0, 1 are in use then): the one-wave-per-SIMD build has LDS to spare
+    // (two workgroups per CU) and keeps a 42-field place for them; the two-waves-per-SIMD build and CC8 go through a global scratch record instead
     static constexpr int WM0 = PARK0 + (HAS_PARK ? 2 * 2 * 64 * 4 : 0);
-    static constexpr int TOTAL = WM0 + (WMLDS ? 36 * 64 : 0);
+    static constexpr int TOTAL = WM0 + (WMLDS ? 42 * 64 : 0);
     // hand-over of the Cholesky factor (21 + 6 floats per lane, wave B -> wave A at barrier X): aliases the g rows of slots 3 and 4,
     // which wave A writes only after it has read the factor
     static constexpr int LFAC0 = G0 + (ROLL ? 16 : 12) * LDS_ROW;
@@ -824,31 +824,32 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
             DGtot.choice += DG.choice * (unsigned)(2 * sub + 1);
         }
 
-        // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y, i.e. qacc = Wm y with wave B's Wm = (M + hD)^-1 L ----
+        // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y, i.e. qacc = G^-T (V y) with wave B's G (G G^T = M + hD) and V = G^-1 L ----
         float qacc[6];
-        if (!(GW && c01)) {   // wave B parked Wm = (M + hD)^-1 L before barrier 1: in the idle LDS place of the rows of slots 0, 1, or (a finger on a cube) in its own
+        // wave B left V = G^-1 L and G ((M + hD) = G G^T) before barrier 1: in the idle LDS rows of slots 0, 1, or (a finger on a cube) in their own LDS
+        // place / this lane's global scratch record.  qacc = G^-T (V y).
+        auto final_solve = [&](auto glob_tag) {
+            constexpr bool GLOB = decltype(glob_tag)::value;
+            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
+            const float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
+            auto get = [&](int f) -> float { return GLOB ? gw[f] : pw[f * 64]; };
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                float s = 0.f;
+                float sacc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6; k++) s = fmaf(pw[(i * 6 + k) * 64], y[k], s);
-                qacc[i] = s;
+                for (int k = 0; k <= i; k++) sacc = fmaf(get(i * (i + 1) / 2 + k), y[k], sacc);
+                qacc[i] = sacc;
             }
-        } else {              // ... or, column-major, in this lane's global scratch record (same sums in the same order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 36;
-            float wm[36];
 #pragma unroll
-            for (int k = 0; k < 36; k++) wm[k] = gw[k];
+            for (int i = 5; i >= 0; i--) {   // back substitution with G^T
+                float sacc = qacc[i];
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < 6; k++) s = fmaf(wm[k * 6 + i], y[k], s);
-                qacc[i] = s;
+                for (int k = i + 1; k < 6; k++) sacc = fmaf(-get(21 + k * (k - 1) / 2 + i), qacc[k], sacc);
+                qacc[i] = sacc * get(36 + i);
             }
-        }
+        };
+        if (GW && c01) final_solve(std::true_type{}); else final_solve(std::false_type{});
 #pragma unroll
         for (int j = 0; j < 6; j++) xacc[j * 64] = qacc[j];   // wave B integrates its copy of the arm state with the same values
         if (prof) pf_mark = clock64();
@@ -1554,8 +1555,8 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
 
-        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.  Wm = (M + hD)^-1 L is
-        // built here and handed to wave A, which computes qacc = Wm y itself at the end of its sweeps: no round trip, and neither factor outlives this block.
+        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.  What wave A needs for it is
+        // built here and handed over; wave A finishes the solve itself at the end of its sweeps: no round trip, and neither factor outlives this block.
         Chol6 CL2;
         float Lf[6][6];
         {
@@ -1575,30 +1576,34 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 }
             chol6(Mm, CL2);
         }
-        // Wm -> wave A: in the idle LDS place of the rows of slots 0, 1; with a finger on a cube those rows are in use and Wm goes to its own LDS place
-        // (build for one wave per SIMD) or, column-major, to this lane's global scratch record (144 B; the build for two waves per SIMD has no LDS left,
-        // and keeping the factors beyond this point would cost this wave the registers it does not have at the 256-register cap)
-        auto build_wm = [&]() {
+        // (M + hD) = G G^T.  Wave A needs qacc = (M + hD)^-1 L y = G^-T (V y) with V = G^-1 L (lower triangular): this wave hands over V (21) and G (15 + 6
+        // inverse diagonals) -- six forward substitutions on columns that start with zeros, a quarter of the work of Wm = G^-T V -- and wave A finishes with 21 + 21
+        // multiply-adds.  Place (42 fields: V row-major, G's strict lower part row-major, G's inverse diagonal): the idle LDS rows of slots 0, 1; with a finger on a
+        // cube those rows are in use and the record goes to its own LDS place (build for one wave per SIMD) or to this lane's global scratch record (168 B; the build for
+        // two waves per SIMD has no LDS left, and keeping the factors for a solve after the sweeps would cost this wave registers it does not have at the 256-register cap)
+        auto hand_over = [&](auto glob_tag) {
+            constexpr bool GLOB = decltype(glob_tag)::value;
             float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
-            float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 36;
+            float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
+            auto put = [&](int f, float v) { if (GLOB) gw[f] = v; else pw[f * 64] = v; };
 #pragma unroll
-            for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of Wm
+            for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of V
                 float col[6];
 #pragma unroll
                 for (int i = 0; i < 6; i++) col[i] = i < j ? 0.f : Lf[i][j];
                 fsub(CL2, col);
-                bsub(CL2, col);
-                if (GW && c01) {
 #pragma unroll
-                    for (int i = 0; i < 6; i++) gw[j * 6 + i] = col[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) pw[(i * 6 + j) * 64] = col[i];
-                }
+                for (int i = j; i < 6; i++) put(i * (i + 1) / 2 + j, col[i]);
             }
-            if (GW && c01) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
+#pragma unroll
+            for (int i = 1; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < i; j++) put(21 + i * (i - 1) / 2 + j, CL2.L[i][j]);
+#pragma unroll
+            for (int i = 0; i < 6; i++) put(36 + i, CL2.id[i]);
+            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
         };
-        build_wm();   // (measured: moving this into the second sweep, where this wave waits for wave A, is slower -- 80 more live registers)
+        if (GW && c01) hand_over(std::true_type{}); else hand_over(std::false_type{});
         if (prof) pf_mark = clock64();
         wg_barrier();   // B1: wave A has set up its rows and decided whether this substep is coupled
         if (prof) pf_wait += clock64() - pf_mark;
@@ -1948,7 +1953,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
         publish_pose();   // (this wave finishes its sweeps first: the integration is off the critical path)
-        // (the implicitfast solve qacc = Wm y is wave A's: it has y; this wave reads qacc after barrier E)
+        // (the implicitfast solve is wave A's: it has y; this wave reads qacc after barrier E)
         if (prof) pf_mark = clock64();
         wg_barrier();   // E
         if (prof) pf_wait += clock64() - pf_mark;
@@ -2003,7 +2008,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool WALLS, bool ROLL, int OCC, bool CC8>
 __global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const float *__restrict__ action) {
-    constexpr bool GW = OCC == 2 || CC8;   // where Wm travels in substeps with a finger on a cube: global scratch record (true) or its own LDS place
+    constexpr bool GW = OCC == 2 || CC8;   // where V and G travel in substeps with a finger on a cube: global scratch record (true) or their own LDS place
     __shared__ float lds[Lds2<NC, ROLL, CC8, !GW>::TOTAL];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
