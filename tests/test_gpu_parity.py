@@ -27,7 +27,7 @@ MAX_DQ, MAX_DV = util.MAX_DQ, util.MAX_DV
 @pytest.fixture(autouse=True, params=["auto", "single"])
 def kernel_family(request, monkeypatch):
     """every test of this module runs against both step-kernel families: "auto" = what lcr_create dispatches for the shard size (test sizes:
-    the two-cooperating-waves kernels of lcr_kernels2.hip; >= 65 536 envs: the one-wave kernels) and "single" = the one-wave-per-64-envs
+    the two-cooperating-waves kernels of lcr_kernels2.hip; larger shards: test_default_dispatch_of_the_step_kernel_families) and "single" = the one-wave-per-64-envs
     kernels of lcr_kernels.hip forced at every size (LCR_STEP_KERNEL, read by lcr_create)"""
     if request.param != "auto":
         monkeypatch.setenv("LCR_STEP_KERNEL", request.param)
@@ -900,6 +900,30 @@ def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mod
     assert worst > 0.0          # (the families really are different kernels: identical bits would mean the override did not take)
     for sim in sims.values():
         sim.close()
+
+
+def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, monkeypatch):
+    """lcr_create's choice (lcr_config.step_kernel = 0, no override): two cooperating waves per 64 envs while the shard's waves fit the SIMDs one
+    each; above that the two-waves-per-SIMD build for ReachCube (the bench default), the one-wave kernels for the other tasks; the converged
+    solver mode always runs the one-wave kernels.  (MI355X: 256 CUs -> the boundary is 32 768 envs.)"""
+    import torch
+    from gym_lowcostrobot_amd import VecSim
+
+    if kernel_family != "auto":
+        pytest.skip("the default dispatch is what is tested")
+    monkeypatch.delenv("LCR_STEP_KERNEL", raising=False)
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    fit = simds // 2 * 64                                  # largest shard with one wave per SIMD
+    expect = [("reach", fit, 1), ("reach", 2 * fit, 2), ("reach", fit + 64, 2), ("push", fit, 1), ("push", 2 * fit, 0), ("stack", fit, 1), ("stack", fit + 64, 0),
+              ("pick_place", 2 * fit, 0), ("push_loop", fit, 1), ("push_loop", 2 * fit, 0)]
+    for task, n, fam in expect:
+        sim = VecSim(task, n)
+        got = hip_lib.lcr_step_kernel_family(sim.handle)
+        assert got == fam, (task, n, got, fam, sim.step_kernel_family)
+        sim.close()
+    sim = VecSim("reach", 2 * fit, pgs_iters=-1)
+    assert hip_lib.lcr_step_kernel_family(sim.handle) == 0
+    sim.close()
 
 
 def test_zz_outlier_census(hip_lib):
