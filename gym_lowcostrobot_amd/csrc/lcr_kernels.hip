@@ -527,8 +527,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             dist = bestd;
             slot_cube[sp] = cidx;
         } else if (s < 4) {
-            dist = sph[sp].z - srad[sp];
-            pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
+            const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
+            dist = sph[sp].z - srad[sp] - htop;
+            pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
+            sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
         } else if (P.arm_collision) {
             // arm-link proxies (D3): both ends of link_3, link_4 motor, link_5 motor body, link_6 jaw root.  One contact: the
             // deepest candidate in the order proxy 0 floor, proxy 1 floor, proxy 2 floor, proxy 3 floor, proxy 3 cubes, proxy 4

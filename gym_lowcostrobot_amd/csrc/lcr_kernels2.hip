@@ -384,8 +384,10 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 dist = bestd;
                 slot_cube[sp] = cidx;
             } else if (s < 4) {
-                dist = sph[sp].z - srad[sp];
-                pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
+                const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
+                dist = sph[sp].z - srad[sp] - htop;
+                pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
+                sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
             } else if (P.arm_collision) {
                 const int plink[5] = {2, 2, 3, 4, 5};
                 const float px[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, py[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, pz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};

@@ -58,6 +58,15 @@ DEV float impedance(float dist, float d0, float dw, float inv_width) {
 // outer rectangle of the rails (inner faces + the boxes' thickness).  A cube that was knocked over a rail lies outside the pen untouched, as next to the
 // reference's wall boxes, instead of being "deep inside" a half-space (which ejected it at up to 1 200 m/s: 0.5 % of the env-states of a random-policy run
 // had the cube out there).  The penetration a rail can see is thereby bounded by thickness + half a cube diagonal.
+// (D7) finger spheres ride over the rails: above a rail box's footprint the "floor" a finger sphere meets is the box's top face (push_cube_loop.xml:45-48:
+// left / right walls |x| in [0.115, 0.135], y in [0.08, 0.19]; top / bottom walls |x| < 0.125, y in [0.08, 0.10] / [0.17, 0.19]; top at z = 0.012).
+// The boxes' side faces are not modelled for the fingers: a finger that comes in low is lifted onto the rail instead of being stopped by it.
+DEV float rail_top(float x, float y) {
+    const bool in_y = y > WALL_Y0 - WALL_THICK && y < WALL_Y1 + WALL_THICK;
+    const bool side = fabsf(x) > WALL_X && fabsf(x) < WALL_X + WALL_THICK && in_y;
+    const bool ends = fabsf(x) < WALL_X + 0.5f * WALL_THICK && in_y && (y < WALL_Y0 || y > WALL_Y1);
+    return (side || ends) ? WALL_TOP : 0.f;
+}
 DEV bool cube_in_pen(f3 c) {
     return fabsf(c.x) < WALL_X + WALL_THICK && c.y > WALL_Y0 - WALL_THICK && c.y < WALL_Y1 + WALL_THICK;
 }

@@ -508,18 +508,26 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) { /* 
     ct->mu = K->mu_finger_cube; ct->solimp = SOLIMP_FINGER_CUBE;
     return 1;
 }
-static int collide_plane_sphere_g(const real *centre, double radius, int link, contact_t *ct) {
-    real dist = centre[2] - (real)radius;
+/* (D7) height of the surface a finger sphere meets at (x, y): the top face of a rail box above its footprint (push_cube_loop.xml:45-48), else the floor */
+static real rail_top(real x, real y) {
+    real ax = x < 0 ? -x : x;
+    int in_y = y > (real)WALL_Y0 - (real)WALL_THICK && y < (real)WALL_Y1 + (real)WALL_THICK;
+    int side = ax > (real)WALL_X && ax < (real)WALL_X + (real)WALL_THICK && in_y;
+    int ends = ax < (real)WALL_X + (real)0.5 * (real)WALL_THICK && in_y && (y < (real)WALL_Y0 || y > (real)WALL_Y1);
+    return (side || ends) ? (real)WALL_TOP : (real)0;
+}
+static int collide_plane_sphere_g(const real *centre, double radius, int link, real htop, contact_t *ct) {
+    real dist = centre[2] - (real)radius - htop;
     if (!(dist < 0)) return 0;
-    v3set(ct->pos, centre[0], centre[1], dist * (real)0.5);
+    v3set(ct->pos, centre[0], centre[1], htop + dist * (real)0.5);
     real nz[3] = {0, 0, 1};
     make_frame(ct->frame, nz);
     ct->b1 = -1; ct->b2 = link; ct->dist = dist;
-    ct->sel = 0;
+    ct->sel = htop > 0 ? 1 : 0;   /* which surface: part of the decision signature */
     return 1;
 }
-static int collide_plane_sphere(const kin_t *K, int s, contact_t *ct) {
-    if (!collide_plane_sphere_g(K->sph[s], SPH_RAD[s], SPH_LINK[s], ct)) return 0;
+static int collide_plane_sphere(const kin_t *K, int s, int walls, contact_t *ct) {
+    if (!collide_plane_sphere_g(K->sph[s], SPH_RAD[s], SPH_LINK[s], walls ? rail_top(K->sph[s][0], K->sph[s][1]) : (real)0, ct)) return 0;
     ct->slot = 14 + s;
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
     ct->dim = 4;
@@ -531,7 +539,7 @@ static int collide_link_group(const kin_t *K, int g, int ngroups, contact_t *out
     for (int s = 0; s < NLPX; s++) {
         if ((ngroups == 3 ? LPX_GROUP3[s] : LPX_GROUP[s]) != g) continue;
         contact_t tmp;
-        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], &tmp)) {
+        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], (real)0, &tmp)) {
             tmp.mu = MU_LINK_FLOOR; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 3;
             tmp.sel = 64 * (s + 1);
             if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
@@ -876,7 +884,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         if (have) con[ncon++] = cand[0];
     }
     for (int s = 0; s < NSPH; s++)
-        if (collide_plane_sphere(&K, s, con + ncon)) ncon++;
+        if (collide_plane_sphere(&K, s, T->walls, con + ncon)) ncon++;
     if (P->arm_collision)
         for (int g = 0; g < (P->proxy_groups == 3 ? 3 : 1); g++)
             if (collide_link_group(&K, g, P->proxy_groups == 3 ? 3 : 1, con + ncon)) ncon++;

@@ -490,6 +490,35 @@ def test_push_loop_parity(hip_lib, monkeypatch, carry):
     sim.close()
 
 
+@pytest.mark.parametrize("carry", [False, True], ids=["cold", "carry"])
+def test_push_loop_fingers_over_the_rails(hip_lib, monkeypatch, carry):
+    """(D7) above a rail's footprint the finger spheres meet the rail's top face (z = 0.012): ee-mode envs steer their tips to points below the
+    surface inside the pen, over each of the four rails and across their edges; kernel vs oracle every step, and the tips over a rail do end higher"""
+    from oracle import orc
+
+    monkeypatch.setattr(util, "CARRY_DEFAULT", carry)
+    n = 256
+    sim, o = util.make_pair("push_loop", n, auto_reset=False, max_episode_steps=0, action_mode="ee")
+    o.reset(seeds=np.arange(n)); sim.reset(seeds=np.arange(n))
+    o.qpos[:, 6:9] = [0.09, 0.12, 0.0149]                       # cube out of the way
+    rng = np.random.default_rng(12)
+    tx = rng.uniform(-0.14, 0.14, n); ty = rng.uniform(0.07, 0.20, n)
+    tx[:64] = rng.uniform(-0.05, 0.05, 64); ty[:64] = rng.uniform(0.171, 0.189, 64)      # over the far rail
+    tx[64:128] = rng.uniform(-0.05, 0.05, 64); ty[64:128] = rng.uniform(0.12, 0.15, 64)  # inside the pen
+    k = sim.action_dim
+    for t in range(30):
+        a = np.zeros((n, k), np.float32)
+        for e in range(n):
+            _, site, _ = orc.fk(o.qpos[e, :6])
+            a[e, :3] = np.clip(np.array([tx[e] - site[0], ty[e] - site[1], -0.02 - site[2]]) / 0.02, -1, 1)
+        dq, dv, ok, st = util.parity_step(sim, o, a, 2e-5, 4e-3, where=("rail_top", t))
+        assert ok.mean() >= 0.99, (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
+    z = np.array([orc.fk(o.qpos[e, :6])[2][:, 2].min() for e in range(128)])
+    assert np.median(z[:64]) - np.median(z[64:128]) > 0.006, (np.median(z[:64]), np.median(z[64:128]))
+    assert (((o.active_mask >> 14) & 3) != 0).mean() > 0.3      # the finger<->floor slots are in use
+    sim.close()
+
+
 def test_sharded_vecsim_single_process(hip_lib):
     """several handles in one process (here: two shards on the same GPU) reproduce the unsharded batch bit for bit"""
     from gym_lowcostrobot_amd import VecSim

@@ -369,6 +369,26 @@ def test_loop_cube_outside_the_rails_is_left_alone():
     assert o.qpos[2, 6] < 0.11 and np.abs(o.qvel[2, 6:9]).max() < 0.5                                          # straddling: back inside, no ejection
 
 
+def test_loop_finger_rides_over_a_rail():
+    """(D7) above a rail's footprint a finger sphere meets the rail's top face (z = 0.012) instead of the floor: the same arm pose pressed down
+    over the far rail ends ~12 mm higher than next to it"""
+    from oracle import orc as _o
+    tips = []
+    for ytgt in (0.135, 0.18):            # inside the pen / over the bottom rail (y in [0.17, 0.19])
+        o = orc.Oracle("push_loop", 1, auto_reset=0, max_episode_steps=0, action_mode=1)
+        o.reset(seeds=[0])
+        o.qpos[0, 6:9] = [0.09, 0.12, 0.0149]          # cube out of the way
+        for _ in range(40):
+            _, site, sph = _o.fk(o.qpos[0, :6])
+            d = np.array([0.0 - site[0], ytgt - site[1], -0.02 - site[2]])     # drive the tip towards a point below the surface
+            a = np.zeros((1, o.action_dim), np.float32); a[0, :3] = np.clip(d / 0.02, -1, 1)
+            o.step(a)
+        _, site, sph = _o.fk(o.qpos[0, :6])
+        assert abs(sph[:, 1].mean() - ytgt) < 0.012, sph
+        tips.append(sph[:, 2].min())
+    assert tips[1] - tips[0] > 0.006, tips      # over the rail the finger spheres end clearly higher (soft finger contact: not the full 12 mm)
+
+
 # ---------------------------------------------------------------- analytic known answers of the restated MuJoCo pipeline
 def test_kat_free_fall_semi_implicit_euler():
     """no contact: v_n = -g h n and z_n = z0 - g h^2 n(n+1)/2 exactly (velocity first, then position)"""
