@@ -494,6 +494,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool link_on_cube = false;       // slot 4: this lane's contact is against a cube (else the floor)
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
     int link_bi = 0;             // slot 4: which proxy
+    float link_htop = 0.f;       // slot 4 on the floor: height of the surface under the proxy (PushCubeLoop: a rail's top face, D7)
     int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
@@ -552,8 +553,13 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int i = 0; i < 5; i++) {
                 const int L = plink[i];
                 const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
-                const float df = cz - pr[i];
-                if (df < bestd) { bestd = df; bi = i; oncube = false; }
+                float df = cz - pr[i], hi = 0.f;
+                if constexpr (WALLS) {   // (D7) above a rail's footprint the surface is the rail's top face
+                    const f3 cw_ = local_point(F, L, px[i], py[i], pz[i]);
+                    hi = rail_top(cw_.x, cw_.y);
+                    df -= hi;
+                }
+                if (df < bestd) { bestd = df; bi = i; oncube = false; link_htop = hi; }
                 if (i >= 3 && wave_near) {
                     const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
 #pragma unroll
@@ -564,7 +570,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
             link_bi = bi;
-            if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
+            if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = link_htop > 0.f ? 1 : 0; }
             sel += 64 * (bi + 1);
             dist = bestd;
             link_on_cube = oncube;
@@ -595,7 +601,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
                     cb = f2v{m, m} * ci + cb;
                 }
-                if (!oncube) pos = mk(cb.x, cb.y, 0.5f * dist);
+                if (!oncube) pos = mk(cb.x, cb.y, link_htop + 0.5f * dist);
             }
             if (may_cube) make_frame(n, T.t1, T.t2);   // (for n = +z this is the floor frame t1 = +y, t2 = -x)
             // joints that move the contact point: the finger spheres sit on link_5 / link_6, the proxies on link_3..link_6

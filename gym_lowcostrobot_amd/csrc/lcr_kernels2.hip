@@ -351,6 +351,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         bool slot_any[NAS];
         bool link_on_cube = false;
         int link_nj = 3, link_bi = 0;
+        float link_htop = 0.f;   // slot 4 on the floor: height of the surface under the proxy (PushCubeLoop: a rail's top face, D7)
         int slot_cube[3] = {0, 0, 0};
         {
         const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
@@ -405,8 +406,13 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 for (int i = 0; i < 5; i++) {
                     const int L = plink[i];
                     const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
-                    const float df = cz - pr[i];
-                    if (df < bestd) { bestd = df; bi = i; oncube = false; }
+                    float df = cz - pr[i], hi = 0.f;
+                    if constexpr (WALLS) {   // (D7) above a rail's footprint the surface is the rail's top face
+                        const f3 cw_ = local_point(F, L, px[i], py[i], pz[i]);
+                        hi = rail_top(cw_.x, cw_.y);
+                        df -= hi;
+                    }
+                    if (df < bestd) { bestd = df; bi = i; oncube = false; link_htop = hi; }
                     if (i >= 3 && wave_near) {
                         const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
 #pragma unroll
@@ -417,7 +423,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                     }
                 }
                 link_bi = bi;
-                if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
+                if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = link_htop > 0.f ? 1 : 0; }
                 sel += 64 * (bi + 1);
                 dist = bestd;
                 link_on_cube = oncube;
@@ -450,7 +456,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                         const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
                         cb = f2v{m, m} * ci + cb;
                     }
-                    if (!oncube) pos = mk(cb.x, cb.y, 0.5f * dist);
+                    if (!oncube) pos = mk(cb.x, cb.y, link_htop + 0.5f * dist);
                 }
                 if (may_cube) make_frame(n, T.t1, T.t2);
                 auto joint_on = [&](int j) -> bool {

@@ -534,14 +534,14 @@ static int collide_plane_sphere(const kin_t *K, int s, int walls, contact_t *ct)
     return 1;
 }
 /* arm-link proxies (group g = 0): the deepest penetration among them against the floor and (gripper body) the cubes */
-static int collide_link_group(const kin_t *K, int g, int ngroups, contact_t *out) {
+static int collide_link_group(const kin_t *K, int g, int ngroups, int walls, contact_t *out) {
     int have = 0;
     for (int s = 0; s < NLPX; s++) {
         if ((ngroups == 3 ? LPX_GROUP3[s] : LPX_GROUP[s]) != g) continue;
         contact_t tmp;
-        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], (real)0, &tmp)) {
+        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], walls ? rail_top(K->lpx[s][0], K->lpx[s][1]) : (real)0, &tmp)) {   /* (D7: rail tops) */
             tmp.mu = MU_LINK_FLOOR; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 3;
-            tmp.sel = 64 * (s + 1);
+            tmp.sel += 64 * (s + 1);
             if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
         }
         if (LPX_CUBE[s])
@@ -887,7 +887,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         if (collide_plane_sphere(&K, s, T->walls, con + ncon)) ncon++;
     if (P->arm_collision)
         for (int g = 0; g < (P->proxy_groups == 3 ? 3 : 1); g++)
-            if (collide_link_group(&K, g, P->proxy_groups == 3 ? 3 : 1, con + ncon)) ncon++;
+            if (collide_link_group(&K, g, P->proxy_groups == 3 ? 3 : 1, T->walls, con + ncon)) ncon++;
 
     /* -- constraint rows: joint limits first, then contacts (n, t1, t2 [, torsion]) */
     real J[MAX_ROWS * ORC_NV_MAX], aref[MAX_ROWS], Rr[MAX_ROWS];
