@@ -303,7 +303,10 @@ def main():
                 "algorithmic_bytes_per_env_step": alg_bytes,
                 "traffic_note": "traffic counts solver state the SURVEY.md 8(d) formula does not: the constraint forces carried from one control step to the "
                                 "next (warm start as MuJoCo's qacc_warmstart, DESIGN.md section 4 D1) are read and written once per env-step: "
-                                "2 x 4 B x 42 (one cube) .. 84 (Stack) floats",
+                                "2 x 4 B x 42 (one cube) .. 84 (Stack) floats"
+                                + ("; the two-waves-per-SIMD build of the two-wave kernels also spills ~30 registers of its cube wave at the 256-register cap "
+                                   "(scratch: written once and read once per step, ~0.25 KB per env-step) and hands 42 floats per env from the cube wave to the arm wave "
+                                   "through a global record in substeps with a finger on a cube" if "two waves per SIMD" in sim.step_kernel_family else ""),
                 "note": "state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick",
             },
             "state_finite": finite,
