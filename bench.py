@@ -42,6 +42,18 @@ CONFIGS = {
     4: ("PickPlaceCube-v0", 32768, "state"),     # 131 072 envs over 4 GPUs, ee-IK action mode
     5: ("StackTwoCubes-v0", 32768, "both"),      # 262 144 envs over 8 GPUs, state + two ray-cast 240x320x3 frames
 }
+# The step-kernel family is a property of the JOB (lcr_config.global_envs / step_kernel, include/lcr.h), never of the shard size, so that every sharding of a
+# job gives identical bits.  BASELINE's sharded jobs (configs 4, 5) are cut into 32 768-env shards, where the two-cooperating-waves family is the faster
+# one: those jobs PIN it; a run on fewer GPUs than the job names is one (or some) of its shards and makes the same choice.
+JOB = {4: {"global_envs": 131072, "step_kernel": "coop"}, 5: {"global_envs": 262144, "step_kernel": "coop"}}
+
+
+def job_kwargs(config_id, n, world):
+    """(global_envs, step_kernel) of the job a bench sim is a shard of"""
+    j = JOB.get(config_id)
+    if j is None:
+        return {"global_envs": n * world, "step_kernel": "auto"}
+    return {"global_envs": max(j["global_envs"], n * world), "step_kernel": j["step_kernel"]}
 
 
 def kernel_sha16():
@@ -78,16 +90,36 @@ def cpu_baseline(task, action_mode, budget_s=12.0):
         a = rng.uniform(-1, 1, (n, o.action_dim)).astype(np.float32)
         o.step(a, threads=threads)
     dt = time.perf_counter() - t0
-    # config 1 of BASELINE.json: one env on one thread (latency per control step)
+    # config 1 of BASELINE.json: one env on one thread (latency per control step).  The box-to-box spread of this number was 4x in round 3 (a cold
+    # core, the thread migrating): pin the thread to one core, warm it up for ~0.3 s, report the MEDIAN of five regions of 200 steps
     o1 = orc.Oracle(task, 1, action_mode={"joint": 0, "ee": 1}[action_mode])
     o1.reset(seeds=np.zeros(1, np.uint64))
     a1 = rng.uniform(-1, 1, (200, 1, o1.action_dim)).astype(np.float32)
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(old_aff)[len(old_aff) // 2]})
+    except (AttributeError, OSError):
+        old_aff = None
     t1 = time.perf_counter()
-    for i in range(200):
-        o1.step(a1[i], threads=1)
-    dt1 = time.perf_counter() - t1
+    while time.perf_counter() - t1 < 0.3:
+        for i in range(50):
+            o1.step(a1[i], threads=1)
+    regions = []
+    for r in range(5):
+        t1 = time.perf_counter()
+        for i in range(200):
+            o1.step(a1[i], threads=1)
+        regions.append(time.perf_counter() - t1)
+    if old_aff is not None:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except OSError:
+            pass
+    dt1 = float(np.median(regions))
     return {
-        "single_env_single_thread": {"value": 200 / dt1, "unit": "env-steps/s", "ms_per_step": 1e3 * dt1 / 200},
+        "single_env_single_thread": {"value": 200 / dt1, "unit": "env-steps/s", "ms_per_step": 1e3 * dt1 / 200,
+                                     "regions_ms_per_step": [1e3 * x / 200 for x in regions], "note": "one pinned core, 0.3 s warm-up, median of 5 x 200 steps"},
         "value_per_core": n * steps / dt / threads,
         "value": n * steps / dt,
         "unit": "env-steps/s",
@@ -166,8 +198,9 @@ def main():
     if args.obs == "both":
         alg_bytes += 2 * 240 * 320 * 3  # write-once frames
     n = args.envs_per_gpu
+    jk = job_kwargs(args.config, n, world)
     sim = VecSim(task, n, device=local_rank, env_id_offset=sharding.shard_offset(n, rank), observation_mode=args.obs, action_mode=action_mode,
-                 pgs_iters=args.pgs_iters, base_seed=0, arm_collision=args.arm_collision)
+                 pgs_iters=args.pgs_iters, base_seed=0, arm_collision=args.arm_collision, **jk)
     stream = torch.cuda.current_stream()
     sim.set_stream(stream.cuda_stream)
 
@@ -218,7 +251,8 @@ def main():
         for cid in (4, 5):
             wl, n_c, obs_c = CONFIGS[cid]
             t_c, m_c, b_c = WORKLOADS[wl]
-            sim_c = VecSim(t_c, n_c, device=local_rank, env_id_offset=sharding.shard_offset(n_c, rank), observation_mode=obs_c, action_mode=m_c, base_seed=0)
+            sim_c = VecSim(t_c, n_c, device=local_rank, env_id_offset=sharding.shard_offset(n_c, rank), observation_mode=obs_c, action_mode=m_c, base_seed=0,
+                           **job_kwargs(cid, n_c, world))
             sim_c.set_stream(stream.cuda_stream)
             bufs_c = [sim_c.alloc_actions() for _ in range(8)]
             for i, b in enumerate(bufs_c):
@@ -283,6 +317,8 @@ def main():
                             f"n_substeps=20, max_episode_steps=50, auto-reset on, pgs_iters={args.pgs_iters}",
                 "envs_per_gpu": n,
                 "global_envs": n * world,
+                "job": {"global_envs": jk["global_envs"], "step_kernel": jk["step_kernel"],
+                        "note": "kernel family chosen from the task and the JOB size (lcr_config.global_envs), never the shard size: any sharding of the job gives identical bits"},
                 "parallelism": f"env-sharded x{world}, no collective",
                 "arm_collision": bool(args.arm_collision),
                 "kernel_sha16": sha,

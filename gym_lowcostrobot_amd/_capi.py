@@ -11,13 +11,14 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NWARM = 124   # LCR_NWARM: floats per env of carried constraint forces (layout: include/lcr.h)
 TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
 REWARD_TYPES = {"sparse": 0, "dense": 1}
 STEP_KERNELS = {"auto": 0, "single": 1, "coop": 2}   # lcr_config.step_kernel
+PROFILE_MODES = {None: None, "wave_cycles": 2, "phase_cycles": 3}   # lcr_config.diagnostics values 2, 3 (per-wave cycle read-back; see include/lcr.h)
 COMPAT_ZERO_QVEL_ON_RESET = 1
 COMPAT_COLD_SOLVE_EACH_STEP = 2   # contact solver starts every control step from zero forces (default: forces carried across steps)
 IMG_H, IMG_W = 240, 320
@@ -30,7 +31,7 @@ SYMBOLS = [
     "lcr_create", "lcr_destroy", "lcr_set_stream", "lcr_sync", "lcr_reset", "lcr_step", "lcr_step_host",
     "lcr_get_obs", "lcr_get_outputs", "lcr_fetch_host", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
     "lcr_memcpy_h2d", "lcr_memcpy_d2h", "lcr_timer_begin", "lcr_timer_end", "lcr_fill_random_actions",
-    "lcr_calibrate_copy", "lcr_render", "lcr_render_state", "lcr_step_kernel_family",
+    "lcr_calibrate_copy", "lcr_render", "lcr_render_state", "lcr_render_terminal", "lcr_step_kernel_family",
 ]
 
 
@@ -63,6 +64,7 @@ class LcrConfig(ctypes.Structure):
         ("finger_cube_condim", ctypes.c_int32),
         ("step_kernel", ctypes.c_int32),
         ("cc_points", ctypes.c_int32),
+        ("global_envs", ctypes.c_int64),   # ABI v4: envs of the whole job (0 = n_envs); the step_kernel = 0 dispatch looks at it, never at the shard size
     ]
 
 
@@ -184,6 +186,7 @@ def load():
     L.lcr_calibrate_copy.argtypes = [vp, vp, ctypes.c_size_t]
     L.lcr_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.lcr_render_state.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+    L.lcr_render_terminal.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("lcr_last_error", "lcr_destroy"):

@@ -84,6 +84,8 @@ struct lcr_sim {
     LcrCam cam_front, cam_top, cam_vizu;
     unsigned char *render_dev;  // scratch frame for lcr_render
     size_t render_bytes;
+    void *term_stage;           // staging of lcr_render_terminal: env ids, gathered poses, two frame blocks
+    size_t term_stage_bytes;
     // lcr_fetch_host: pinned host mirror of the arena range [qpos .. did_reset] (+ terminal observations)
     size_t fetch_bytes, tobs_off, tobs_bytes;
     char *host_mirror;
@@ -129,8 +131,14 @@ int lcr_config_default(lcr_config *cfg, int task) {
     // StackTwoCubes 4e-4 -- default coefficient 1e-4 m but cube inertia 1.1e-5), off where it does not (<= 4e-5: deviation D4)
     cfg->finger_cube_condim = (task == LCR_TASK_PUSH_LOOP || task == LCR_TASK_STACK) ? 6 : 4;
     cfg->diagnostics = 0;
+    cfg->step_kernel = 0;
+    cfg->cc_points = 0;
+    cfg->global_envs = 0;   // this handle is the whole job
     return LCR_OK;
 }
+
+// the two-wave kernels implement neither the converged solver mode nor the per-wave cycle read-back of diagnostics = 2
+static bool two_wave_possible(const lcr_config *cfg) { return cfg->pgs_iters >= 0 && cfg->diagnostics != 2; }
 
 static int resolved_block_gripper(const lcr_config *cfg) {
     if (cfg->block_gripper >= 0) return cfg->block_gripper ? 1 : 0;
@@ -157,8 +165,19 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->pgs_iters < 0 && !(cfg->pgs_tol > 0)) return fail(LCR_ERR_INVALID, "pgs_tol must be positive in converged mode (pgs_iters < 0)");
     if (cfg->finger_cube_condim != 0 && cfg->finger_cube_condim != 4 && cfg->finger_cube_condim != 6) return fail(LCR_ERR_INVALID, "finger_cube_condim must be 4 or 6");
     if (cfg->cc_points != 0 && cfg->cc_points != 4 && cfg->cc_points != 8) return fail(LCR_ERR_INVALID, "cc_points must be 4 or 8");
+    if (cfg->cc_points == 8 && cfg->task != LCR_TASK_STACK) return fail(LCR_ERR_INVALID, "cc_points = 8 is the cube<->cube manifold of StackTwoCubes; this task has one cube");
     if (cfg->cc_points == 8 && cfg->pgs_iters < 0) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 is implemented by the two-wave kernels, the converged solver mode (pgs_iters < 0) by the one-wave kernels");
-    if (cfg->step_kernel < 0 || cfg->step_kernel > 2) return fail(LCR_ERR_INVALID, "step_kernel must be 0 (by shard size), 1 (one wave per 64 envs) or 2 (two cooperating waves)");
+    if (cfg->step_kernel < 0 || cfg->step_kernel > 2) return fail(LCR_ERR_INVALID, "step_kernel must be 0 (by task and job size), 1 (one wave per 64 envs) or 2 (two cooperating waves)");
+    if (cfg->diagnostics < 0 || cfg->diagnostics > 3) return fail(LCR_ERR_INVALID, "diagnostics must be 0, 1 (decision signature), 2 or 3 (per-wave cycle read-back, profiling)");
+    // combinations no kernel implements are refused, not silently degraded
+    if (cfg->cc_points == 8 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 runs on the two-wave kernels, diagnostics = 2 (per-wave cycles) on the one-wave kernels");
+    if (cfg->cc_points == 8 && cfg->step_kernel == 1) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 is implemented by the two-wave kernels only (step_kernel = 1 pins the one-wave family)");
+    if (cfg->step_kernel == 2 && cfg->pgs_iters < 0) return fail(LCR_ERR_UNSUPPORTED, "the converged solver mode (pgs_iters < 0) is implemented by the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
+    if (cfg->step_kernel == 2 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "diagnostics = 2 (per-wave cycles) reads back the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
+    if (cfg->global_envs < 0) return fail(LCR_ERR_INVALID, "global_envs must be >= 0 (0 = n_envs)");
+    if (cfg->global_envs > 0 && (cfg->env_id_offset < 0 || cfg->env_id_offset + (int64_t)cfg->n_envs > cfg->global_envs))
+        return fail(LCR_ERR_INVALID, "shard [env_id_offset, env_id_offset + n_envs) = [%lld, %lld) does not lie inside the job of global_envs = %lld",
+                    (long long)cfg->env_id_offset, (long long)(cfg->env_id_offset + cfg->n_envs), (long long)cfg->global_envs);
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
     int k = lcr_action_dim(cfg);
@@ -280,24 +299,30 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.big_lds = (cfg->task == LCR_TASK_STACK && (N + 63) / 64 <= 3 * (size_t)prop.multiProcessorCount) ? 1 : 0;
         if (const char *ov = getenv("LCR_STACK_LDS")) { if (cfg->task == LCR_TASK_STACK) D.big_lds = strcmp(ov, "big") == 0 ? 1 : (strcmp(ov, "small") == 0 ? 0 : D.big_lds); }
         D.walls = loop ? 1 : 0;
-        // step-kernel family.  Shards whose 2 x ceil(N / 64) waves fit the chip's SIMDs one each (<= 32 768 envs on an MI355X: BASELINE configs 4
-        // and 5) run the two-cooperating-waves kernels (lcr_kernels2.hip, variant compiled for one wave per SIMD).  Larger shards: the variant
-        // compiled for two waves per SIMD where it is the faster one -- measured (DESIGN.md section 5, 65 536 envs, random policy): ReachCube 0.265 ms
-        // against 0.290 ms on the one-wave-per-64-envs kernels; the tasks with more finger<->cube coupling 0.37-0.39 against 0.34 (a coupled workgroup
-        // runs its two waves in series and at top priority: that works while its SIMD partners are mostly uncoupled) -- else the one-wave kernels.
-        // lcr_config.step_kernel pins a family; LCR_STEP_KERNEL=single|coop1|coop2 overrides (tests and profiling exercise every family at small sizes).
+        // step-kernel family: a function of the task, the config and the size of the JOB (lcr_config.global_envs; 0 = this handle is the job) -- never of
+        // the shard size, so that every sharding of a job runs the same arithmetic (bit-identical results for G = 1/2/4/8).  Measured on an
+        // MI355X with the job as ONE shard (random policy): up to 32 768 envs (2 x 512 waves: one per SIMD) the two-cooperating-waves
+        // kernels win on every task (-16 ... -25 %); above, they win for ReachCube (0.266 against 0.289 ms at 65 536 envs) and lose for the tasks with
+        // more finger<->cube coupling (0.39 against 0.34 ms; PushCubeLoop 1.30 against 0.62).  lcr_config.step_kernel pins a family (a job cut into shards of
+        // <= 32 768 envs pins 2); LCR_STEP_KERNEL=single|coop1|coop2 overrides (tests and profiling exercise every build at small sizes).
+        // WHICH BUILD of the two-wave family a shard runs does follow its size (one wave per SIMD while 2 x ceil(N / 64) waves fit the chip's SIMDs, else the
+        // build compiled for two waves per SIMD): same source, same bits.
         {
             const size_t waves2 = 2 * ((N + 63) / 64), simds = 4 * (size_t)prop.multiProcessorCount;
-            D.coop = waves2 <= simds ? 1 : (cfg->task == LCR_TASK_REACH ? 2 : 0);
-            if (cfg->step_kernel == 1) D.coop = 0;
-            else if (cfg->step_kernel == 2) D.coop = waves2 <= simds ? 1 : 2;
+            const int64_t job = cfg->global_envs > 0 ? cfg->global_envs : (int64_t)N;
             D.cc8 = (cfg->task == LCR_TASK_STACK && cfg->cc_points == 8) ? 1 : 0;
+            bool two_wave = job <= 32768 || cfg->task == LCR_TASK_REACH;
+            if (cfg->step_kernel == 1) two_wave = false;
+            else if (cfg->step_kernel == 2) two_wave = true;
+            if (D.cc8) two_wave = true;                               // the eight-point manifold lives in the two-wave kernels only
+            if (cfg->pgs_iters < 0 || cfg->diagnostics == 2) two_wave = false;   // converged solver mode, per-wave cycle read-back: one-wave kernels only
+            D.coop = two_wave ? (waves2 <= simds ? 1 : 2) : 0;
             if (const char *ov = getenv("LCR_STEP_KERNEL")) {
-                if (strcmp(ov, "single") == 0) D.coop = 0;
-                else if (strcmp(ov, "coop1") == 0) D.coop = 1;
-                else if (strcmp(ov, "coop2") == 0) D.coop = 2;
+                if (strcmp(ov, "single") == 0 && !D.cc8) D.coop = 0;
+                else if (strcmp(ov, "coop1") == 0 && two_wave_possible(cfg)) D.coop = 1;
+                else if (strcmp(ov, "coop2") == 0 && two_wave_possible(cfg)) D.coop = 2;
             }
-            if (D.cc8 && !D.coop) D.coop = waves2 <= simds ? 1 : 2;   // the eight-point manifold lives in the two-wave kernels only
+            if (D.cc8) D.coop = 1;   // (74-80 KiB of LDS per workgroup: its only build is the one-wave-per-SIMD one)
         }
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;
@@ -347,6 +372,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     make_cameras(cfg->task, s->cam_front, s->cam_top, s->cam_vizu);
     s->render_dev = nullptr;
     s->render_bytes = 0;
+    s->term_stage = nullptr;
+    s->term_stage_bytes = 0;
     s->action_stage = (float *)(base + o_act);
     s->mask_dev = (unsigned char *)(base + o_mask);
     s->seeds_dev = (unsigned long long *)(base + o_seeds);
@@ -374,6 +401,7 @@ void lcr_destroy(lcr_sim *s) {
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     if (s->render_dev) (void)hipFree(s->render_dev);
+    if (s->term_stage) (void)hipFree(s->term_stage);
     if (s->host_mirror) (void)hipHostFree(s->host_mirror);
     (void)hipFree(s->arena);
     delete s;
@@ -385,7 +413,7 @@ void lcr_destroy(lcr_sim *s) {
 
 int lcr_step_kernel_family(lcr_sim *s) {
     if (!s) return fail(LCR_ERR_INVALID, "sim is NULL");
-    return (s->dev.coop && s->dev.pgs_iters >= 0 && s->dev.diag != 2) ? s->dev.coop : 0;
+    return s->dev.coop;
 }
 
 int lcr_set_stream(lcr_sim *s, void *hip_stream) {
@@ -660,6 +688,47 @@ int lcr_render_state(lcr_sim *s, int camera, int width, int height, const double
     if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(rgb_host, s->render_dev, bytes, hipMemcpyDeviceToHost));
+    return LCR_OK;
+}
+
+int lcr_render_terminal(lcr_sim *s, const int32_t *env_ids_host, int count, uint8_t *front_host, uint8_t *top_host) {
+    SIMCHK(s);
+    if (count < 0 || (count > 0 && (!env_ids_host || !front_host || !top_host))) return fail(LCR_ERR_INVALID, "NULL argument");
+    if (!s->has_images) return fail(LCR_ERR_UNSUPPORTED, "terminal frames need observation_mode image / both (the frame background is only kept then)");
+    for (int i = 0; i < count; i++)
+        if (env_ids_host[i] < 0 || env_ids_host[i] >= s->dev.n) return fail(LCR_ERR_INVALID, "env id %d out of range", env_ids_host[i]);
+    const size_t img = (size_t)LCR_IMG_H * LCR_IMG_W * 3;
+    const int CHUNK = 1024;   // envs per pass: 2 x 225 KiB of frames each -> at most 450 MiB of staging
+    const int cap = count < CHUNK ? count : CHUNK;
+    if (cap == 0) return LCR_OK;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_ids = 0, o_q = al(sizeof(int) * cap), o_t = o_q + al(sizeof(float) * s->nq * cap), o_f = o_t + al(sizeof(float) * 3 * cap),
+                 o_tp = o_f + al(img * cap), need = o_tp + al(img * cap);
+    if (need > s->term_stage_bytes) {
+        if (s->term_stage) (void)hipFree(s->term_stage);
+        s->term_stage = nullptr; s->term_stage_bytes = 0;
+        hipError_t e = hipMalloc((void **)&s->term_stage, need);
+        if (e != hipSuccess) return fail(LCR_ERR_OOM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        s->term_stage_bytes = need;
+    }
+    char *base = (char *)s->term_stage;
+    for (int done = 0; done < count; done += cap) {
+        const int c = count - done < cap ? count - done : cap;
+        HIPCHK(hipMemcpyAsync(base + o_ids, env_ids_host + done, sizeof(int) * c, hipMemcpyHostToDevice, s->stream));
+        int rc = lcr_launch_gather_terminal(s->dev, (const int *)(base + o_ids), c, (float *)(base + o_q), (float *)(base + o_t), s->stream);
+        if (rc) return fail(LCR_ERR_HIP, "gather launch failed: %s", hipGetErrorString((hipError_t)rc));
+        LcrDev P1 = s->dev;   // a `c`-env view of the handle whose state arrays are the gathered terminal poses
+        P1.n = c;
+        P1.qpos = (float *)(base + o_q);
+        P1.target = (float *)(base + o_t);
+        P1.img_front = (unsigned char *)(base + o_f);
+        P1.img_top = (unsigned char *)(base + o_tp);
+        rc = lcr_launch_render_obs(P1, s->cam_front, s->cam_top, s->stream);
+        if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
+        HIPCHK(hipMemcpyAsync(front_host + (size_t)done * img, base + o_f, img * c, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(top_host + (size_t)done * img, base + o_tp, img * c, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     return LCR_OK;
 }
 

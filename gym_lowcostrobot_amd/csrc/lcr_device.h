@@ -85,6 +85,7 @@ int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsig
 int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed,
                             unsigned long long step, void *stream);
 int lcr_launch_render_obs(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream);
+int lcr_launch_gather_terminal(const LcrDev &P, const int *ids_dev, int count, float *qpos_out, float *target_out, void *stream);
 int lcr_launch_render_bg(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream);
 int lcr_launch_render_single(const LcrDev &P, const LcrCam &cam, int env, int W, int H, unsigned char *out_dev, void *stream);
 int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream);

@@ -473,7 +473,31 @@ __global__ __launch_bounds__(256) void lcr_render_single_kernel(LcrDev P, LcrCam
     out[3 * (size_t)pix + 2] = (unsigned char)(rgb >> 16);
 }
 
+// terminal poses of the listed envs (the step kernel has already reset them: term_obs / term_quat hold the last pose of the episode) gathered into a
+// compact [nq][count] qpos + [3][count] target block, so that lcr_render_obs_kernel can draw their last frames as one batch (lcr_render_terminal)
+__global__ __launch_bounds__(256) void lcr_gather_terminal_kernel(LcrDev P, const int *ids, int count, float *qpos_out, float *target_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const size_t N = (size_t)P.n, C = (size_t)count;
+    const int e = ids[i];
+    const float *t = P.term_obs + e, *tq = P.term_quat + e;   // term_obs rows: arm_qpos 0-5, arm_qvel 6-11, cube 12-14, aux 15-17
+    for (int j = 0; j < 6; j++) qpos_out[j * C + i] = t[j * N];
+    for (int j = 0; j < 3; j++) qpos_out[(6 + j) * C + i] = t[(12 + j) * N];
+    for (int j = 0; j < 4; j++) qpos_out[(9 + j) * C + i] = tq[j * N];
+    if (P.task == 4) {
+        for (int j = 0; j < 3; j++) qpos_out[(13 + j) * C + i] = t[(15 + j) * N];
+        for (int j = 0; j < 4; j++) qpos_out[(16 + j) * C + i] = tq[(4 + j) * N];
+    }
+    for (int j = 0; j < 3; j++) target_out[j * C + i] = P.has_target ? t[(15 + j) * N] : 0.f;
+}
+
 }  // namespace
+
+int lcr_launch_gather_terminal(const LcrDev &P, const int *ids_dev, int count, float *qpos_out, float *target_out, void *stream) {
+    hipLaunchKernelGGL(lcr_gather_terminal_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, ids_dev, count, qpos_out, target_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 int lcr_launch_render_obs(const LcrDev &P, const LcrCam &front, const LcrCam &top, void *stream) {
     if (!P.img_front || !P.img_top) return 0;

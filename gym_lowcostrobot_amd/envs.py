@@ -60,7 +60,8 @@ class _LowCostRobotEnv(sp.EnvBase):
     def get_observation(self):
         obs = self._sim.observations()
         keys = self.observation_space.spaces  # gymnasium.spaces.Dict has no key-membership __contains__; .spaces is the mapping
-        return {k: (v[0] if v.ndim >= 2 else v) for k, v in obs.items() if k in keys}
+        # (keys in the reference's insertion order: arm_qpos, arm_qvel, [target_pos], [images], cube position(s) -- push_cube_env.py:293-306)
+        return {k: (obs[k][0] if obs[k].ndim >= 2 else obs[k]) for k in keys if k in obs}
 
     def reset(self, seed=None, options=None):
         try:
@@ -128,7 +129,7 @@ class LiftCubeEnv(_LowCostRobotEnv):
     _task = "lift"
 
     def __init__(self, observation_mode="image", action_mode="joint", reward_type="sparse", block_gripper=False,
-                 distance_threshold=0.05, cube_xy_range=0.3, height_threshold=0.1, n_substeps=20, render_mode=None):
+                 distance_threshold=0.05, height_threshold=0.1, cube_xy_range=0.3, n_substeps=20, render_mode=None):
         self.distance_threshold = distance_threshold
         self.height_threshold = height_threshold
         self.cube_xy_range = cube_xy_range
@@ -190,7 +191,11 @@ class PushCubeLoopEnv(_LowCostRobotEnv):
         div = bool(out["did_reset"][0])
         if div:
             info["diverged"] = True
-        return self.get_observation(), float(out["reward"][0]), False, div, info
+        # reward types as the reference's arithmetic leaves them (push_cube_loop_env.py:340-357): the int 5 on success, the int -2 when
+        # `min(max(x, -2), -1)` clips, numpy.float64 otherwise
+        r = float(out["reward"][0])
+        reward = 5 if info["success"] else (-2 if r <= -2.0 else np.float64(r))
+        return self.get_observation(), reward, False, div, info
 
 
 class StackTwoCubesEnv(_LowCostRobotEnv):

@@ -8,8 +8,6 @@ infos[i]["terminal_observation"], and infos[i]["TimeLimit.truncated"] / ["is_suc
 Host cost per step is O(1) python + one packed device-to-host copy (VecSim.fetch_host, 132 B/env) + work proportional to the
 number of envs that finished an episode in this step; there is no per-env python loop.
 """
-import types
-
 import numpy as np
 
 from . import spaces as sp
@@ -19,6 +17,29 @@ try:  # pragma: no cover
     from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv
 except Exception:
     _SB3VecEnv = object
+
+
+class _SharedInfo(dict):
+    """The info dict every env that did NOT finish an episode in a step refers to (65 536 fresh dicts per step would dominate the step time).
+    It is a real dict -- isinstance checks, copy.deepcopy, pickling (subprocess / IPC wrappers) work, and a copy is an ordinary writable dict --
+    but writing into the shared instance fails loudly instead of leaking the key into every env."""
+    __slots__ = ()
+
+    def _ro(self, *a, **k):
+        raise TypeError("this info dict is shared by all envs that did not finish an episode in this step: copy it (dict(info)) before writing")
+
+    __setitem__ = __delitem__ = clear = pop = popitem = setdefault = update = __ior__ = _ro
+
+    def __copy__(self):
+        return dict(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        return {copy.deepcopy(k, memo): copy.deepcopy(v, memo) for k, v in self.items()}
+
+    def __reduce__(self):
+        return (dict, (dict(self),))
 
 
 def _obs_spaces(sim, observation_mode):
@@ -76,25 +97,19 @@ class LowCostRobotVecEnv(_SB3VecEnv):
     def _obs(self):
         return self._obs_from(self.sim.fetch_host())
 
-    def _terminal_frames(self, t, tq_col):
-        """image_front / image_top of a terminal pose: the kernel has already reset the env (its frame buffers show the reset state),
-        so the last frames of the episode are ray-cast from terminal_obs row `t` (18,) + terminal_quat column `tq_col` (8,)"""
-        sim = self.sim
-        qpos = np.zeros(sim.nq)
-        qpos[0:6] = t[0:6]; qpos[6:9] = t[12:15]; qpos[9:13] = tq_col[0:4]
-        if sim.task_name == "stack":
-            qpos[13:16] = t[15:18]; qpos[16:20] = tq_col[4:8]
-        tgt = t[15:18] if sim.task_name in ("push", "pick_place") else None
-        return sim.render_state(qpos, tgt, "camera_front"), sim.render_state(qpos, tgt, "camera_top")
-
     def _terminal(self, tobs_rows, env_ids):
         """terminal observation dicts -- EXACTLY the keys of observation_space (SB3's VecTransposeImage and the TimeLimit bootstrap of
-        PPO index every key of infos[i]["terminal_observation"]) -- for the rows of `tobs_rows` (k, 18): arm_qpos6, arm_qvel6, cube3, aux3"""
+        PPO index every key of infos[i]["terminal_observation"]) -- for the rows of `tobs_rows` (k, 18): arm_qpos6, arm_qvel6, cube3, aux3.
+        Image modes: the kernel has already reset these envs (their frame buffers show the reset state), so the last frames of the episodes
+        are ray-cast from the terminal poses -- ALL of them in one batched call (lcr_render_terminal: with TimeLimit(50) and a common
+        start every env finishes in the same step)."""
         sim = self.sim
         img = self.observation_mode in ("image", "both")
-        tq = sim.terminal_quat.numpy() if img and len(env_ids) else None
+        fr = tp = None
+        if img and len(env_ids):
+            fr, tp = sim.render_terminal(env_ids)
         out = []
-        for t, e in zip(tobs_rows, env_ids):
+        for j, t in enumerate(tobs_rows):
             d = {"arm_qpos": t[0:6].copy(), "arm_qvel": t[6:12].copy()}
             if sim.task_name in ("push", "pick_place"):
                 d["target_pos"] = t[15:18].copy()
@@ -103,7 +118,7 @@ class LowCostRobotVecEnv(_SB3VecEnv):
                 if sim.task_name == "stack":
                     d["cube_blue_pos"] = t[15:18].copy()
             if img:
-                d["image_front"], d["image_top"] = self._terminal_frames(t, tq[:, e])
+                d["image_front"], d["image_top"] = fr[j], tp[j]
             out.append({k: d[k] for k in self._keys})
         return out
 
@@ -133,19 +148,20 @@ class LowCostRobotVecEnv(_SB3VecEnv):
         lift = self.task == "lift"
         # envs that did NOT finish an episode all refer to ONE read-only mapping per step (65 536 dicts per step would dominate the step
         # time); a wrapper that tries to write into it fails loudly instead of leaking the key into every env
-        shared = types.MappingProxyType({"TimeLimit.truncated": False} if lift else {"is_success": False, "TimeLimit.truncated": False})
+        shared = _SharedInfo({"TimeLimit.truncated": False} if lift else {"is_success": False, "TimeLimit.truncated": False})
         infos = [shared] * self.num_envs
         idx = np.nonzero(dones | dres)[0]
         if idx.size:
             tl = trunc[idx] & ~term[idx]
             succ = h["is_success"][idx]
-            tobs = self._terminal(h["terminal_obs"][idx], idx) if h["terminal_obs"] is not None else [None] * idx.size
+            ridx = idx[dres[idx]]                  # envs the kernel has reset: they carry a terminal observation
+            tobs = dict(zip(ridx.tolist(), self._terminal(h["terminal_obs"][ridx], ridx))) if (h["terminal_obs"] is not None and ridx.size) else {}
             for j, i in enumerate(idx):
                 d = {"TimeLimit.truncated": bool(tl[j])}
                 if not lift:
                     d["is_success"] = bool(succ[j])
                 if dres[i]:
-                    d["terminal_observation"] = tobs[j]
+                    d["terminal_observation"] = tobs.get(int(i))
                 infos[i] = d
         return obs, h["reward"].copy(), dones, infos
 
@@ -156,14 +172,47 @@ class LowCostRobotVecEnv(_SB3VecEnv):
     def close(self):
         self.sim.close()
 
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        return [int(indices)] if np.isscalar(indices) else [int(i) for i in indices]
+
     def get_attr(self, attr_name, indices=None):
-        return [getattr(self, attr_name, None)] * self.num_envs
+        """per-env attribute reads SB3 performs (`render_mode`, `spec`, `reward_range`, wrapper probes): the batch answers for every env"""
+        v = {"render_mode": None, "spec": None, "reward_range": (-float("inf"), float("inf")), "metadata": {"render_modes": ["rgb_array"], "render_fps": 25}}.get(attr_name)
+        v = getattr(self, attr_name, v)
+        return [v for _ in self._indices(indices)]
 
     def set_attr(self, attr_name, value, indices=None):
         setattr(self, attr_name, value)
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        raise NotImplementedError("batched simulator: no per-env python objects")
+        """The calls SB3 / rl_zoo3 make through env_method on a DummyVecEnv, answered per env (a list, one entry per index) from the batch:
+        `get_wrapper_attr` (attribute probes of Monitor / evaluate_policy), `render` (one ray-cast frame per env), `compute_reward` /
+        `is_success` / `goal_distance` (the reference's public reward helpers, reach_cube_env.py:335-348, evaluated with the env's
+        parameters), `get_state`, `action_masks`-style probes of methods the envs do not have raise AttributeError as a real env would."""
+        ids = self._indices(indices)
+        if method_name == "get_wrapper_attr":
+            return self.get_attr(args[0] if args else kwargs["name"], ids)
+        if method_name == "render":
+            return [self.sim.render(i, "camera_vizu", 640, 640) for i in ids]
+        if method_name in ("goal_distance", "is_success", "compute_reward") and self.task != "lift" and self.task != "push_loop":
+            a, b = (np.asarray(x, np.float64) for x in (args[0], args[1]))
+            d = float(np.linalg.norm(a - b))
+            thr = float(self.sim.cfg.distance_threshold)
+            if method_name == "goal_distance":
+                r = d
+            elif method_name == "is_success":
+                r = np.bool_(d < thr)
+            else:   # reach_cube_env.py:343-348
+                r = -np.float32(d > thr) if self.sim.cfg.reward_type == 0 else -d
+            return [r for _ in ids]
+        if method_name == "get_state":
+            st = self.sim.get_state()
+            return [{k: (v[..., i] if v.ndim > 1 else v[i]) for k, v in st.items()} for i in ids]
+        if method_name in ("seed", "close"):
+            return [None for _ in ids]
+        raise AttributeError(f"the batched simulator's envs have no method {method_name!r}")
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         return [False] * self.num_envs
@@ -214,12 +263,12 @@ class LowCostRobotVectorEnv:
                 fin[sim.cube_name] = t[:, 12:15].copy()
                 if sim.task_name == "stack":
                     fin["cube_blue_pos"] = t[:, 15:18].copy()
-            if v.observation_mode in ("image", "both"):   # final frames: ray-cast from the terminal poses of the envs that were reset
-                fin["image_front"] = np.zeros((self.num_envs, 240, 320, 3), np.uint8)
+            if v.observation_mode in ("image", "both"):   # final frames: ONE batched ray-cast of the terminal poses of the envs that were reset
+                ridx = np.nonzero(h["did_reset"])[0]
+                fin["image_front"] = np.zeros((self.num_envs, 240, 320, 3), np.uint8)   # (calloc'ed: pages of envs that were not reset are never touched)
                 fin["image_top"] = np.zeros((self.num_envs, 240, 320, 3), np.uint8)
-                tq = sim.terminal_quat.numpy()
-                for e in np.nonzero(h["did_reset"])[0]:
-                    fin["image_front"][e], fin["image_top"][e] = v._terminal_frames(t[e], tq[:, e])
+                if ridx.size:
+                    fin["image_front"][ridx], fin["image_top"][ridx] = sim.render_terminal(ridx)
             fin = {k: fin[k] for k in v._keys}
             infos["final_obs"] = fin
             infos["_final_obs"] = h["did_reset"].copy()

@@ -74,6 +74,8 @@ class VecSim:
         finger_cube_condim=None,
         step_kernel="auto",
         cc_points=None,
+        global_envs=None,
+        profile=None,
     ):
         self.L = _capi.load()
         if action_mode not in ACTION_MODES:
@@ -106,12 +108,20 @@ class VecSim:
         cfg.base_seed = int(base_seed)
         cfg.arm_collision = int(bool(arm_collision))
         cfg.pgs_tol = float(pgs_tol)
-        cfg.diagnostics = int(diagnostics)   # True / 1: decision signature; 2, 3: per-wave cycle read-back (profiling aids)
+        # diagnostics is a boolean here (the decision signature + data.ctrl of every step); the profiling aids that reuse those arrays as
+        # per-wave cycle counters are a separate, named argument: profile="wave_cycles" (one-wave kernels) | "phase_cycles" (two-wave kernels)
+        if diagnostics not in (False, True, 0, 1):
+            raise ValueError(f"diagnostics must be a bool, got {diagnostics!r} (cycle read-back: profile='wave_cycles' | 'phase_cycles')")
+        if profile not in _capi.PROFILE_MODES:
+            raise ValueError(f"invalid profile {profile!r} (None | 'wave_cycles' | 'phase_cycles')")
+        cfg.diagnostics = _capi.PROFILE_MODES[profile] if profile is not None else int(bool(diagnostics))
         if finger_cube_condim is not None:   # default: lcr_config_default's choice for the task (6 for PushCubeLoop, else 4)
             cfg.finger_cube_condim = int(finger_cube_condim)
         if step_kernel not in _capi.STEP_KERNELS:
             raise ValueError(f"invalid step_kernel {step_kernel!r} (auto | single | coop)")
-        cfg.step_kernel = _capi.STEP_KERNELS[step_kernel]   # kernel family; pin it when results must be bit-identical across shardings
+        cfg.step_kernel = _capi.STEP_KERNELS[step_kernel]   # kernel family: "auto" = by task and JOB size (global_envs), never by shard size
+        if global_envs is not None:   # envs of the whole job this sim is a shard of: every shard declares the same number -> same family, same bits
+            cfg.global_envs = int(global_envs)
         if cc_points is not None:   # StackTwoCubes: 4 (default) or 8 cube<->cube manifold points
             cfg.cc_points = int(cc_points)
         self.cfg = cfg
@@ -229,6 +239,15 @@ class VecSim:
         check(self.L.lcr_render_state(self.handle, cam, int(width), int(height), _vp(q), _vp(t), _vp(out)))
         return out
 
+    def render_terminal(self, env_ids):
+        """last frames (camera_front, camera_top) of the episodes the last step ended in the listed envs, ray-cast as ONE batch from their
+        terminal poses (the envs themselves have already been reset): two (len(env_ids), 240, 320, 3) uint8 arrays"""
+        ids = np.ascontiguousarray(env_ids, np.int32)
+        front = np.empty((ids.size, _capi.IMG_H, _capi.IMG_W, 3), np.uint8)
+        top = np.empty_like(front)
+        check(self.L.lcr_render_terminal(self.handle, _vp(ids), int(ids.size), _vp(front), _vp(top)))
+        return front, top
+
     def read_rows(self, arr, rows):
         """host copies of selected leading-axis rows of a device array (e.g. the frames of a few recorded envs): one small
         device-to-host copy per row instead of the whole array"""
@@ -264,15 +283,16 @@ class VecSim:
     def observations(self):
         """dict of (N, .) float32 numpy arrays with the reference's keys (get_observation reach:281-295)."""
         obs = {"arm_qpos": self.arm_qpos.numpy().T.copy(), "arm_qvel": self.arm_qvel.numpy().T.copy()}
-        if OBS_MODES["state"] == self.cfg.obs_mode or OBS_MODES["both"] == self.cfg.obs_mode:
-            obs[self.cube_name] = self.cube_pos.numpy().T.copy()
-            if self.task_name == "stack":
-                obs["cube_blue_pos"] = self.aux_pos.numpy().T.copy()
+        # (insertion order of the reference's get_observation: target_pos, images, cube position(s) -- push_cube_env.py:293-306)
         if self.task_name in ("push", "pick_place"):
             obs["target_pos"] = self.aux_pos.numpy().T.copy()  # always present (push_cube_env.py:297)
         if self.image_front is not None:
             obs["image_front"] = self.image_front.numpy()
             obs["image_top"] = self.image_top.numpy()
+        if OBS_MODES["state"] == self.cfg.obs_mode or OBS_MODES["both"] == self.cfg.obs_mode:
+            obs[self.cube_name] = self.cube_pos.numpy().T.copy()
+            if self.task_name == "stack":
+                obs["cube_blue_pos"] = self.aux_pos.numpy().T.copy()
         return obs
 
     def fetch_host(self):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LCR_ABI_VERSION 3
+#define LCR_ABI_VERSION 4
 
 typedef enum lcr_status {
     LCR_OK = 0,
@@ -90,22 +90,31 @@ typedef struct lcr_config {
                                   every arm geom collides in the reference); 0: finger tips only */
     uint64_t base_seed;        /* envs never explicitly seeded use SeedSequence(base_seed + global env id) */
     double pgs_tol;            /* 1e-6; used when pgs_iters < 0 */
-    int32_t diagnostics;       /* 1: lcr_out_view.active_mask / active_count / max_sweeps are written by every step */
+    int32_t diagnostics;       /* 0 | 1: lcr_out_view.active_mask / active_count / max_sweeps / choice / ctrl are written by every step (the decision
+                                  signature).  2, 3: profiling aids -- the same arrays carry per-wave cycle counters instead (2: one-wave kernels,
+                                  which it also selects; 3: phases of the two-wave kernels).  Anything else: LCR_ERR_INVALID */
     int32_t finger_cube_condim; /* rows of a finger<->cube contact.  6 = MuJoCo's: normal, two tangents, torsion, two rolling (follower.xml:15
                                   condim="6" wins the max rule over the cube's 4; rolling coefficient = max of both geoms).  4 = without the
                                   rolling rows (8-12 % faster).  lcr_config_default: 6 for PushCubeLoop (coefficient 1.5 m) and
                                   StackTwoCubes (light cubes), 4 for the other tasks (effect below the parity tolerance: deviation D4,
                                   DESIGN.md).  0 = the task's default */
-    int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by shard size and task (two cooperating waves per 64 envs while the shard's
-                                  waves fit the GPU's SIMDs one each -- <= 32 768 envs on an MI355X; larger shards: two cooperating waves, two per
-                                  SIMD, for ReachCube, where that is the faster kernel, else one wave per 64 envs); 1 = one wave
-                                  per 64 envs always; 2 = two cooperating waves always.  The families regroup the same arithmetic and agree to
-                                  fp32 rounding (~1e-7 per control step), not bit for bit: a job that must give identical bits under
-                                  different shardings pins 1 or 2 (results are bit-identical across shardings within a family). */
+    int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by task and JOB size (global_envs below, never the shard size n_envs):
+                                  two cooperating waves per 64 envs for jobs of <= 32 768 envs and for ReachCube, one wave per 64 envs for larger
+                                  jobs of the other tasks -- the faster family when the job runs as ONE shard on an MI355X; 1 = one wave per
+                                  64 envs always; 2 = two cooperating waves always (the faster family on shards of <= 32 768 envs whatever the job size:
+                                  a job sharded that finely pins 2).  The families regroup the same arithmetic and agree to fp32 rounding (~1e-7 per
+                                  control step), not bit for bit; WITHIN a family results are bit-identical for every sharding.  Because 0 looks at the
+                                  job and not at the shard, every sharding of a job whose shards declare the same global_envs runs the same family
+                                  and gives identical bits; which build of the family a shard runs (one / two waves per SIMD,
+                                  rows in LDS / global scratch) does follow its size and does not change a bit. */
     int32_t cc_points;         /* StackTwoCubes: cube<->cube manifold points kept per substep.  4 (default, 0 = default): the extremes along the diagonals
                                   of the reference face; 8: also the extremes along its two axes -- as many points as MuJoCo's box-box
                                   collider may return (stack_two_cubes.xml:25-35; narrows deviation D5).  8 runs on the
-                                  two-cooperating-waves kernels whatever step_kernel says. */
+                                  two-cooperating-waves kernels (step_kernel = 1 with it: LCR_ERR_UNSUPPORTED); other tasks: LCR_ERR_INVALID */
+    int64_t global_envs;       /* ABI v4: number of envs of the whole JOB this handle is one shard of (all GPUs together); 0 = n_envs (the handle is
+                                  the job).  Must be >= env_id_offset + n_envs.  Only the step_kernel = 0 dispatch reads it (see there): the reference
+                                  has one independent MjData per env (reach_cube_env.py:89-90), so how a batch is cut into shards must not show in
+                                  the results */
 } lcr_config;
 
 typedef struct lcr_sim lcr_sim;
@@ -251,6 +260,13 @@ int lcr_render(lcr_sim *sim, int env, int camera, int width, int height, uint8_t
 /* The same for an arbitrary pose given by the caller (qpos_host[nq] as env.data.qpos, target_host[3] or NULL): e.g. the last
  * frame of an episode whose env the step kernel has already reset (terminal_obs + terminal_quat).  Does not touch the sim state. */
 int lcr_render_state(lcr_sim *sim, int camera, int width, int height, const double *qpos_host, const float *target_host, uint8_t *rgb_host);
+
+/* Batched last frames of finished episodes (what DummyVecEnv puts into infos[i]["terminal_observation"]["image_front" / "image_top"],
+ * examples/gym_manipulation_sb3.py:34-39 with observation_mode image / both; reach_cube_env.py:288-292): the step kernel has already reset
+ * those envs, so their frame buffers show the reset state; this draws camera_front / camera_top of the TERMINAL poses (terminal_obs +
+ * terminal_quat of the last step) of the `count` listed envs with the observation ray-caster, as one batch, into
+ * front_host / top_host [count][240][320][3].  Needs observation_mode image / both.  Synchronous. */
+int lcr_render_terminal(lcr_sim *sim, const int32_t *env_ids_host, int count, uint8_t *front_host, uint8_t *top_host);
 
 /* Measurement support: copy n_floats floats from the start of the state arena to dst_dev with one dword load and
  * one dword store per lane (the step kernel's access pattern): a launch with a KNOWN byte count (4*n read, 4*n

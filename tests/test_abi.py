@@ -37,7 +37,8 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.max_episode_steps == 50                        # gym_lowcostrobot/__init__.py:12
         assert cfg.impratio == 100.0
         assert cfg.finger_cube_condim == (6 if task in ("push_loop", "stack") else 4)   # rolling rows where they matter
-        assert cfg.step_kernel == 0 and cfg.cc_points == 0          # kernel family by shard size; default cube<->cube manifold (4 points)
+        assert cfg.step_kernel == 0 and cfg.cc_points == 0          # kernel family by task and job size; default cube<->cube manifold (4 points)
+        assert cfg.global_envs == 0                                  # ABI v4: this handle is the whole job
         k = hip_lib.lcr_action_dim(ctypes.byref(cfg))
         assert k == (5 if task in ("reach", "push", "push_loop") else 6)  # block_gripper defaults reach:82 / lift:82
         cfg.action_mode = _capi.ACTION_MODES["ee"]
@@ -73,6 +74,23 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
     hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS["stack"])
     cfg.cc_points, cfg.pgs_iters = 8, -1          # the eight-point manifold lives in the two-wave kernels, the converged mode in the one-wave kernels
     assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_UNSUPPORTED
+    # combinations no kernel implements are refused instead of silently degraded (each check runs before any device is touched)
+    for task, setup, code, msg in (
+        ("reach", dict(cc_points=8), _capi.LCR_ERR_INVALID, b"one cube"),
+        ("stack", dict(cc_points=8, diagnostics=2), _capi.LCR_ERR_UNSUPPORTED, b"diagnostics = 2"),
+        ("stack", dict(cc_points=8, step_kernel=1), _capi.LCR_ERR_UNSUPPORTED, b"two-wave kernels only"),
+        ("push", dict(step_kernel=2, pgs_iters=-1), _capi.LCR_ERR_UNSUPPORTED, b"converged solver mode"),
+        ("push", dict(step_kernel=2, diagnostics=2), _capi.LCR_ERR_UNSUPPORTED, b"per-wave cycles"),
+        ("push", dict(diagnostics=4), _capi.LCR_ERR_INVALID, b"diagnostics must be"),
+        ("push", dict(diagnostics=-1), _capi.LCR_ERR_INVALID, b"diagnostics must be"),
+        ("push", dict(global_envs=-5), _capi.LCR_ERR_INVALID, b"global_envs"),
+        ("push", dict(n_envs=64, env_id_offset=100, global_envs=128), _capi.LCR_ERR_INVALID, b"does not lie inside the job"),
+    ):
+        hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS[task])
+        for k, v in setup.items():
+            setattr(cfg, k, v)
+        assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == code, (task, setup)
+        assert msg in hip_lib.lcr_last_error(), (setup, hip_lib.lcr_last_error())
     assert hip_lib.lcr_step_kernel_family(None) == _capi.LCR_ERR_INVALID
     hip_lib.lcr_config_default(ctypes.byref(cfg), 0)
     cfg.action_mode = 7
@@ -81,6 +99,30 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
     assert hip_lib.lcr_step(None, None) == _capi.LCR_ERR_INVALID
     with pytest.raises(ValueError):
         _capi.check(_capi.LCR_ERR_INVALID)
+
+
+def test_integration_snippet_matches_the_struct(hip_lib):
+    """INTEGRATION.md section 2 is what a maintainer of the reference would copy: the ctypes structure it shows must have exactly the size
+    lcr_config_default writes (round 3 shipped a snippet two fields short: lcr_config_default's memset then ran 8 bytes past the object)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = doc[doc.index("class LcrConfig(ctypes.Structure):"):doc.index("cfg = LcrConfig()")]
+    fields = re.findall(r'\("([a-z_0-9]+)",\s*ctypes\.(c_[a-z0-9]+)\)', blk)
+    assert len(fields) >= 20
+    Snip = type("Snip", (ctypes.Structure,), {"_fields_": [(n, getattr(ctypes, t)) for n, t in fields]})
+    cfg = _capi.LcrConfig()
+    assert hip_lib.lcr_config_default(ctypes.byref(cfg), 0) == 0
+    assert ctypes.sizeof(Snip) == cfg.struct_size == ctypes.sizeof(_capi.LcrConfig)
+    assert [(n, t) for n, t in Snip._fields_] == list(_capi.LcrConfig._fields_)            # same names, types and order as the binding in use
+    for n, _ in Snip._fields_:
+        assert getattr(Snip, n).offset == getattr(_capi.LcrConfig, n).offset, n
+    # every field of the C struct is in the binding (declaration order): parse `struct lcr_config` of the header
+    hdr = open(os.path.join(ROOT, "include", "lcr.h")).read()
+    body = hdr[hdr.index("typedef struct lcr_config {"):hdr.index("} lcr_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = re.findall(r"\b(?:u?int(?:32|64)_t|double)\s+([a-z_0-9]+)\s*;", body)
+    assert c_fields == [n for n, _ in _capi.LcrConfig._fields_]
+    import subprocess, sys
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_snippet.py"), "--check"]).returncode == 0, "run tools/gen_integration_snippet.py"
 
 
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")

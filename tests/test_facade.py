@@ -516,3 +516,97 @@ print('one runtime:', libs)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "one runtime" in r.stdout
+
+
+def test_shared_info_dict_is_a_read_only_real_dict():
+    """the info dict shared by all unfinished envs of a step: a dict subclass (isinstance checks, deepcopy and pickling of SB3 / subprocess
+    wrappers work; copies are ordinary writable dicts) that refuses in-place writes"""
+    import copy
+    import pickle
+
+    from gym_lowcostrobot_amd.vecenv import _SharedInfo
+
+    s = _SharedInfo({"is_success": False, "TimeLimit.truncated": False})
+    assert isinstance(s, dict) and s["is_success"] is False and dict(s) == {"is_success": False, "TimeLimit.truncated": False}
+    for write in (lambda: s.__setitem__("episode", 1), lambda: s.update(a=1), lambda: s.pop("is_success"), lambda: s.setdefault("x", 1), lambda: s.clear()):
+        with pytest.raises(TypeError):
+            write()
+    for c in (copy.copy(s), copy.deepcopy(s), pickle.loads(pickle.dumps(s)), copy.deepcopy([s, s])[1]):
+        assert type(c) is dict and c == dict(s)
+        c["episode"] = 1                                   # copies are plain dicts
+    assert "episode" not in s
+
+
+@pytest.mark.gpu
+def test_batched_terminal_frames_match_the_per_env_raycast(hip_lib):
+    """lcr_render_terminal: the last frames of ALL finished episodes in one batched ray-cast (the per-env python loop of
+    lcr_render_state calls was an O(#done) cliff -- with TimeLimit(50) every env finishes in the same step).  Checked against the per-pixel
+    single-frame path from the same terminal poses, and timed."""
+    import time
+
+    from gym_lowcostrobot_amd import LowCostRobotVecEnv
+
+    for task in ("push", "stack"):
+        n = 96
+        v = LowCostRobotVecEnv(task, n, observation_mode="both", max_episode_steps=2, seed=5)
+        v.reset()
+        rng = np.random.default_rng(1)
+        a = rng.uniform(-1, 1, (n, v.action_space.shape[0])).astype(np.float32)
+        v.step(a)
+        obs, rew, dones, infos = v.step(a)
+        assert dones.mean() > 0.5           # TimeLimit(2); a few envs succeeded in the first step and are one step into their next episode
+        fin = np.nonzero(dones)[0]
+        sim = v.sim
+        tob, tq = sim.terminal_obs.numpy(), sim.terminal_quat.numpy()
+        worst = 0.0
+        for e in (int(fin[0]), int(fin[len(fin) // 2]), int(fin[-1])):
+            t = tob[:, e]
+            qpos = np.zeros(sim.nq); qpos[0:6] = t[0:6]; qpos[6:9] = t[12:15]; qpos[9:13] = tq[0:4, e]
+            if task == "stack":
+                qpos[13:16] = t[15:18]; qpos[16:20] = tq[4:8, e]
+            tgt = t[15:18] if task == "push" else None
+            for key, cam in (("image_front", "camera_front"), ("image_top", "camera_top")):
+                ref = sim.render_state(qpos, tgt, cam).astype(int)
+                got = infos[e]["terminal_observation"][key].astype(int)
+                frac = float((np.abs(ref - got).max(axis=-1) > 2).mean())
+                worst = max(worst, frac)
+                assert frac < 5e-4, (task, e, key, frac)          # culled tile path vs one-thread-per-pixel path (cf. test_image_tile_path_matches_per_pixel_raycast)
+            np.testing.assert_array_equal(infos[e]["terminal_observation"]["arm_qpos"], t[0:6])
+        # frames of the reset state differ from the terminal frames (the arm went back to q = 0)
+        assert np.abs(obs["image_front"][fin[0]].astype(int) - infos[fin[0]]["terminal_observation"]["image_front"].astype(int)).max() > 20
+        ids = np.arange(n, dtype=np.int32)
+        t0 = time.perf_counter()
+        fr, tp = sim.render_terminal(ids)
+        dt = time.perf_counter() - t0
+        assert fr.shape == (n, 240, 320, 3) and tp.std() > 5
+        print(f"[terminal frames] {task}: {n} envs x 2 cameras in {dt * 1e3:.1f} ms (batched; worst pixel mismatch fraction {worst:.2e})")
+        with pytest.raises(ValueError):
+            sim.render_terminal([n])                          # out of range
+        v.close()
+    s2 = LowCostRobotVecEnv("reach", 4, observation_mode="state")
+    from gym_lowcostrobot_amd._capi import LcrError
+    with pytest.raises(LcrError):
+        s2.sim.render_terminal([0])                           # needs image observations
+    s2.close()
+
+
+@pytest.mark.gpu
+def test_vecenv_env_method_answers_per_env(hip_lib):
+    """env_method / get_attr as SB3's evaluate_policy, Monitor probes and rl_zoo3 wrappers use them on a DummyVecEnv: lists with one entry per env"""
+    from gym_lowcostrobot_amd import LowCostRobotVecEnv
+
+    v = LowCostRobotVecEnv("reach", 6, seed=1)
+    v.reset()
+    assert v.env_method("get_wrapper_attr", "render_mode") == [None] * 6
+    assert v.get_attr("render_mode", indices=[1, 3]) == [None, None]
+    assert v.env_is_wrapped(object) == [False] * 6
+    r = v.env_method("compute_reward", np.array([0.0, 0.2, 0.1]), np.array([0.0, 0.2, 0.06]), indices=[0, 5])
+    assert len(r) == 2 and r[0] == np.float32(-0.0) and np.signbit(r[0]) and r[0].dtype == np.float32     # reach_cube_env.py:343-348 golden value
+    assert v.env_method("is_success", np.zeros(3), np.array([0.1, 0, 0]), indices=2) == [np.bool_(False)]
+    st = v.env_method("get_state", indices=[4])
+    assert st[0]["qpos"].shape == (13,)
+    frames = v.env_method("render", indices=[0])
+    assert frames[0].shape == (640, 640, 3) and frames[0].std() > 5
+    with pytest.raises(AttributeError):
+        v.env_method("action_masks")
+    v.close()
