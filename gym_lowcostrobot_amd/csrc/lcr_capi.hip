@@ -291,6 +291,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         const double mur = lcrm::SCENE_CUBE_MU_ROLL[cfg->task], mufr = mur > 0.0001 ? mur : 0.0001;   // rolling: max(cube, finger default 1e-4)
         D.rr_fc = (float)(muf * muf / (mufr * mufr));
         D.inv_mu_fcr2 = (float)(1.0 / (mufr * mufr));
+        D.mu_c2 = (float)(mu * mu); D.mu_ct2 = (float)(mut * mut);
+        D.mu_fc2 = (float)(muf * muf); D.mu_fct2 = (float)(muft * muft); D.mu_fcr2 = (float)(mufr * mufr);
         const bool roll_default = loop || cfg->task == LCR_TASK_STACK;
         D.roll = (cfg->finger_cube_condim == 6 || (cfg->finger_cube_condim == 0 && roll_default)) ? 1 : 0;   // 0 = the task's default
         // Stack shards of at most three waves per CU (MI355X: up to 49 152 envs; BASELINE config 5's per-GPU size is 32 768) run the kernel

@@ -64,6 +64,9 @@ struct LcrDev {
     int coop;            // 0: one wave per 64 envs (lcr_kernels.hip); 1 / 2: two cooperating waves per 64 envs (lcr_kernels2.hip) compiled for
                          // one / two waves per SIMD (<= 512 / <= 256 registers per lane)
     int big_lds;         // Stack: the shard has at most three waves per CU -> the variant that keeps every g row in LDS (46 / 52 KiB per wave)
+    // squared friction coefficients (round 4: the contact blocks take a projected-gradient step in the variables f_j / mu_j, lcr_step_common.h soc_step)
+    float mu_c2, mu_ct2;             // cube geom: tangential, torsional
+    float mu_fc2, mu_fct2, mu_fcr2;  // finger<->cube pair (max rule): tangential, torsional, rolling
 };
 
 // pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height

@@ -211,10 +211,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.aref[2] = B_DEF * vp.x;       // t2 = -x
             T.aref[3] = -B_DEF * cww[c].z;  // torsion about n
             // (an inactive slot gets inv = 0: with f = 0 its row updates then come out as exactly zero in the sweeps, no per-sweep selects)
-            T.inv[0] = T.act ? rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn) : 0.f;
-            T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
-            T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
-            T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+            {   // k[] of the block step (lcr_step_common.h soc_step): Ln = 2 (A + R)_nn, Lt = 2 (mu^2 ((A + R)_11 + (A + R)_22) + mu_tors^2 (A + R)_33)
+                const float KF = WALLS ? 3.f : 2.f;   // (PushCubeLoop: three groups, see soc_step)
+                const float Ln = KF * (minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn);
+                const float a12 = 2.f * minv + iinv * (2.f * T.r.z * T.r.z + T.r.x * T.r.x + T.r.y * T.r.y) + 2.f * Rf;
+                const float Ls = KF * P.mu_ct2 * (iinv + Rt);
+                const float Lt = WALLS ? KF * P.mu_c2 * a12 : fmaf(KF * P.mu_c2, a12, Ls);
+                const float iLt = T.act ? rcp(Lt) : 0.f, iLs = WALLS ? (T.act ? rcp(Ls) : 0.f) : iLt;
+                T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
+            }
             if (c == 0 && NC == 1 && !ROLL) {
                 float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                 pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
@@ -364,6 +369,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 f3 vrel = (S.cv[1] + cross(cww[1], r1)) - (S.cv[0] + cross(cww[0], r0));
                 f3 wrel = cww[1] - cww[0];
                 ccl[(size_t)(s * CC_REC + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CC_REC + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CC_REC + 2) * CS] = cpos[s].z;
+                float ccLn = 1.f, ccLt = 0.f;   // metric of the block step (soc_step)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
@@ -383,7 +389,14 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
                     }
                     ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
-                    ccl[(size_t)(s * CC_REC + 11 + r) * CS] = cc_act[s] ? rcp(diag + Rr) : 0.f;
+                    if (r == 0) ccLn = 2.f * (diag + Rr); else ccLt = fmaf(2.f * (r == 3 ? P.mu_ct2 : P.mu_c2), diag + Rr, ccLt);
+                }
+                {   // k[] of soc_step in the record's four "inverse diagonal" fields
+                    const float iLt = cc_act[s] ? rcp(ccLt) : 0.f;
+                    ccl[(size_t)(s * CC_REC + 11) * CS] = cc_act[s] ? rcp(ccLn) : 0.f;
+                    ccl[(size_t)(s * CC_REC + 12) * CS] = P.mu_c2 * iLt;
+                    ccl[(size_t)(s * CC_REC + 13) * CS] = ccLn * rcp(ccLn + ccLt);
+                    ccl[(size_t)(s * CC_REC + 14) * CS] = P.mu_ct2 * iLt;
                 }
                 ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
             }
@@ -469,10 +482,13 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     T.aref[1] = -B_DEF * vp.y;
                     T.aref[2] = -B_DEF * sg * vp.z;
                     T.aref[3] = -B_DEF * sg * w.x;
-                    T.inv[0] = T.act ? rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn) : 0.f;
-                    T.inv[1] = T.act ? rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf) : 0.f;
-                    T.inv[2] = T.act ? rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf) : 0.f;
-                    T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+                    {   // k[] of soc_step
+                        const float Ln = 3.f * (minv + iinv * (r.y * r.y + r.z * r.z) + Rn);   // (three groups: soc_step SEP)
+                        const float a12 = 2.f * minv + iinv * (2.f * r.x * r.x + r.z * r.z + r.y * r.y) + 2.f * Rf;
+                        const float Lt = 3.f * P.mu_c2 * a12, Ls = 3.f * P.mu_ct2 * (iinv + Rt);
+                        const float iLt = T.act ? rcp(Lt) : 0.f, iLs = T.act ? rcp(Ls) : 0.f;
+                        T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) T.f[k] = T.act ? W.wall[2 * pr + c][k] : 0.f;   // warm start
                     // a += M^-1 J^T f in pair coordinates
@@ -623,6 +639,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             float Rf = Rn * P.inv_impratio;
             float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
             T.Rn = Rn;
+            // squared friction coefficients of this slot's rows (finger<->cube pair: max rule; finger geoms mu 1.5 / torsional 0.005; a link proxy on the
+            // floor mu 1, on a cube the cube's) and the metric of the block step (soc_step)
+            const float m2_tan = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
+            const float m2_tors = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : P.mu_ct2);
+            float Ln = 1.f, Lt = 0.f, Ls = 0.f;
             // point Jacobian columns of the link at the contact point
             f3 jc[6];
 #pragma unroll
@@ -674,7 +695,14 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
                 const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
-                T.inv[r] = row_on ? rcp(gg + diagc + Rr) : 0.f;              // (a row that is off: f = 0 and inv = 0 -> its updates are exactly 0)
+                {
+                    const float arr = gg + diagc + Rr;
+                    const float m2r = r == 0 ? 1.f : (r < 3 ? m2_tan : (r == 3 ? m2_tors : P.mu_fcr2));
+                    const float KF = WALLS ? 3.f : 2.f;
+                    if (r == 0) Ln = KF * arr;
+                    else if (WALLS && r >= 3) Ls = fmaf(row_on ? KF * m2r : 0.f, arr, Ls);
+                    else Lt = fmaf(row_on ? KF * m2r : 0.f, arr, Lt);
+                }
                 const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
 #pragma unroll
@@ -686,6 +714,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
                     else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
                 }
+            }
+            {   // k[] of soc_step: iLn, mu_tan^2 iLt, w, mu_tors^2 iLt (, mu_roll^2 iLt)
+                const float iLn = T.act ? rcp(Ln) : 0.f, iLt = T.act ? rcp(Lt) : 0.f, iLs = WALLS ? ((T.act && Ls > 0.f) ? rcp(Ls) : 0.f) : iLt;
+                T.inv[0] = iLn; T.inv[1] = m2_tan * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = (s != 4 || oncube) ? m2_tors * iLs : 0.f;   // (a link proxy on the floor has no torsion row: condim 3)
+                if constexpr (ROLL) { T.inv[4] = P.mu_fcr2 * iLs; T.inv[5] = 0.f; }
             }
         }
     }
@@ -766,10 +799,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const f3 r = T.r;
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * P.rt_cube;
-                // Block form of the four Gauss-Seidel row updates of this contact (same arithmetic as row-by-row GS):
-                // rows J_r = [d_r ; c_r], d = (z, y, -x, 0), c = (r x d) resp. z for the torsion row.  The row residuals
-                // against the CURRENT acceleration (u_r) are independent of each other; the coupling inside the contact is
-                // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
+                // rows J_r = [d_r ; c_r], d = (z, y, -x, 0), c = (r x d) resp. z for the torsion row: the gradient rows u_r against the CURRENT accelerations
                 float aref0 = T.aref[0], aref1 = T.aref[1], aref2 = T.aref[2], aref3 = T.aref[3];
                 float inv0 = T.inv[0], inv1 = T.inv[1], inv2 = T.inv[2], inv3 = T.inv[3];
                 if (c == 0 && NC == 1 && !ROLL) {
@@ -782,19 +812,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - aref1 + Rf * T.f[1];
                 const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - aref2 + Rf * T.f[2];
                 const float u3 = cal[c].z - aref3 + Rt * T.f[3];
-                const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
-                float nf = fmaxf(T.f[0] - u0 * inv0, 0.f);
-                const float d0 = nf - T.f[0];                               // (inactive slot: f = 0, inv = 0 -> every delta is 0)
-                const float d1a = -(u1 + B01 * d0) * inv1;
-                const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv2;
-                const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv3;
-                // elliptic cone: radial projection of the friction part
-                const float fn = T.f[0] + d0;
-                const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
-                const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
-                T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                // one projected-gradient step of the whole block (soc_step): the four gradient rows above are taken from the same accelerations
+                const float uu[4] = {u0, u1, u2, u3}, kk[4] = {inv0, inv1, inv2, inv3};
+                float nf[4];
+                soc_step<4, WALLS>(T.f, uu, kk, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                const float d0 = nf[0] - T.f[0], d1 = nf[1] - T.f[1], d2 = nf[2] - T.f[2], d3 = nf[3] - T.f[3];   // (inactive slot: f = 0, k = 0 -> every delta is 0)
+                T.f[0] = nf[0]; T.f[1] = nf[1]; T.f[2] = nf[2]; T.f[3] = nf[3];
                 track(d0, d1, d2, d3, T.f[0], T.f[1], T.f[2], T.f[3]);   // (converged mode: net change of the sweep, after the cone projection)
                 // a += M^-1 J^T delta
                 ca[c].z = fmaf(minv, d0, ca[c].z);
@@ -830,24 +853,13 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float u1 = dot(cct1, A) - aref[1] + Rf * f[1];
                     const float u2 = dot(cct2, A) - aref[2] + Rf * f[2];
                     const float u3 = dot(ccn, Wr) - aref[3] + Rt * f[3];
-                    const float p00 = dot(r0, ccn), p01 = dot(r0, cct1), p02 = dot(r0, cct2);
-                    const float p10 = dot(r1, ccn), p11 = dot(r1, cct1), p12 = dot(r1, cct2);
-                    const float B01 = -iinv * (p00 * p01 + p10 * p11), B02 = -iinv * (p00 * p02 + p10 * p12), B12 = -iinv * (p01 * p02 + p11 * p12);
-                    const float B13 = -iinv * (p02 + p12), B23 = iinv * (p01 + p11);   // n.((r0+r1) x t1) = -(r0+r1).t2, n.((r0+r1) x t2) = (r0+r1).t1
-                    const float nf = fmaxf(f[0] - u0 * inv[0], 0.f);
-                    const float d0 = nf - f[0];
-                    const float d1a = -(u1 + B01 * d0) * inv[1];
-                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv[2];
-                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv[3];
-                    // elliptic cone: radial projection of the friction part
-                    const float fn = f[0] + d0;
-                    const float g1 = f[1] + d1a, g2 = f[2] + d2a, g3 = f[3] + d3a;
-                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                    const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
-                    track(d0, e1, e2, e3, fn, f[1] + e1, f[2] + e2, f[3] + e3);
-                    ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
-                    ccl[(size_t)(s * CC_REC + 5) * CS] = f[2] + e2; ccl[(size_t)(s * CC_REC + 6) * CS] = f[3] + e3;
+                    const float uu[4] = {u0, u1, u2, u3};
+                    float nf[4];
+                    soc_step<4, WALLS>(f, uu, inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);   // one projected-gradient step of the block (lcr_step_common.h)
+                    const float d0 = nf[0] - f[0], e1 = nf[1] - f[1], e2 = nf[2] - f[2], e3 = nf[3] - f[3];
+                    track(d0, e1, e2, e3, nf[0], nf[1], nf[2], nf[3]);
+                    ccl[(size_t)(s * CC_REC + 3) * CS] = nf[0]; ccl[(size_t)(s * CC_REC + 4) * CS] = nf[1];
+                    ccl[(size_t)(s * CC_REC + 5) * CS] = nf[2]; ccl[(size_t)(s * CC_REC + 6) * CS] = nf[3];
                     // a += M^-1 J^T delta: the force change F acts at the contact point on cube 1 and, negated, on cube 0
                     const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
                     const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
@@ -872,20 +884,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float u1 = a.y - r.z * w.x + r.x * w.z - T.aref[1] + Rf * T.f[1];
                     const float u2 = sg * (a.z + r.y * w.x - r.x * w.y) - T.aref[2] + Rf * T.f[2];
                     const float u3 = sg * w.x - T.aref[3] + Rt * T.f[3];
-                    const float B01 = -sg * iinv * r.x * r.y, B02 = -iinv * r.x * r.z, B12 = -sg * iinv * r.y * r.z;
-                    const float B13 = -sg * iinv * r.z, B23 = iinv * r.y;
-                    const float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
-                    const float d0 = nf - T.f[0];
-                    const float d1a = -(u1 + B01 * d0) * T.inv[1];
-                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
-                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
-                    // elliptic cone: radial projection of the friction part
-                    const float fn = T.f[0] + d0;
-                    const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
-                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                    const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
-                    T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                    const float uu[4] = {u0, u1, u2, u3};
+                    float nf[4];
+                    soc_step<4, WALLS>(T.f, uu, T.inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                    const float d0 = nf[0] - T.f[0], d1 = nf[1] - T.f[1], d2 = nf[2] - T.f[2], d3 = nf[3] - T.f[3];
+                    T.f[0] = nf[0]; T.f[1] = nf[1]; T.f[2] = nf[2]; T.f[3] = nf[3];
                     track(d0, d1, d2, d3, T.f[0], T.f[1], T.f[2], T.f[3]);
                     const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
                     const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
@@ -927,94 +930,50 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
                 // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
                 const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
-                // The cube's share of the four row residuals is tracked as SCALARS: v_r = d_r . (acceleration of the contact
-                // point of the cube), wn = n . (angular acceleration).  A force change dlt on row j moves them by closed-form
-                // couplings, because (rc x d_i).(rc x d_j) = |rc|^2 delta_ij - (rc.d_i)(rc.d_j) for the orthonormal frame:
-                //   v_i -= dlt (k delta_ij - iinv p_i p_j), k = minv + iinv |rc|^2, p_i = rc . d_i;   wn -= iinv dlt n.(rc x d_j)
-                // and the summed force is applied to the cube once at the end of the slot.
-                // (ROLL: the rolling rows need the angular acceleration about t1 and t2 as well: wq = (n, t1, t2) . alpha, wn = wq[0])
-                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f, w1 = 0.f, w2 = 0.f;
+                // the cube's share of the gradient rows: v_r = d_r . (acceleration of the cube's contact point), wn / w1 / w2 = (n, t1, t2) . (angular acceleration)
+                float vq[3] = {0.f, 0.f, 0.f}, wn = 0.f, w1 = 0.f, w2 = 0.f;
                 if (may_cube) {
                     const f3 Ac = a_lin + cross(a_ang, T.rc);
                     vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
-                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
                     wn = dot(T.n, a_ang);
                     if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
-                    kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
-                    if (s == 4) {   // floor lanes: no cube share in the residuals
+                    if (s == 4) {   // floor lanes: no cube share in the rows
 #pragma unroll
                         for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
                         wn = oncube ? wn : 0.f;
                     }
                 }
-                // effect of a force change dlt on row j on the tracked scalars
-                auto couple = [&](int j, float dlt) {
-                    if (j < 3) {
-                        const float c = iinv_e * pq[j] * dlt;
+                // gradient rows of the block from the SAME forces (no serial dependence inside the block), one projected-gradient step (soc_step), then y follows
+                float u[NRW], fcur[NRW], nf[NRW];
 #pragma unroll
-                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
-                        vq[j] = fmaf(-kq, dlt, vq[j]);
-                        // n.(rc x t1) = -rc.t2, n.(rc x t2) = rc.t1, n.(rc x n) = 0
-                        if (j == 1) wn = fmaf(iinv_e * dlt, pq[2], wn);
-                        if (j == 2) wn = fmaf(-iinv_e * dlt, pq[1], wn);
-                        if (nrow == 6) {   // d_i . (rc x d_j) = rc . (d_j x d_i), right-handed frame n x t1 = t2, t1 x t2 = n, t2 x n = t1
-                            if (j == 0) { w1 = fmaf(-iinv_e * dlt, pq[2], w1); w2 = fmaf(iinv_e * dlt, pq[1], w2); }
-                            if (j == 1) w2 = fmaf(-iinv_e * dlt, pq[0], w2);
-                            if (j == 2) w1 = fmaf(iinv_e * dlt, pq[0], w1);
-                        }
-                    } else if (j == 3) {   // torsion: angular acceleration changes by -iinv dlt n; contact point by (-iinv dlt n) x rc
-                        wn = fmaf(-iinv_e, dlt, wn);
-                        vq[1] = fmaf(iinv_e * dlt, pq[2], vq[1]);    // t1.(n x rc) = -p_2
-                        vq[2] = fmaf(-iinv_e * dlt, pq[1], vq[2]);   // t2.(n x rc) =  p_1
-                    } else if (j == 4) {   // rolling about t1: alpha -= iinv dlt t1; point acceleration += (-iinv dlt t1) x rc
-                        w1 = fmaf(-iinv_e, dlt, w1);
-                        vq[0] = fmaf(-iinv_e * dlt, pq[2], vq[0]);   // n.(t1 x rc)  =  p_2
-                        vq[2] = fmaf(iinv_e * dlt, pq[0], vq[2]);    // t2.(t1 x rc) = -p_0
-                    } else {               // rolling about t2
-                        w2 = fmaf(-iinv_e, dlt, w2);
-                        vq[0] = fmaf(iinv_e * dlt, pq[1], vq[0]);    // n.(t2 x rc)  = -p_1
-                        vq[1] = fmaf(-iinv_e * dlt, pq[0], vq[1]);   // t1.(t2 x rc) =  p_0
+                for (int r = 0; r < NRW; r++) {
+                    fcur[r] = T.f[r];
+                    u[r] = 0.f;
+                    if (r < nrow) {
+                        const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                        const float gy = acc.x + acc.y;
+                        float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                        float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                        if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
+                        u[r] = gy + jc_a - arefv[r] + Rr * fcur[r];
                     }
-                };
-#pragma unroll
-                for (int r = 0; r < nrow; r++) {
-                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
-                    const float gy = acc.x + acc.y;
-                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
-                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
-                    if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
-                    float res = gy + jc_a - arefv[r] + Rr * T.f[r];
-                    float nf = T.f[r] - res * invv[r];
-                    if (r == 0) nf = fmaxf(nf, 0.f);
-                    float dlt = nf - T.f[r];
-                    T.f[r] += dlt;
-                    {
-                        const float2v d2 = {dlt, dlt};
-#pragma unroll
-                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                    }
-                    if (may_cube) couple(r, dlt);
                 }
-                // cone projection (finger geoms: mu 1.5; a link proxy on the floor: mu 1; on a cube: the cube's friction)
-                {
-                    float fn = T.f[0];
+                {   // (finger geoms: mu 1.5 / torsional 0.005; finger<->cube pair: max rule; a link proxy on the floor: mu 1, on a cube: the cube's friction)
                     const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
                     const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
-                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow >= 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
-                    if constexpr (ROLL) { if (nrow == 6) s2 = fmaf(T.f[4] * T.f[4] + T.f[5] * T.f[5], P.inv_mu_fcr2, s2); }
-                    float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                    soc_step<NRW, WALLS>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
+                }
 #pragma unroll
-                    for (int r = 1; r < nrow; r++) {
-                        float dlt = T.f[r] * sc - T.f[r];
-                        T.f[r] += dlt;
+                for (int r = 0; r < NRW; r++) {
+                    if (r < nrow) {
+                        const float dlt = nf[r] - fcur[r];
+                        T.f[r] = nf[r];
                         const float2v d2 = {dlt, dlt};
 #pragma unroll
                         for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                        // (the tracked scalars are not needed any more: the next slot starts from the updated accelerations)
                     }
                 }
-                // (converged mode: the NET force change of this sweep, after the cone projection -- a sliding contact at its projected fixed
-                //  point has a non-zero raw tangential update every sweep, which is then scaled back)
+                // (converged mode: the net force change of this sweep)
                 track(T.f[0] - f_in[0], T.f[1] - f_in[1], T.f[2] - f_in[2], T.f[3] - f_in[3], T.f[0], T.f[1], T.f[2], T.f[3]);
                 if constexpr (ROLL) { if (nrow == 6) track(T.f[4] - f_in[4], T.f[5] - f_in[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
                 f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot

@@ -477,6 +477,10 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 float Rf = Rn * P.inv_impratio;
                 float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
                 T.Rn = Rn;
+                // squared friction coefficients of this slot's rows (finger geoms mu 1.5 / torsional 0.005; a link proxy on the floor mu 1, on a cube the cube's)
+                const float m2_tan = s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f);
+                const float m2_tors = s < 4 ? MU_TORS * MU_TORS : P.mu_ct2;
+                float Ln = 1.f, Lt = 0.f, Ls = 0.f;
                 f3 jc[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
@@ -522,7 +526,15 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                     if (ROLL && r > 3) Rr = Rf * P.rr_fc;
                     T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                     const bool row_on = T.act && (s != 4 || r < 3 || oncube);
-                    T.inv[r] = row_on ? rcp(gg + diagc + Rr) : 0.f;
+                    // metric of the block step (soc_step): Ln = 2 (A + R)_nn, Lt = 2 sum mu_j^2 (A + R)_jj over the friction rows that are on
+                    {
+                        const float arr = gg + diagc + Rr;
+                        const float m2r = r == 0 ? 1.f : (r < 3 ? m2_tan : (r == 3 ? m2_tors : P.mu_fcr2));
+                        const float KF = WALLS ? 3.f : 2.f;
+                    if (r == 0) Ln = KF * arr;
+                    else if (WALLS && r >= 3) Ls = fmaf(row_on ? KF * m2r : 0.f, arr, Ls);
+                    else Lt = fmaf(row_on ? KF * m2r : 0.f, arr, Lt);
+                    }
                     const float fw = row_on ? Wf[s][r] : 0.f;
                     Wf[s][r] = fw;
 #pragma unroll
@@ -534,6 +546,11 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                         if (NC == 2 && cidx == 1) { dca[NC - 1] = dca[NC - 1] + dl; dcal[NC - 1] = dcal[NC - 1] + da; }
                         else { dca[0] = dca[0] + dl; dcal[0] = dcal[0] + da; }
                     }
+                }
+                {   // k[] of soc_step: iLn, mu_tan^2 iLt, w, mu_tors^2 iLt
+                    const float iLn = T.act ? rcp(Ln) : 0.f, iLt = T.act ? rcp(Lt) : 0.f, iLs = WALLS ? ((T.act && Ls > 0.f) ? rcp(Ls) : 0.f) : iLt;
+                    T.inv[0] = iLn; T.inv[1] = m2_tan * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = (s != 4 || oncube) ? m2_tors * iLs : 0.f;   // (a link proxy on the floor has no torsion row: condim 3)
+                    if constexpr (ROLL) { T.inv[4] = P.mu_fcr2 * iLs; T.inv[5] = 0.f; }
                 }
                 if (LL::HAS_PARK && (s == 2 || s == 3)) {   // park the per-substep constants of the finger<->floor slots (read back once per sweep)
                     float4v *pk = reinterpret_cast<float4v *>(lds + LL::PARK0) + (size_t)((s - 2) * 2) * 64 + lane;
@@ -662,77 +679,43 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
                 if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
                 const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
-                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f, w1 = 0.f, w2 = 0.f;
+                float vq[3] = {0.f, 0.f, 0.f}, wn = 0.f, w1 = 0.f, w2 = 0.f;
                 if (may_cube) {
                     const f3 Ac = a_lin + cross(a_ang, T.rc);
                     vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
-                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
                     wn = dot(T.n, a_ang);
                     if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
-                    kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
                     if (s == 4) {
 #pragma unroll
                         for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
                         wn = oncube ? wn : 0.f;
                     }
                 }
-                auto couple = [&](int j, float dlt) {
-                    if (j < 3) {
-                        const float c = iinv_e * pq[j] * dlt;
+                // gradient rows of the block from the SAME forces (no serial dependence inside the block), one projected-gradient step, then the change goes to y
+                float u[NRW], fcur[NRW], nf[NRW];
 #pragma unroll
-                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
-                        vq[j] = fmaf(-kq, dlt, vq[j]);
-                        if (j == 1) wn = fmaf(iinv_e * dlt, pq[2], wn);
-                        if (j == 2) wn = fmaf(-iinv_e * dlt, pq[1], wn);
-                        if (nrow == 6) {
-                            if (j == 0) { w1 = fmaf(-iinv_e * dlt, pq[2], w1); w2 = fmaf(iinv_e * dlt, pq[1], w2); }
-                            if (j == 1) w2 = fmaf(-iinv_e * dlt, pq[0], w2);
-                            if (j == 2) w1 = fmaf(iinv_e * dlt, pq[0], w1);
-                        }
-                    } else if (j == 3) {
-                        wn = fmaf(-iinv_e, dlt, wn);
-                        vq[1] = fmaf(iinv_e * dlt, pq[2], vq[1]);
-                        vq[2] = fmaf(-iinv_e * dlt, pq[1], vq[2]);
-                    } else if (j == 4) {
-                        w1 = fmaf(-iinv_e, dlt, w1);
-                        vq[0] = fmaf(-iinv_e * dlt, pq[2], vq[0]);
-                        vq[2] = fmaf(iinv_e * dlt, pq[0], vq[2]);
-                    } else {
-                        w2 = fmaf(-iinv_e, dlt, w2);
-                        vq[0] = fmaf(iinv_e * dlt, pq[1], vq[0]);
-                        vq[1] = fmaf(-iinv_e * dlt, pq[0], vq[1]);
+                for (int r = 0; r < NRW; r++) {
+                    fcur[r] = Wf[s][r];
+                    u[r] = 0.f;
+                    if (r < nrow) {
+                        const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                        const float gy = acc.x + acc.y;
+                        float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                        float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                        if (ROLL && r > 3) { jc_a = may_cube ? (r == 4 ? -w1 : -w2) : 0.f; Rr = Rf * P.rr_fc; }
+                        u[r] = gy + jc_a - arefv[r] + Rr * fcur[r];
                     }
-                };
-#pragma unroll
-                for (int r = 0; r < nrow; r++) {
-                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
-                    const float gy = acc.x + acc.y;
-                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
-                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
-                    if (ROLL && r > 3) { jc_a = may_cube ? (r == 4 ? -w1 : -w2) : 0.f; Rr = Rf * P.rr_fc; }
-                    float res = gy + jc_a - arefv[r] + Rr * Wf[s][r];
-                    float nf = Wf[s][r] - res * invv[r];
-                    if (r == 0) nf = fmaxf(nf, 0.f);
-                    float dlt = nf - Wf[s][r];
-                    Wf[s][r] += dlt;
-                    {
-                        const float2v d2 = {dlt, dlt};
-#pragma unroll
-                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                    }
-                    if (may_cube) couple(r, dlt);
                 }
-                {   // cone projection (finger geoms: mu 1.5; a link proxy on the floor: mu 1; on a cube: the cube's friction)
-                    float fn = Wf[s][0];
+                {
                     const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
                     const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
-                    float s2 = (Wf[s][1] * Wf[s][1] + Wf[s][2] * Wf[s][2]) * imu2 + (nrow >= 4 ? Wf[s][3] * Wf[s][3] * imt2 : 0.f);
-                    if constexpr (ROLL) { if (nrow == 6) s2 = fmaf(Wf[s][4] * Wf[s][4] + Wf[s][5] * Wf[s][5], P.inv_mu_fcr2, s2); }
-                    float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                    soc_step<NRW, WALLS>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
+                }
 #pragma unroll
-                    for (int r = 1; r < nrow; r++) {
-                        float dlt = Wf[s][r] * sc - Wf[s][r];
-                        Wf[s][r] += dlt;
+                for (int r = 0; r < NRW; r++) {
+                    if (r < nrow) {
+                        const float dlt = nf[r] - fcur[r];
+                        Wf[s][r] = nf[r];
                         const float2v d2 = {dlt, dlt};
 #pragma unroll
                         for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
@@ -1186,6 +1169,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 const float Rt = Rf * P.rt_fc;
                 T.Rn = Rn;
                 const int nj = sp == 0 ? 5 : 6;   // joints that move the sphere (link_5 / link_6)
+                float Ln01 = 1.f, Lt01 = 0.f, Ls01 = 0.f;
                 f3 jc[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) jc[j] = j < nj ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
@@ -1222,7 +1206,14 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                     if (ROLL && r > 3) Rr = Rf * P.rr_fc;
                     T.aref[r] = -B_FC * vel - (r == 0 ? K_FC * imp * dist : 0.f);
-                    T.inv[r] = T.act ? rcp(gg + diagc + Rr) : 0.f;   // (a row that is off: f = 0 and inv = 0 -> its updates are exactly 0)
+                    {   // metric of the block step (soc_step)
+                        const float arr = gg + diagc + Rr;
+                        const float m2r = r == 0 ? 1.f : (r < 3 ? P.mu_fc2 : (r == 3 ? P.mu_fct2 : P.mu_fcr2));
+                        const float KF = WALLS ? 3.f : 2.f;
+                        if (r == 0) Ln01 = KF * arr;
+                        else if (WALLS && r >= 3) Ls01 = fmaf(KF * m2r, arr, Ls01);
+                        else Lt01 = fmaf(KF * m2r, arr, Lt01);
+                    }
                     const float fw = T.act ? Wf01[sp][r] : 0.f;       // warm start: previous substep's force of this slot
                     Wf01[sp][r] = fw;
 #pragma unroll
@@ -1231,6 +1222,11 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     const f3 da = r < 3 ? (-iinv * fw) * cross(T.rc, d) : (-iinv * fw) * d;
                     if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
                     else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
+                }
+                {   // k[] of soc_step (a slot that is off in this lane: zeros -> its updates are exact zeros)
+                    const float iLn = T.act ? rcp(Ln01) : 0.f, iLt = T.act ? rcp(Lt01) : 0.f, iLs = WALLS ? (T.act ? rcp(Ls01) : 0.f) : iLt;
+                    T.inv[0] = iLn; T.inv[1] = P.mu_fc2 * iLt; T.inv[2] = Ln01 * rcp(Ln01 + Lt01); T.inv[3] = P.mu_fct2 * iLs;
+                    if constexpr (ROLL) { T.inv[4] = P.mu_fcr2 * iLs; T.inv[5] = 0.f; }
                 }
             }
         }
@@ -1303,10 +1299,15 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 T.aref[1] = -B_DEF * vp.y;
                 T.aref[2] = B_DEF * vp.x;
                 T.aref[3] = -B_DEF * cww[c].z;
-                T.inv[0] = T.act ? rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn) : 0.f;
-                T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
-                T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
-                T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+                {   // k[] of soc_step: Ln = 2 (A + R)_nn, Lt = 2 (mu^2 ((A + R)_11 + (A + R)_22) + mu_tors^2 (A + R)_33)
+                    const float KF = WALLS ? 3.f : 2.f;   // (PushCubeLoop: three groups, see soc_step)
+                    const float Ln = KF * (minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn);
+                    const float a12 = 2.f * minv + iinv * (2.f * T.r.z * T.r.z + T.r.x * T.r.x + T.r.y * T.r.y) + 2.f * Rf;
+                    const float Ls = KF * P.mu_ct2 * (iinv + Rt);
+                    const float Lt = WALLS ? KF * P.mu_c2 * a12 : fmaf(KF * P.mu_c2, a12, Ls);
+                    const float iLt = T.act ? rcp(Lt) : 0.f, iLs = WALLS ? (T.act ? rcp(Ls) : 0.f) : iLt;
+                    T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
+                }
                 float (&Tf)[4] = Wfloor[c][s];   // the carried forces ARE this slot's forces from here on (zero if the slot is off)
 #pragma unroll
                 for (int k = 0; k < 4; k++) { Tf[k] = T.act ? Tf[k] : 0.f; }
@@ -1447,6 +1448,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     f3 vrel = (cv[1] + cross(cww[1], r1)) - (cv[0] + cross(cww[0], r0));
                     f3 wrel = cww[1] - cww[0];
                     ccl[(size_t)(s * CC_REC + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CC_REC + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CC_REC + 2) * CS] = cpos[s].z;
+                    float ccLn = 1.f, ccLt = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
@@ -1466,7 +1468,14 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                             } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
                         }
                         ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
-                        ccl[(size_t)(s * CC_REC + 11 + r) * CS] = cc_act[s] ? rcp(diag + Rr) : 0.f;
+                        if (r == 0) ccLn = 2.f * (diag + Rr); else ccLt = fmaf(2.f * (r == 3 ? P.mu_ct2 : P.mu_c2), diag + Rr, ccLt);
+                    }
+                    {   // k[] of soc_step in the record's four "inverse diagonal" fields
+                        const float iLt = cc_act[s] ? rcp(ccLt) : 0.f;
+                        ccl[(size_t)(s * CC_REC + 11) * CS] = cc_act[s] ? rcp(ccLn) : 0.f;
+                        ccl[(size_t)(s * CC_REC + 12) * CS] = P.mu_c2 * iLt;
+                        ccl[(size_t)(s * CC_REC + 13) * CS] = ccLn * rcp(ccLn + ccLt);
+                        ccl[(size_t)(s * CC_REC + 14) * CS] = P.mu_ct2 * iLt;
                     }
                     ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
                 }
@@ -1546,10 +1555,13 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                         T.aref[1] = -B_DEF * vp.y;
                         T.aref[2] = -B_DEF * sg * vp.z;
                         T.aref[3] = -B_DEF * sg * w.x;
-                        T.inv[0] = T.act ? rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn) : 0.f;
-                        T.inv[1] = T.act ? rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf) : 0.f;
-                        T.inv[2] = T.act ? rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf) : 0.f;
-                        T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+                        {   // k[] of soc_step
+                            const float Ln = 3.f * (minv + iinv * (r.y * r.y + r.z * r.z) + Rn);   // (three groups: soc_step SEP)
+                            const float a12 = 2.f * minv + iinv * (2.f * r.x * r.x + r.z * r.z + r.y * r.y) + 2.f * Rf;
+                            const float Lt = 3.f * P.mu_c2 * a12, Ls = 3.f * P.mu_ct2 * (iinv + Rt);
+                            const float iLt = T.act ? rcp(Lt) : 0.f, iLs = T.act ? rcp(Ls) : 0.f;
+                            T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; k++) T.f[k] = T.act ? Wwall[2 * pr + c][k] : 0.f;
                         const float la = minv * sg * T.f[0], lb = minv * T.f[1], lc = minv * sg * T.f[2];
@@ -1643,18 +1655,11 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - T.aref[1] + Rf * Tf[1];
                     const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - T.aref[2] + Rf * Tf[2];
                     const float u3 = cal[c].z - T.aref[3] + Rt * Tf[3];
-                    const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
-                    float nf = fmaxf(Tf[0] - u0 * T.inv[0], 0.f);
-                    const float d0 = nf - Tf[0];
-                    const float d1a = -(u1 + B01 * d0) * T.inv[1];
-                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
-                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
-                    const float fn = Tf[0] + d0;
-                    const float g1 = Tf[1] + d1a, g2 = Tf[2] + d2a, g3 = Tf[3] + d3a;
-                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                    const float d1 = g1 * sc - Tf[1], d2 = g2 * sc - Tf[2], d3 = g3 * sc - Tf[3];
-                    Tf[0] = fn; Tf[1] += d1; Tf[2] += d2; Tf[3] += d3;
+                    const float uu[4] = {u0, u1, u2, u3};
+                    float nf[4];
+                    soc_step<4, WALLS>(Tf, uu, T.inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                    const float d0 = nf[0] - Tf[0], d1 = nf[1] - Tf[1], d2 = nf[2] - Tf[2], d3 = nf[3] - Tf[3];
+                    Tf[0] = nf[0]; Tf[1] = nf[1]; Tf[2] = nf[2]; Tf[3] = nf[3];
                     ca[c].z = fmaf(minv, d0, ca[c].z);
                     ca[c].y = fmaf(minv, d1, ca[c].y);
                     ca[c].x = fmaf(-minv, d2, ca[c].x);
@@ -1685,22 +1690,12 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                         const float u1 = dot(cct1, A) - aref[1] + Rf * f[1];
                         const float u2 = dot(cct2, A) - aref[2] + Rf * f[2];
                         const float u3 = dot(ccn, Wr) - aref[3] + Rt * f[3];
-                        const float p00 = dot(r0, ccn), p01 = dot(r0, cct1), p02 = dot(r0, cct2);
-                        const float p10 = dot(r1, ccn), p11 = dot(r1, cct1), p12 = dot(r1, cct2);
-                        const float B01 = -iinv * (p00 * p01 + p10 * p11), B02 = -iinv * (p00 * p02 + p10 * p12), B12 = -iinv * (p01 * p02 + p11 * p12);
-                        const float B13 = -iinv * (p02 + p12), B23 = iinv * (p01 + p11);
-                        const float nf = fmaxf(f[0] - u0 * inv[0], 0.f);
-                        const float d0 = nf - f[0];
-                        const float d1a = -(u1 + B01 * d0) * inv[1];
-                        const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv[2];
-                        const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv[3];
-                        const float fn = f[0] + d0;
-                        const float g1 = f[1] + d1a, g2 = f[2] + d2a, g3 = f[3] + d3a;
-                        const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                        const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                        const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
-                        ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
-                        ccl[(size_t)(s * CC_REC + 5) * CS] = f[2] + e2; ccl[(size_t)(s * CC_REC + 6) * CS] = f[3] + e3;
+                        const float uu[4] = {u0, u1, u2, u3};
+                        float nf[4];
+                        soc_step<4, WALLS>(f, uu, inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                        const float d0 = nf[0] - f[0], e1 = nf[1] - f[1], e2 = nf[2] - f[2], e3 = nf[3] - f[3];
+                        ccl[(size_t)(s * CC_REC + 3) * CS] = nf[0]; ccl[(size_t)(s * CC_REC + 4) * CS] = nf[1];
+                        ccl[(size_t)(s * CC_REC + 5) * CS] = nf[2]; ccl[(size_t)(s * CC_REC + 6) * CS] = nf[3];
                         const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
                         const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
                         ca[1] = axpy(minv, Fd, ca[1]); ca[0] = axpy(-minv, Fd, ca[0]);
@@ -1723,19 +1718,11 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                         const float u1 = a.y - r.z * w.x + r.x * w.z - T.aref[1] + Rf * T.f[1];
                         const float u2 = sg * (a.z + r.y * w.x - r.x * w.y) - T.aref[2] + Rf * T.f[2];
                         const float u3 = sg * w.x - T.aref[3] + Rt * T.f[3];
-                        const float B01 = -sg * iinv * r.x * r.y, B02 = -iinv * r.x * r.z, B12 = -sg * iinv * r.y * r.z;
-                        const float B13 = -sg * iinv * r.z, B23 = iinv * r.y;
-                        const float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
-                        const float d0 = nf - T.f[0];
-                        const float d1a = -(u1 + B01 * d0) * T.inv[1];
-                        const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
-                        const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
-                        const float fn = T.f[0] + d0;
-                        const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
-                        const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
-                        const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-                        const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
-                        T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                        const float uu[4] = {u0, u1, u2, u3};
+                        float nf[4];
+                        soc_step<4, WALLS>(T.f, uu, T.inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                        const float d0 = nf[0] - T.f[0], d1 = nf[1] - T.f[1], d2 = nf[2] - T.f[2], d3 = nf[3] - T.f[3];
+                        T.f[0] = nf[0]; T.f[1] = nf[1]; T.f[2] = nf[2]; T.f[3] = nf[3];
                         const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
                         const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
                         const float ab = iinv * sg * (r.z * d0 - r.x * d2);
@@ -1768,72 +1755,32 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 for (int r = 0; r < NRW; r++) f_in[r] = Wf01[s][r];
                 const bool second = NC == 2 && s01_cube[s] == 1;
                 const f3 a_lin = second ? ca[NC - 1] : ca[0], a_ang = second ? cal[NC - 1] : cal[0];
-                float vq[3], pq[3], wn, kq, w1 = 0.f, w2 = 0.f;
+                float vq[3], wn, w1 = 0.f, w2 = 0.f;
                 {
                     const f3 Ac = a_lin + cross(a_ang, T.rc);
                     vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
-                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
                     wn = dot(T.n, a_ang);
                     if (NRW == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
-                    kq = fmaf(iinv, dot(T.rc, T.rc), minv);
                 }
-                auto couple = [&](int j, float dlt) {
-                    if (j < 3) {
-                        const float c = iinv * pq[j] * dlt;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
-                        vq[j] = fmaf(-kq, dlt, vq[j]);
-                        if (j == 1) wn = fmaf(iinv * dlt, pq[2], wn);
-                        if (j == 2) wn = fmaf(-iinv * dlt, pq[1], wn);
-                        if (NRW == 6) {
-                            if (j == 0) { w1 = fmaf(-iinv * dlt, pq[2], w1); w2 = fmaf(iinv * dlt, pq[1], w2); }
-                            if (j == 1) w2 = fmaf(-iinv * dlt, pq[0], w2);
-                            if (j == 2) w1 = fmaf(iinv * dlt, pq[0], w1);
-                        }
-                    } else if (j == 3) {
-                        wn = fmaf(-iinv, dlt, wn);
-                        vq[1] = fmaf(iinv * dlt, pq[2], vq[1]);
-                        vq[2] = fmaf(-iinv * dlt, pq[1], vq[2]);
-                    } else if (j == 4) {
-                        w1 = fmaf(-iinv, dlt, w1);
-                        vq[0] = fmaf(-iinv * dlt, pq[2], vq[0]);
-                        vq[2] = fmaf(iinv * dlt, pq[0], vq[2]);
-                    } else {
-                        w2 = fmaf(-iinv, dlt, w2);
-                        vq[0] = fmaf(iinv * dlt, pq[1], vq[0]);
-                        vq[1] = fmaf(-iinv * dlt, pq[0], vq[1]);
-                    }
-                };
+                float u[NRW], fcur[NRW], nf[NRW];
 #pragma unroll
                 for (int r = 0; r < NRW; r++) {
+                    fcur[r] = Wf01[s][r];
                     const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
                     const float gy = acc.x + acc.y;
                     float jc_a = r < 3 ? -vq[r] : -wn;
                     float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
                     if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
-                    const float res = gy + jc_a - T.aref[r] + Rr * Wf01[s][r];
-                    float nf = Wf01[s][r] - res * T.inv[r];
-                    if (r == 0) nf = fmaxf(nf, 0.f);
-                    const float dlt = nf - Wf01[s][r];
-                    Wf01[s][r] += dlt;
+                    u[r] = gy + jc_a - T.aref[r] + Rr * fcur[r];
+                }
+                soc_step<NRW, WALLS>(fcur, u, T.inv, 1.f / (MU_FINGER * MU_FINGER), P.inv_mu_fct2, P.inv_mu_fcr2, NRW, nf);   // (finger<->cube pair: max rule, the finger's 1.5 is the largest cube friction of any task)
+#pragma unroll
+                for (int r = 0; r < NRW; r++) {
+                    const float dlt = nf[r] - fcur[r];
+                    Wf01[s][r] = nf[r];
                     const float2v d2 = {dlt, dlt};
 #pragma unroll
                     for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                    couple(r, dlt);
-                }
-                {   // cone projection (finger geoms: mu 1.5; torsional / rolling: max of finger and cube)
-                    const float fn = Wf01[s][0];
-                    float s2 = (Wf01[s][1] * Wf01[s][1] + Wf01[s][2] * Wf01[s][2]) * (1.f / (MU_FINGER * MU_FINGER)) + Wf01[s][3] * Wf01[s][3] * P.inv_mu_fct2;
-                    if constexpr (ROLL) s2 = fmaf(Wf01[s][4] * Wf01[s][4] + Wf01[s][5] * Wf01[s][5], P.inv_mu_fcr2, s2);
-                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
-#pragma unroll
-                    for (int r = 1; r < NRW; r++) {
-                        const float dlt = Wf01[s][r] * sc - Wf01[s][r];
-                        Wf01[s][r] += dlt;
-                        const float2v d2 = {dlt, dlt};
-#pragma unroll
-                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                    }
                 }
                 yv[0] = yp[0].x; yv[1] = yp[0].y; yv[2] = yp[1].x; yv[3] = yp[1].y; yv[4] = yp[2].x; yv[5] = yp[2].y;
                 {

@@ -12,6 +12,7 @@
 #include "lcr_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -793,6 +794,390 @@ static void body_invweight(const task_model *T, int b, double *tr, double *ro) {
 static int g_diag_rows, g_diag_contacts;
 static double g_diag_res;
 
+/* ---- yard-stick of the contact solver (orc_params.cone = 1, orc_io.kkt): MuJoCo's per-contact PGS block update and the KKT certificate ---- */
+/* min 1/2 y'Ay + y'b  s.t. |y| <= r  (n <= 5): Newton on the multiplier of the norm constraint, MJ-DOC mju_QCQP after scaling by the friction coefficients */
+static void qcqp_ball(int n, const double *A, const double *b, double r, double *y) {
+    double lam = 0, L[25], x[5];
+    for (int it = 0; it < 60; it++) {
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) L[i * n + j] = A[i * n + j] + (i == j ? lam : 0.0);
+        /* Cholesky (A is positive definite: a diagonal block of A + R) */
+        for (int j = 0; j < n; j++) {
+            double d = L[j * n + j];
+            for (int k = 0; k < j; k++) d -= L[j * n + k] * L[j * n + k];
+            d = d > 1e-300 ? sqrt(d) : 1e-150;
+            L[j * n + j] = d;
+            for (int i = j + 1; i < n; i++) {
+                double s = L[i * n + j];
+                for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+                L[i * n + j] = s / d;
+            }
+        }
+        /* y = -(A + lam I)^-1 b */
+        for (int i = 0; i < n; i++) { double s = -b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
+        for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * y[k]; y[i] = s / L[i * n + i]; }
+        double val = -r * r;
+        for (int i = 0; i < n; i++) val += y[i] * y[i];
+        if (val <= 1e-14 * (1.0 + r * r)) break;                 /* inside the ball (lam = 0) or on it */
+        /* d|y|^2 / dlam = -2 y'(A + lam I)^-1 y */
+        for (int i = 0; i < n; i++) { double s = y[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
+        double der = 0;
+        for (int i = 0; i < n; i++) der += x[i] * x[i];          /* = y'(LL')^-1 y */
+        der *= -2.0;
+        const double delta = -val / der;
+        if (!(delta > 0) || delta < 1e-16 * (1.0 + lam)) break;
+        lam += delta;
+    }
+}
+static void pgs_block_exact(const real *A, int nr, const real *bvec, const real *Rr, real *f, int i0, int dm, const double *mu) {
+    double AR[36], res[6], old[6];
+    for (int j = 0; j < dm; j++) {
+        double s = (double)bvec[i0 + j] + (double)Rr[i0 + j] * (double)f[i0 + j];
+        for (int m = 0; m < nr; m++) s += (double)A[(size_t)(i0 + j) * nr + m] * (double)f[m];
+        res[j] = s; old[j] = (double)f[i0 + j];
+        for (int k = 0; k < dm; k++) AR[j * dm + k] = (double)A[(size_t)(i0 + j) * nr + i0 + k] + (j == k ? (double)Rr[i0 + j] : 0.0);
+    }
+    double fn;
+    double cur[6];
+    for (int j = 0; j < dm; j++) cur[j] = old[j];
+    if (old[0] < MJ_MINVAL) {
+        /* The block sits at the apex of its cone.  Zero is the block's optimum iff its gradient c = res - AR old lies in the dual cone, in scaled variables
+         * (f~ = (f_n, f_j / mu_j), c~ = (c_n, mu_j c_j)):  |c~_t| <= c~_n.  MuJoCo's PGS only tries the normal row here and therefore stays at zero whenever the
+         * normal row alone does not want a force -- although with mu > 1 the convex problem (and MuJoCo's default Newton solver) may have a non-zero optimum
+         * there.  To reach THAT optimum: otherwise step along the projection of -c~ onto the cone with an exact line search, then continue with the friction QCQP. */
+        double c[6], ct[6], d[6], xn = 0;
+        for (int j = 0; j < dm; j++) { c[j] = res[j]; for (int k = 0; k < dm; k++) c[j] -= AR[j * dm + k] * old[k]; }
+        ct[0] = c[0];
+        for (int j = 1; j < dm; j++) { ct[j] = mu[j - 1] * c[j]; xn += ct[j] * ct[j]; }
+        xn = sqrt(xn);
+        if (xn <= ct[0]) { for (int j = 0; j < dm; j++) f[i0 + j] = 0; return; }           /* zero is optimal for this block */
+        /* P_soc(-c~) */
+        if (xn <= -ct[0]) { for (int j = 0; j < dm; j++) d[j] = -ct[j]; }
+        else { const double a = 0.5 * (-ct[0] + xn); d[0] = a; for (int j = 1; j < dm; j++) d[j] = -a * ct[j] / xn; }
+        for (int j = 1; j < dm; j++) d[j] *= mu[j - 1];                                       /* back to force units */
+        double num = 0, den = 0;
+        for (int j = 0; j < dm; j++) { num += d[j] * c[j]; for (int k = 0; k < dm; k++) den += d[j] * AR[j * dm + k] * d[k]; }
+        const double al = den > 0 ? -num / den : 0.0;
+        for (int j = 0; j < dm; j++) cur[j] = al > 0 ? al * d[j] : 0.0;
+        fn = cur[0];
+    } else {                            /* ray update: exact line search along the current force direction (stays inside the cone) */
+        double den = 0, num = 0;
+        for (int j = 0; j < dm; j++) { num += old[j] * res[j]; for (int k = 0; k < dm; k++) den += old[j] * AR[j * dm + k] * old[k]; }
+        if (den >= MJ_MINVAL) {
+            double x = -num / den;
+            if (old[0] + x * old[0] < 0) x = -1.0;
+            for (int j = 0; j < dm; j++) cur[j] = old[j] + x * old[j];
+        }
+        fn = cur[0];
+    }
+    if (fn < MJ_MINVAL) { for (int j = 0; j < dm; j++) f[i0 + j] = (real)(j == 0 ? (fn > 0 ? fn : 0) : 0); return; }
+    /* friction rows given the normal force: gradient at friction x is  bc + Ac x,  bc_j = res_j - sum_k AR_jk old_k + AR_j0 fn  (k over all rows of the block) */
+    const int n = dm - 1;
+    double Ac[25], bc[5], y[5];
+    for (int j = 0; j < n; j++) {
+        double s = res[j + 1] + AR[(j + 1) * dm] * fn;
+        for (int k = 0; k < dm; k++) s -= AR[(j + 1) * dm + k] * old[k];
+        bc[j] = s * mu[j];
+        for (int k = 0; k < n; k++) Ac[j * n + k] = AR[(j + 1) * dm + k + 1] * mu[j] * mu[k];
+    }
+    qcqp_ball(n, Ac, bc, fn, y);
+    f[i0] = (real)fn;
+    for (int j = 0; j < n; j++) f[i0 + 1 + j] = (real)(y[j] * mu[j]);
+}
+/* A contact block at the apex of its cone (all its forces zero): is zero the block's optimum?  If not, step along the projection of the negative
+ * gradient onto the cone with an exact line search (see pgs_block_exact).  Returns 1 if the block moved.  Used by cone = 2: the row-by-row sweep with
+ * radial projection (D2) plus this escape, which removes the false fixed point at the apex while keeping the product's cheap row updates. */
+static int pgs_apex_escape(const real *A, int nr, const real *bvec, const real *Rr, real *f, int i0, int dm, const double *mu) {
+    double c[6], ct[6], d[6], xn = 0;
+    for (int j = 0; j < dm; j++) {
+        double s = (double)bvec[i0 + j];
+        for (int m = 0; m < nr; m++) s += (double)A[(size_t)(i0 + j) * nr + m] * (double)f[m];
+        c[j] = s;
+    }
+    ct[0] = c[0];
+    for (int j = 1; j < dm; j++) { ct[j] = mu[j - 1] * c[j]; xn += ct[j] * ct[j]; }
+    xn = sqrt(xn);
+    if (xn <= ct[0]) return 0;
+    if (xn <= -ct[0]) { for (int j = 0; j < dm; j++) d[j] = -ct[j]; }
+    else { const double a = 0.5 * (-ct[0] + xn); d[0] = a; for (int j = 1; j < dm; j++) d[j] = -a * ct[j] / xn; }
+    for (int j = 1; j < dm; j++) d[j] *= mu[j - 1];
+    double num = 0, den = 0;
+    for (int j = 0; j < dm; j++) {
+        num += d[j] * c[j];
+        for (int k = 0; k < dm; k++) den += d[j] * ((double)A[(size_t)(i0 + j) * nr + i0 + k] + (j == k ? (double)Rr[i0 + j] : 0.0)) * d[k];
+    }
+    const double al = den > 0 ? -num / den : 0.0;
+    if (!(al > 0)) return 0;
+    for (int j = 0; j < dm; j++) f[i0 + j] = (real)(al * d[j]);
+    return 1;
+}
+/* cone = 3: one projected-gradient step on the whole contact block, in the scaled variables y = (f_n, f_j / mu_j) in which the elliptic cone is the
+ * second-order cone: y <- P_soc(y - g~ / Lb), g~ = (g_n, mu_j g_j) the block's gradient at the current forces and Lb = trace of the scaled block of A + R (an
+ * upper bound of its largest eigenvalue, so the step never overshoots).  Fixed points are exactly the optima of the convex problem (no apex trap, no radial
+ * bias), the cost per sweep is that of the row-by-row update, and all rows of a block are evaluated from the same forces (no serial dependence inside it). */
+static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr, real *f, int i0, int dm, const double *mu, int scalar_step, int sep) {
+    /* Projected-gradient step in the metric D = diag(Ln, Lt, .., Lt) of the scaled variables y = (f_n, f_j / mu_j):  y <- P_K^D(y - D^-1 g~).
+     * Ln = 2 (A + R)_nn and Lt = 2 sum_j mu_j^2 (A + R)_jj majorise the scaled block (a PSD matrix is below k times its block diagonal for k diagonal blocks,
+     * and a PSD block below its trace), so the step never increases the objective; its fixed points are exactly the optima.  The D-projection onto the
+     * second-order cone is closed-form for this two-group metric: with v = y - D^-1 g~, N = |v_t|:
+     *     inside (N <= v_n): v;   else  y_n = max(0, w v_n + (1 - w) N),  y_t = v_t y_n / N,  w = Ln / (Ln + Lt).
+     * In force units:  v_n = f_n - u_n / Ln,  v_j mu_j = f_j - mu_j^2 u_j / Lt  (u = gradient rows).
+     * sep (PushCubeLoop, whose cube has torsional and rolling coefficients of 1.5 m, push_cube_loop.xml:31: their scaled curvature mu^2 / I is four orders of
+     * magnitude above the tangential rows' and would set the step of all friction rows): the torsional and rolling rows form a THIRD group with their own
+     * Ls (all three scaled by 3 instead of 2); the cone is enforced on (normal, tangential) in closed form as above and the third group is then limited to what
+     * the cone leaves, |y_s| <= sqrt(y_n^2 - |y_t|^2) -- the exact D-projection whenever that limit is not reached, which with coefficients of 1.5 m it never is in
+     * practice (a torque of mu_s f_n = 1.5 m x f_n would be needed). */
+    real u[6], Ln = 0, Lt = 0, Ls = 0;
+    const real kf = sep ? 3 : 2;
+    for (int j = 0; j < dm; j++) {
+        real s = bvec[i0 + j] + Rr[i0 + j] * f[i0 + j];
+        for (int m = 0; m < nr; m++) s += A[(size_t)(i0 + j) * nr + m] * f[m];
+        u[j] = s;
+        const real d = A[(size_t)(i0 + j) * nr + i0 + j] + Rr[i0 + j];
+        if (j == 0) Ln = kf * d;
+        else if (sep && j >= 3) Ls += kf * (real)(mu[j - 1] * mu[j - 1]) * d;
+        else Lt += kf * (real)(mu[j - 1] * mu[j - 1]) * d;
+    }
+    if (scalar_step) { Ln = (real)0.5 * (Ln + Lt); Lt = Ln; }   /* (study, cone = 4) one scalar step 1 / trace for the whole block */
+    const real iLn = (real)1 / Ln, iLt = (real)1 / Lt, iLs = Ls > 0 ? (real)1 / Ls : 0, w = Ln / (Ln + Lt);
+    real fp[6], s2 = 0, s2s = 0;
+    fp[0] = f[i0] - u[0] * iLn;
+    for (int j = 1; j < dm; j++) {
+        const real m2 = (real)(mu[j - 1] * mu[j - 1]);
+        if (sep && j >= 3) { fp[j] = f[i0 + j] - m2 * u[j] * iLs; s2s += fp[j] * fp[j] / m2; }
+        else { fp[j] = f[i0 + j] - m2 * u[j] * iLt; s2 += fp[j] * fp[j] / m2; }
+    }
+    const real N = (real)sqrt((double)s2);
+    real a = w * fp[0] + ((real)1 - w) * N, y0 = fp[0];
+    if (a > y0) y0 = a;
+    if (y0 < 0) y0 = 0;
+    real sc = 1;
+    if (N > y0) sc = y0 / N;
+    f[i0] = y0;
+    real scs = 1;
+    if (sep) {   /* what the cone leaves for the third group: nothing when (normal, tangential) was projected onto the cone's surface; else y_n^2 - N^2 */
+        if (N > y0) scs = 0;
+        else {
+            const real lim2 = (y0 - N) * (y0 + N);
+            if (s2s > lim2) scs = (real)sqrt((double)(lim2 / s2s));
+        }
+    }
+    for (int j = 1; j < dm; j++) f[i0 + j] = fp[j] * ((sep && j >= 3) ? scs : sc);
+}
+/* natural residual of the KKT conditions of  min_{f in K} 1/2 f'(A + R) f + f'b  (orc_io.kkt) */
+static double kkt_residual(const real *A, int nr, const real *bvec, const real *Rr, const real *f, const int *kind, const int *blkdim, const double *const *rowmu) {
+    double worst = 0, fmax = 0;
+    double g[MAX_ROWS];
+    for (int i = 0; i < nr; i++) {
+        double s = (double)bvec[i] + (double)Rr[i] * (double)f[i];
+        for (int j = 0; j < nr; j++) s += (double)A[(size_t)i * nr + j] * (double)f[j];
+        g[i] = s;
+        if (fabs((double)f[i]) > fmax) fmax = fabs((double)f[i]);
+    }
+    for (int i = 0; i < nr; i++) {
+        if (kind[i] == 0) {             /* limit: f >= 0, g >= 0, f g = 0 */
+            const double r = fabs((double)f[i] < g[i] ? (double)f[i] : g[i]);
+            if (r > worst) worst = r;
+        } else if (kind[i] == 1) {      /* contact block: z = f~ - g~ projected onto the second-order cone */
+            const int dm = blkdim[i];
+            const double *mu = rowmu[i];
+            double ft[6], z[6];
+            ft[0] = (double)f[i]; z[0] = ft[0] - g[i];
+            double xn = 0;
+            for (int r = 1; r < dm; r++) { ft[r] = (double)f[i + r] / mu[r - 1]; z[r] = ft[r] - mu[r - 1] * g[i + r]; xn += z[r] * z[r]; }
+            xn = sqrt(xn);
+            double p[6];
+            if (xn <= z[0]) { for (int r = 0; r < dm; r++) p[r] = z[r]; }
+            else if (xn <= -z[0]) { for (int r = 0; r < dm; r++) p[r] = 0; }
+            else { const double a = 0.5 * (z[0] + xn); p[0] = a; for (int r = 1; r < dm; r++) p[r] = a * z[r] / xn; }
+            for (int r = 0; r < dm; r++) { const double d = fabs(ft[r] - p[r]); if (d > worst) worst = d;
+                if (getenv("ORC_KKT_DEBUG") && d > 1.0) fprintf(stderr, "kkt blk row0=%d dm=%d r=%d d=%g f=%g g=%g ft=%g p=%g mu=%g fn=%g gn=%g\n", i, dm, r, d, (double)f[i + r], g[i + r], ft[r], p[r], r ? mu[r - 1] : 1.0, (double)f[i], g[i]); }
+        }
+    }
+    return worst / (1.0 + fmax);
+}
+
+/* ---- exact optimum of MuJoCo's convex constraint problem (orc_params.solver = 1): Newton's method on the PRIMAL, as MuJoCo's default solver --------------
+ * (follower.xml:3 sets no solver -> Newton).  MJ-DOC "Computation / Constraint model": the constrained acceleration minimises
+ *     F(x) = 1/2 (x - a0)' M (x - a0) + sum_b s_b(J_b x - aref_b),     s_b(z) = max_{f in K_b} ( -f'z - 1/2 f'R_b f ),
+ * the Fenchel dual of  min_{f in K} 1/2 f'(A + R) f + f'(J a0 - aref)  (what PGS iterates on); the constraint forces are f_b = argmax.  Because the friction
+ * rows are regularised by R_f mu_0^2 / mu_j^2 the block maximiser is closed-form in the scaled variables y = (f_n, f_j / mu_j), w = (z_n, mu_j z_j), N = |w_t|:
+ *     top    (w_n >= N):                       y = 0
+ *     bottom (N / Rt <= -w_n / Rn):            y_n = -w_n / Rn,  y_t = -w_t / Rt                     (inside the cone: plain quadratic)
+ *     middle (otherwise):                      y_n = (N - w_n) / (Rn + Rt),  y_t = -y_n w_t / N       (on the cone's surface)
+ * with Rn = R of the normal row, Rt = R_f mu_0^2.  F is convex, C^1 and piecewise quadratic in nv <= 18 unknowns; Newton with a backtracking line search
+ * converges in a handful of iterations.  The result is certified independently by kkt_residual() on the DUAL problem. */
+typedef struct { int i0, dm; double Rn, Rt; const double *mu; } nblock;
+static double newton_eval(int nv, int nr, const double *Md, const double *Jd, const double *aref, const double *Rr, const double *a0, const int *kind,
+                          const int *blkdim, const double *const *rowmu, const double *x, double *f, double *W /* nr x 6: per-row block of -df/dz, or NULL */) {
+    double cost = 0;
+    for (int i = 0; i < nv; i++) {
+        double s = 0;
+        for (int j = 0; j < nv; j++) s += Md[i * nv + j] * (x[j] - a0[j]);
+        cost += 0.5 * (x[i] - a0[i]) * s;
+    }
+    for (int i = 0; i < nr; i++) {
+        if (kind[i] == 2) continue;
+        const int dm = kind[i] == 0 ? 1 : blkdim[i];
+        double z[6] = {0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < dm; r++) {
+            double s = -aref[i + r];
+            for (int d = 0; d < nv; d++) s += Jd[(size_t)(i + r) * nv + d] * x[d];
+            z[r] = s;
+        }
+        if (W) for (int r = 0; r < dm; r++) for (int c = 0; c < 6; c++) W[(size_t)(i + r) * 6 + c] = 0;
+        if (kind[i] == 0) {
+            const double fi = z[0] < 0 ? -z[0] / Rr[i] : 0.0;
+            f[i] = fi;
+            cost += 0.5 * Rr[i] * fi * fi;                     /* s(z) = -(f z + R f^2 / 2) = R f^2 / 2 at f = -z / R */
+            if (W && z[0] < 0) W[(size_t)i * 6] = 1.0 / Rr[i];
+            continue;
+        }
+        const double *mu = rowmu[i];
+        const double Rn = Rr[i], Rt = Rr[i + 1] * mu[0] * mu[0];
+        double w[6], N = 0;
+        w[0] = z[0];
+        for (int r = 1; r < dm; r++) { w[r] = mu[r - 1] * z[r]; N += w[r] * w[r]; }
+        N = sqrt(N);
+        double y[6];
+        if (w[0] >= N) {                                        /* top zone */
+            for (int r = 0; r < dm; r++) { y[r] = 0; f[i + r] = 0; }
+        } else if (N * Rn <= -w[0] * Rt) {                      /* bottom zone */
+            y[0] = -w[0] / Rn;
+            for (int r = 1; r < dm; r++) y[r] = -w[r] / Rt;
+            if (W) { W[(size_t)i * 6] = 1.0 / Rn; for (int r = 1; r < dm; r++) W[(size_t)(i + r) * 6 + r] = mu[r - 1] * mu[r - 1] / Rt; }
+        } else {                                                /* middle zone */
+            const double D = Rn + Rt;
+            y[0] = (N - w[0]) / D;
+            for (int r = 1; r < dm; r++) y[r] = -y[0] * w[r] / N;
+            if (W) {   /* -dy/dw = [[1/D, -u'/D], [-u/D, u u'/D + (y0/N)(I - u u')]], u = w_t / N; then scale rows and columns by S = diag(1, mu) */
+                double u[6];
+                for (int r = 1; r < dm; r++) u[r] = w[r] / N;
+                W[(size_t)i * 6] = 1.0 / D;
+                for (int r = 1; r < dm; r++) {
+                    W[(size_t)i * 6 + r] = -u[r] / D * mu[r - 1];
+                    W[(size_t)(i + r) * 6] = -u[r] / D * mu[r - 1];
+                    for (int c = 1; c < dm; c++)
+                        W[(size_t)(i + r) * 6 + c] = (u[r] * u[c] / D + (y[0] / N) * ((r == c ? 1.0 : 0.0) - u[r] * u[c])) * mu[r - 1] * mu[c - 1];
+                }
+            }
+        }
+        double quad = 0.5 * Rn * y[0] * y[0], lin = y[0] * w[0];
+        for (int r = 1; r < dm; r++) { quad += 0.5 * Rt * y[r] * y[r]; lin += y[r] * w[r]; }
+        cost += -(quad + lin);
+        f[i] = y[0];
+        for (int r = 1; r < dm; r++) f[i + r] = y[r] * mu[r - 1];
+    }
+    return cost;
+}
+static int newton_primal(int nv, int nr, const real *M, const real *J, const real *aref_r, const real *Rr_r, const real *a0_r, const int *kind,
+                         const int *blkdim, const double *const *rowmu, real *f_out, int max_iter) {
+    double *Md = (double *)malloc(sizeof(double) * ((size_t)nv * nv * 2 + (size_t)nr * nv + (size_t)nr * 8 + (size_t)nv * 6 + (size_t)nr * 6));
+    double *H = Md + (size_t)nv * nv, *Jd = H + (size_t)nv * nv, *aref = Jd + (size_t)nr * nv, *Rr = aref + nr, *f = Rr + nr, *ftry = f + nr;
+    double *a0 = ftry + nr + (size_t)nr * 4, *x = a0 + nv, *g = x + nv, *dx = g + nv, *xt = dx + nv, *tmp = xt + nv, *W = tmp + nv;
+    for (int i = 0; i < nv * nv; i++) Md[i] = (double)M[i];
+    for (size_t i = 0; i < (size_t)nr * nv; i++) Jd[i] = (double)J[i];
+    for (int i = 0; i < nr; i++) { aref[i] = (double)aref_r[i]; Rr[i] = (double)Rr_r[i]; }
+    for (int i = 0; i < nv; i++) { a0[i] = (double)a0_r[i]; x[i] = a0[i]; }
+    int it;
+    for (it = 0; it < max_iter; it++) {
+        const double cost = newton_eval(nv, nr, Md, Jd, aref, Rr, a0, kind, blkdim, rowmu, x, f, W);
+        double gn = 0, scale = 0;
+        for (int i = 0; i < nv; i++) {
+            double s = 0;
+            for (int j = 0; j < nv; j++) s += Md[i * nv + j] * (x[j] - a0[j]);
+            for (int r = 0; r < nr; r++) s -= Jd[(size_t)r * nv + i] * f[r];
+            g[i] = s; gn += s * s; scale += Md[i * nv + i];
+        }
+        if (sqrt(gn) <= 1e-13 * (1.0 + scale)) break;
+        /* H = M + J' W J (W block-diagonal) */
+        for (int i = 0; i < nv * nv; i++) H[i] = Md[i];
+        for (int i = 0; i < nr; i++) {
+            if (kind[i] == 2) continue;
+            const int dm = kind[i] == 0 ? 1 : blkdim[i];
+            for (int r = 0; r < dm; r++)
+                for (int c = 0; c < dm; c++) {
+                    const double wv = W[(size_t)(i + r) * 6 + c];
+                    if (wv == 0) continue;
+                    for (int a = 0; a < nv; a++) {
+                        const double ja = Jd[(size_t)(i + r) * nv + a] * wv;
+                        if (ja == 0) continue;
+                        for (int b = 0; b < nv; b++) H[a * nv + b] += ja * Jd[(size_t)(i + c) * nv + b];
+                    }
+                }
+        }
+        /* Cholesky solve H dx = -g */
+        int ok = 1;
+        for (int j = 0; j < nv && ok; j++) {
+            double d = H[j * nv + j];
+            for (int k = 0; k < j; k++) d -= H[j * nv + k] * H[j * nv + k];
+            if (!(d > 0)) { ok = 0; break; }
+            d = sqrt(d); H[j * nv + j] = d;
+            for (int i = j + 1; i < nv; i++) {
+                double s = H[i * nv + j];
+                for (int k = 0; k < j; k++) s -= H[i * nv + k] * H[j * nv + k];
+                H[i * nv + j] = s / d;
+            }
+        }
+        if (!ok) break;
+        for (int i = 0; i < nv; i++) { double s = -g[i]; for (int k = 0; k < i; k++) s -= H[i * nv + k] * tmp[k]; tmp[i] = s / H[i * nv + i]; }
+        for (int i = nv - 1; i >= 0; i--) { double s = tmp[i]; for (int k = i + 1; k < nv; k++) s -= H[k * nv + i] * dx[k]; dx[i] = s / H[i * nv + i]; }
+        double slope = 0;
+        for (int i = 0; i < nv; i++) slope += g[i] * dx[i];
+        if (!(slope < 0)) break;
+        /* EXACT line search, as MuJoCo's Newton solver does: phi(al) = F(x + al dx) is convex and C^1 (piecewise quadratic: the Hessian jumps where a
+         * contact changes zone, which is where a backtracking Newton step zig-zags), so its minimiser is the root of the increasing function
+         * phi'(al) = grad F(x + al dx) . dx -- bracketed by doubling, then bisected */
+        double lo = 0.0, hi = 1.0, dhi = 0;
+        int ls;
+        for (ls = 0; ls < 60; ls++) {
+            for (int i = 0; i < nv; i++) xt[i] = x[i] + hi * dx[i];
+            newton_eval(nv, nr, Md, Jd, aref, Rr, a0, kind, blkdim, rowmu, xt, ftry, NULL);
+            dhi = 0;
+            for (int i = 0; i < nv; i++) {
+                double sg = 0;
+                for (int j = 0; j < nv; j++) sg += Md[i * nv + j] * (xt[j] - a0[j]);
+                for (int r = 0; r < nr; r++) sg -= Jd[(size_t)r * nv + i] * ftry[r];
+                dhi += sg * dx[i];
+            }
+            if (dhi >= 0) break;
+            lo = hi; hi *= 2.0;
+        }
+        double al = hi;
+        if (dhi > 0) {
+            for (int b = 0; b < 80; b++) {
+                al = 0.5 * (lo + hi);
+                for (int i = 0; i < nv; i++) xt[i] = x[i] + al * dx[i];
+                newton_eval(nv, nr, Md, Jd, aref, Rr, a0, kind, blkdim, rowmu, xt, ftry, NULL);
+                double dm_ = 0;
+                for (int i = 0; i < nv; i++) {
+                    double sg = 0;
+                    for (int j = 0; j < nv; j++) sg += Md[i * nv + j] * (xt[j] - a0[j]);
+                    for (int r = 0; r < nr; r++) sg -= Jd[(size_t)r * nv + i] * ftry[r];
+                    dm_ += sg * dx[i];
+                }
+                if (dm_ > 0) hi = al; else lo = al;
+                if (hi - lo <= 1e-15 * hi) break;
+            }
+            al = 0.5 * (lo + hi);
+        }
+        for (int i = 0; i < nv; i++) xt[i] = x[i] + al * dx[i];
+        if (getenv("ORC_NEWTON_DEBUG")) fprintf(stderr, "newton it=%d cost=%.17g |g|=%.3g slope=%.3g al=%.3g\n", it, cost, sqrt(gn), slope, al);
+        for (int i = 0; i < nv; i++) x[i] = xt[i];
+    }
+    newton_eval(nv, nr, Md, Jd, aref, Rr, a0, kind, blkdim, rowmu, x, f, NULL);
+    if (getenv("ORC_NEWTON_DEBUG2")) {
+        for (int i = 0; i < nr; i++) {
+            double z = -aref[i];
+            for (int d = 0; d < nv; d++) z += Jd[(size_t)i * nv + d] * x[d];
+            fprintf(stderr, "row %d kind %d blk %d z=%g R=%g f=%g z+Rf=%g mu=%g\n", i, kind[i], blkdim[i], z, Rr[i], f[i], z + Rr[i] * f[i], kind[i] == 2 ? rowmu[i][0] : 0.0);
+        }
+    }
+    for (int i = 0; i < nr; i++) f_out[i] = (real)f[i];
+    free(Md);
+    return it;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* one physics substep == mujoco.mj_step (reach_cube_env.py:276-277) -- MJ-DOC restatement          */
 /* ------------------------------------------------------------------------------------------------ */
@@ -801,6 +1186,8 @@ typedef struct {
     uint32_t active_mask;  /* OR over the substeps of the control step: bit = warm-slot id of an active contact (0..17), 18+j joint-limit of dof j */
     uint32_t active_count; /* sum over the substeps of the number of active contacts + limits */
     uint32_t max_sweeps;   /* largest PGS sweep count of a substep (adaptive mode) */
+    double kkt;            /* largest KKT natural residual of a substep's solution (orc_io.kkt), only when asked for */
+    int want_kkt;
     uint32_t choice;       /* wrapping sum over substeps s (weight 2s+1) and active constraints of (slot+1)(sel+1) 2654435761: the discrete choices
                               behind the contacts (which vertex, manifold candidate, box face, proxy member, limit side), plus the
                               number of IK iterations x 0x9E3779B1 */
@@ -986,7 +1373,12 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         /* pgs_iters > 0: exactly that many sweeps.  pgs_iters < 0 ("converged" mode): sweep until the largest force change of
          * a sweep is <= pgs_tol * (1 + largest |force|), at most ORC_PGS_CAP sweeps */
         const int adaptive = P->pgs_iters < 0;
-        const int max_it = adaptive ? ORC_PGS_CAP : P->pgs_iters;
+        int max_it = adaptive ? (P->pgs_cap > 0 ? P->pgs_cap : ORC_PGS_CAP) : P->pgs_iters;
+        if (P->solver == 1) {   /* the exact optimum of the convex problem (primal Newton, as MuJoCo's default solver) instead of PGS sweeps */
+            const int nit = newton_primal(nv, nr, M, J, aref, Rr, a0, kind, blkdim, rowmu, f, 100);
+            if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
+            max_it = 0;
+        }
         double lastchange = 0;
         int sweeps = 0;
         for (int it = 0; it < max_it; it++) {
@@ -995,13 +1387,38 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             real f_start[MAX_ROWS];   /* stopping test of the converged mode: NET change of a row over the sweep (after the cone projection) */
             for (int i = 0; i < nr; i++) f_start[i] = f[i];
             for (int i = 0; i < nr; i++) {
+                if (P->cone == 2 && kind[i] == 1) {   /* block at the apex: escape if zero is not its optimum, then the ordinary row updates */
+                    int at_apex = 1;
+                    for (int r = 0; r < blkdim[i]; r++) at_apex = at_apex && f[i + r] == 0;
+                    if (at_apex) pgs_apex_escape(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i]);
+                }
+                if ((P->cone == 3 || P->cone == 4) && kind[i] == 2) continue;
+                if ((P->cone == 3 || P->cone == 4) && kind[i] == 1) { pgs_block_pg(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i], P->cone == 4, T->walls); continue; }
+                if (P->cone == 1 && kind[i] == 2) continue;                      /* (handled with its block below) */
+                if (P->cone == 1 && kind[i] == 1) { pgs_block_exact(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i]); continue; }
                 real res = bvec[i] + Rr[i] * f[i];
                 for (int j = 0; j < nr; j++) res += A[(size_t)i * nr + j] * f[j];
                 real old = f[i];
                 real nf = f[i] - res / (A[(size_t)i * nr + i] + Rr[i]);
-                if (kind[i] != 2 && nf < 0) nf = 0; /* unilateral rows */
+                if (kind[i] != 2 && nf < 0 && !(P->cone >= 5 && kind[i] == 1)) nf = 0; /* unilateral rows (hybrid study: the contact normal is left to the projection) */
                 f[i] = nf;
                 (void)old;
+                if (P->cone >= 5 && kind[i] == 2 && i == blk0[i] + blkdim[i] - 1) {
+                    /* (study) row-by-row updates as in cone = 0, then the closed-form projection onto the second-order cone in the scaled variables
+                     * (5: Euclidean, w = 1/2; 6: weighted by the diagonal curvatures) instead of the radial scaling with a clamped normal */
+                    const int i0 = blk0[i], dm = blkdim[i];
+                    const double *mu = rowmu[i];
+                    double s2 = 0, dt = 0;
+                    for (int r = 1; r < dm; r++) { const double x = (double)f[i0 + r] / mu[r - 1]; s2 += x * x; dt += mu[r - 1] * mu[r - 1] * ((double)A[(size_t)(i0 + r) * nr + i0 + r] + (double)Rr[i0 + r]); }
+                    const double N = sqrt(s2), d0 = (double)A[(size_t)i0 * nr + i0] + (double)Rr[i0];
+                    const double w = P->cone == 6 ? d0 / (d0 + dt / (dm - 1)) : 0.5;
+                    double y0 = (double)f[i0], a = w * y0 + (1 - w) * N;
+                    if (a > y0) y0 = a;
+                    if (y0 < 0) y0 = 0;
+                    const double sc = N > y0 ? y0 / N : 1.0;
+                    f[i0] = (real)y0;
+                    for (int r = 1; r < dm; r++) f[i0 + r] = (real)((double)f[i0 + r] * sc);
+                } else
                 if (kind[i] == 2 && i == blk0[i] + blkdim[i] - 1) {
                     /* last friction row of this contact: project onto the elliptic cone (D2) */
                     const int i0 = blk0[i], dm = blkdim[i];
@@ -1024,6 +1441,10 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         }
         for (int i = 0; i < nr; i++)
             for (int d = 0; d < nv; d++) qfc[d] += J[(size_t)i * nv + d] * f[i];
+        if (lag->want_kkt) {
+            const double k = kkt_residual(A, nr, bvec, Rr, f, kind, blkdim, rowmu);
+            if (k > lag->kkt) lag->kkt = k;
+        }
         free(MiJt); free(A);
         if ((uint32_t)sweeps > lag->max_sweeps) lag->max_sweeps = (uint32_t)sweeps;
         if (diag) { g_diag_res = lastchange; }
@@ -1086,6 +1507,9 @@ void orc_default_params(orc_params *p, int task) {
     p->arm_collision = 1;
     p->pgs_tol = 1e-6;
     p->cc_points = 4;
+    p->cone = 3;      /* block projected gradient in the second-order-cone variables: what the kernels run (round 4) */
+    p->pgs_cap = 0;   /* 50 */
+    p->solver = 0;    /* PGS (what the kernels run) */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
@@ -1344,6 +1768,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     lag_t lag;
     warm_t warm_local, *warmp = &warm_local;
     memset(&lag, 0, sizeof lag);
+    lag.want_kkt = io->kkt != NULL;
     memset(&warm_local, 0, sizeof warm_local);
     /* The constraint forces of the last substep warm-start the first substep of the next control step (io->warm, one warm_t per env, zero
      * after reset), as MuJoCo carries mjData.qacc_warmstart across mj_step calls and the reference never resets it between env.step calls.
@@ -1354,6 +1779,7 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];
     if (io->sim_time) io->sim_time[e] += P->n_substeps * H_STEP; /* data.time advances in mj_step only */
+    if (io->kkt) io->kkt[e] = lag.kkt;
     if (io->active_mask) {
         io->active_mask[e] = lag.active_mask; io->active_count[e] = lag.active_count; io->max_sweeps[e] = lag.max_sweeps;
         io->choice[e] = lag.choice + (uint32_t)ik_iters * 0x9E3779B1u;

@@ -37,6 +37,9 @@ class OrcParams(ctypes.Structure):
         ("condim6", ctypes.c_int32),
         ("proxy_groups", ctypes.c_int32),
         ("cc_points", ctypes.c_int32),
+        ("cone", ctypes.c_int32),       # 0: radial projection onto the cone (D2, = the kernels); 1: MuJoCo's per-contact block update with the exact friction QCQP
+        ("pgs_cap", ctypes.c_int32),    # most sweeps of the converged mode (0 = 50)
+        ("solver", ctypes.c_int32),     # 0: PGS (= the kernels); 1: primal Newton to machine precision (exact optimum of MuJoCo's convex problem)
     ]
 
 
@@ -63,6 +66,7 @@ class OrcIO(ctypes.Structure):
         ("max_sweeps", ctypes.c_void_p),
         ("choice", ctypes.c_void_p),
         ("warm", ctypes.c_void_p),
+        ("kkt", ctypes.c_void_p),
     ]
 
 
@@ -103,7 +107,7 @@ def _p(a):
 class Oracle:
     """n independent envs stepped on the CPU, AoS arrays (env-major)."""
 
-    def __init__(self, task, n, f32=False, **kw):
+    def __init__(self, task, n, f32=False, kkt=False, **kw):
         self.L = lib(f32)
         self.task = TASKS[task] if isinstance(task, str) else int(task)
         self.n = n
@@ -140,11 +144,14 @@ class Oracle:
         self.choice = np.zeros(n, np.uint32)
         # constraint forces carried between control steps (opaque records; zero them when a state is set from outside)
         self.warm = np.zeros((n, (self.L.orc_warm_bytes() + 7) // 8 * 8), np.uint8)
+        # solver-independent optimality certificate of the contact solve (orc_io.kkt): computed only on request (O(rows^2) per substep)
+        self.kkt = np.zeros(n) if kkt else None
         self.io = OrcIO(
             _p(self.qpos), _p(self.qvel), _p(self.ee_lag), _p(self.target), _p(self.elapsed), _p(self.rng),
             _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.reward64), _p(self.terminated),
             _p(self.truncated), _p(self.is_success), _p(self.did_reset), _p(self.goal), _p(self.sim_time),
             _p(self.active_mask), _p(self.active_count), _p(self.max_sweeps), _p(self.choice), _p(self.warm),
+            _p(self.kkt) if kkt else None,
         )
 
     def reset(self, seeds=None, mask=None):

@@ -1,5 +1,5 @@
-"""Accuracy of the default contact solve (4 warm-started PGS sweeps, deviation D1) against a converged solve (300 cold sweeps)
-of the same model, measured with the CPU oracle on contact-rich random rollouts.  All variants start every control step from the same
+"""Accuracy of the default contact solve (4 warm-started sweeps, deviation D1) against the exact optimum of the same model (primal Newton,
+orc_params.solver = 1), measured with the CPU oracle on contact-rich random rollouts.  All variants start every control step from the same
 state; the difference after ONE control step (20 substeps) is reported for
   cold     the forces start from zero at every control step (LCR_COMPAT_COLD_SOLVE_EACH_STEP; the only mode before round 2), and
   carried  the forces of the last substep warm-start the next control step (default; MuJoCo's qacc_warmstart does the same).
@@ -15,7 +15,9 @@ COLD = 2   # ORC_COMPAT_COLD_SOLVE_EACH_STEP
 def measure(task, n=512, steps=50, seed=3):
     cold = orc.Oracle(task, n, pgs_iters=4, compat=COLD, auto_reset=0, max_episode_steps=0)
     carried = orc.Oracle(task, n, pgs_iters=4, compat=0, auto_reset=0, max_episode_steps=0)
-    ref = orc.Oracle(task, n, pgs_iters=300, warm_start=0, compat=COLD, auto_reset=0, max_episode_steps=0)
+    # reference: the EXACT optimum of every substep's convex problem (primal Newton, orc_params.solver = 1, certified by orc_io.kkt) -- rounds 1-3 compared
+    # against 300 cold sweeps of the same iteration, whose fixed point was not the optimum (tools/kkt_distance.py)
+    ref = orc.Oracle(task, n, solver=1, auto_reset=0, max_episode_steps=0)
     seeds = np.arange(n, dtype=np.uint64) + 1000
     for o in (cold, carried, ref):
         o.reset(seeds)
