@@ -764,6 +764,121 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 fmx = fmaxf(fmaxf(fmx, fmaxf(fabsf(f0), fabsf(f1))), fmaxf(fabsf(f2), fabsf(f3_)));
             }
         };
+        // ---- one arm-coupled slot (finger spheres, arm-link proxies): a block step on its rows ----
+        // The rows of a sweep form two groups that are swept as if concurrently (what the two-wave kernels do with two waves; oracle: orc_params.jacobi) --
+        //   A: joint limits, finger<->floor (slots 2, 3), arm-link proxies (slot 4)          B: floor<->cube, cube<->cube, rails, finger<->cube (slots 0, 1)
+        // Gauss-Seidel inside a group; a group sees the other group's effect on the shared unknowns (the arm acceleration y through slots 0, 1; the cube
+        // accelerations through slot 4) as of the START of the sweep.  In program order group A runs first: y then carries A's changes, yB keeps the sweep-start
+        // value for slots 0, 1 (whose changes go to both copies), and slot 4's change of the cube accelerations is held back in dcaA until the end of the sweep.
+        float yB[6];
+        f3 dcaA[NC], dcalA[NC];
+#pragma unroll
+        for (int k = 0; k < 6; k++) yB[k] = y[k];
+#pragma unroll
+        for (int c = 0; c < NC; c++) { dcaA[c] = mk(0.f, 0.f, 0.f); dcalA[c] = mk(0.f, 0.f, 0.f); }
+        auto arm_slot = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if (!wave_arm || !slot_any[s]) return;
+            ArmSlot<NRW> &T = AS[s];
+            const bool may_cube = s < 2 || s == 4;
+            const bool oncube = s < 2 || (s == 4 && link_on_cube);
+            constexpr bool roll = ROLL;
+            const int nrow = (roll && s < 2) ? 6 : 4;
+            const float Rf = T.Rn * P.inv_impratio;
+            const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
+            // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
+            float2v g[NRW][3];
+#pragma unroll
+            for (int r = 0; r < nrow; r++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    g[r][k] = (NC == 2 && !BIG && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
+                              : (NC == 2 && !BIG && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
+                                                  : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+            // group B (finger<->cube, s < 2) works from y as of the start of the sweep (yB) and its changes go to BOTH copies; group A (s >= 2) works on y
+            float2v yp[3] = {{s < 2 ? yB[0] : y[0], s < 2 ? yB[1] : y[1]}, {s < 2 ? yB[2] : y[2], s < 2 ? yB[3] : y[3]}, {s < 2 ? yB[4] : y[4], s < 2 ? yB[5] : y[5]}};
+            float2v yq[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
+            float arefv[NRW], invv[NRW], f_in[NRW];
+#pragma unroll
+            for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; f_in[r] = T.f[r]; }
+            // pick the cube this slot talks to (wave-divergent only for Stack)
+            f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
+            const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
+            if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+            // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
+            const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
+            // the cube's share of the gradient rows: v_r = d_r . (acceleration of the cube's contact point), wn / w1 / w2 = (n, t1, t2) . (angular acceleration)
+            float vq[3] = {0.f, 0.f, 0.f}, wn = 0.f, w1 = 0.f, w2 = 0.f;
+            if (may_cube) {
+                const f3 Ac = a_lin + cross(a_ang, T.rc);
+                vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
+                wn = dot(T.n, a_ang);
+                if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
+                if (s == 4) {   // floor lanes: no cube share in the rows
+#pragma unroll
+                    for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
+                    wn = oncube ? wn : 0.f;
+                }
+            }
+            // gradient rows of the block from the SAME forces (no serial dependence inside the block), one projected-gradient step (soc_step), then y follows
+            float u[NRW], fcur[NRW], nf[NRW];
+#pragma unroll
+            for (int r = 0; r < NRW; r++) {
+                fcur[r] = T.f[r];
+                u[r] = 0.f;
+                if (r < nrow) {
+                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                    const float gy = acc.x + acc.y;
+                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
+                    u[r] = gy + jc_a - arefv[r] + Rr * fcur[r];
+                }
+            }
+            {   // (finger geoms: mu 1.5 / torsional 0.005; finger<->cube pair: max rule; a link proxy on the floor: mu 1, on a cube: the cube's friction)
+                const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
+                const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
+                soc_step<NRW, WALLS>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
+            }
+#pragma unroll
+            for (int r = 0; r < NRW; r++) {
+                if (r < nrow) {
+                    const float dlt = nf[r] - fcur[r];
+                    T.f[r] = nf[r];
+                    const float2v d2 = {dlt, dlt};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { yp[k] = g[r][k] * d2 + yp[k]; if (s < 2) yq[k] = g[r][k] * d2 + yq[k]; }
+                }
+            }
+            // (converged mode: the net force change of this sweep)
+            track(T.f[0] - f_in[0], T.f[1] - f_in[1], T.f[2] - f_in[2], T.f[3] - f_in[3], T.f[0], T.f[1], T.f[2], T.f[3]);
+            if constexpr (ROLL) { if (nrow == 6) track(T.f[4] - f_in[4], T.f[5] - f_in[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
+            f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
+            if (may_cube) {
+                const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
+                const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
+                dl_lin = (-minv_e) * Fd;
+                f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
+                if constexpr (ROLL) { if (nrow == 6) Td = axpy(T.f[4] - f_in[4], T.t1, axpy(T.f[5] - f_in[5], T.t2, Td)); }
+                dl_ang = (-iinv_e) * Td;
+            }
+            if (s < 2) {
+                yB[0] = yp[0].x; yB[1] = yp[0].y; yB[2] = yp[1].x; yB[3] = yp[1].y; yB[4] = yp[2].x; yB[5] = yp[2].y;
+                y[0] = yq[0].x; y[1] = yq[0].y; y[2] = yq[1].x; y[3] = yq[1].y; y[4] = yq[2].x; y[5] = yq[2].y;
+            } else {
+                y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
+            }
+            if (may_cube) {
+                // slots 0, 1 (group B) change the cube accelerations the group is sweeping; slot 4 (group A) read them as of the start of the sweep (it runs
+                // before group B's rows) and its change is held back until the end of the sweep
+                f3 (&tca)[NC] = s == 4 ? dcaA : ca;
+                f3 (&tcal)[NC] = s == 4 ? dcalA : cal;
+                if (NC == 2) {
+                    if (second) { tca[NC - 1] = tca[NC - 1] + dl_lin; tcal[NC - 1] = tcal[NC - 1] + dl_ang; }
+                    else { tca[0] = tca[0] + dl_lin; tcal[0] = tcal[0] + dl_ang; }
+                } else { tca[0] = tca[0] + dl_lin; tcal[0] = tcal[0] + dl_ang; }
+            }
+        };
         if (wave_lim) {
 #pragma unroll
             for (int j = 0; j < 6; j++) {
@@ -790,6 +905,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], dl, y[k]);
             }
         }
+        // group A: finger<->floor, arm-link proxies (after the joint limits above)
+        arm_slot(std::integral_constant<int, 2>{});
+        arm_slot(std::integral_constant<int, 3>{});
+        arm_slot(std::integral_constant<int, 4>{});
         // floor <-> cube
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -899,101 +1018,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
         }
-        // arm-coupled slots: finger spheres, arm-link proxies
-        if (wave_arm) {
+        // group B, second part: finger<->cube
+        arm_slot(std::integral_constant<int, 0>{});
+        arm_slot(std::integral_constant<int, 1>{});
 #pragma unroll
-            for (int s = 0; s < NAS; s++) {
-                if (!slot_any[s]) continue;
-                ArmSlot<NRW> &T = AS[s];
-                const bool may_cube = s < 2 || s == 4;
-                const bool oncube = s < 2 || (s == 4 && link_on_cube);
-                constexpr bool roll = ROLL;
-                const int nrow = (roll && s < 2) ? 6 : 4;
-                const float Rf = T.Rn * P.inv_impratio;
-                const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
-                // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
-                float2v g[NRW][3];
-#pragma unroll
-                for (int r = 0; r < nrow; r++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-                        g[r][k] = (NC == 2 && !BIG && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
-                                  : (NC == 2 && !BIG && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
-                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
-                float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
-                float arefv[NRW], invv[NRW], f_in[NRW];
-#pragma unroll
-                for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; f_in[r] = T.f[r]; }
-                // pick the cube this slot talks to (wave-divergent only for Stack)
-                f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
-                const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
-                if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
-                // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
-                const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
-                // the cube's share of the gradient rows: v_r = d_r . (acceleration of the cube's contact point), wn / w1 / w2 = (n, t1, t2) . (angular acceleration)
-                float vq[3] = {0.f, 0.f, 0.f}, wn = 0.f, w1 = 0.f, w2 = 0.f;
-                if (may_cube) {
-                    const f3 Ac = a_lin + cross(a_ang, T.rc);
-                    vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
-                    wn = dot(T.n, a_ang);
-                    if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
-                    if (s == 4) {   // floor lanes: no cube share in the rows
-#pragma unroll
-                        for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
-                        wn = oncube ? wn : 0.f;
-                    }
-                }
-                // gradient rows of the block from the SAME forces (no serial dependence inside the block), one projected-gradient step (soc_step), then y follows
-                float u[NRW], fcur[NRW], nf[NRW];
-#pragma unroll
-                for (int r = 0; r < NRW; r++) {
-                    fcur[r] = T.f[r];
-                    u[r] = 0.f;
-                    if (r < nrow) {
-                        const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
-                        const float gy = acc.x + acc.y;
-                        float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
-                        float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
-                        if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
-                        u[r] = gy + jc_a - arefv[r] + Rr * fcur[r];
-                    }
-                }
-                {   // (finger geoms: mu 1.5 / torsional 0.005; finger<->cube pair: max rule; a link proxy on the floor: mu 1, on a cube: the cube's friction)
-                    const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
-                    const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
-                    soc_step<NRW, WALLS>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
-                }
-#pragma unroll
-                for (int r = 0; r < NRW; r++) {
-                    if (r < nrow) {
-                        const float dlt = nf[r] - fcur[r];
-                        T.f[r] = nf[r];
-                        const float2v d2 = {dlt, dlt};
-#pragma unroll
-                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
-                    }
-                }
-                // (converged mode: the net force change of this sweep)
-                track(T.f[0] - f_in[0], T.f[1] - f_in[1], T.f[2] - f_in[2], T.f[3] - f_in[3], T.f[0], T.f[1], T.f[2], T.f[3]);
-                if constexpr (ROLL) { if (nrow == 6) track(T.f[4] - f_in[4], T.f[5] - f_in[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
-                f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
-                if (may_cube) {
-                    const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
-                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
-                    dl_lin = (-minv_e) * Fd;
-                    f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
-                    if constexpr (ROLL) { if (nrow == 6) Td = axpy(T.f[4] - f_in[4], T.t1, axpy(T.f[5] - f_in[5], T.t2, Td)); }
-                    dl_ang = (-iinv_e) * Td;
-                }
-                y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
-                if (may_cube) {
-                    if (NC == 2) {
-                        if (second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }
-                        else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
-                    } else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
-                }
-            }
-        }
+        for (int c = 0; c < NC; c++) { ca[c] = ca[c] + dcaA[c]; cal[c] = cal[c] + dcalA[c]; }   // group A's share of the cube accelerations (slot 4)
         sweeps_done = it + 1;
         if (ADAPT) {
             if (__all(chg <= P.pgs_tol * (1.f + fmx))) break;

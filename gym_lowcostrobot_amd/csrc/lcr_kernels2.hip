@@ -35,6 +35,19 @@
 // :313-348 and the per-task files, reset :297-311); the arithmetic of every block is the one of lcr_kernels.hip, regrouped by owner.
 #include "lcr_step_common.h"
 
+#ifndef LCR_EXP_PRIOA
+#define LCR_EXP_PRIOA 2
+#endif
+#ifndef LCR_EXP_HOT
+#define LCR_EXP_HOT 1
+#endif
+#ifndef LCR_EXP_PRIOB_PRE
+#define LCR_EXP_PRIOB_PRE 3
+#endif
+#ifndef LCR_EXP_PRIOB_POST
+#define LCR_EXP_PRIOB_POST 0
+#endif
+
 #ifndef LCR_PART
 #define LCR_PART (-1)
 #endif
@@ -256,7 +269,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         for (int j = 0; j < 6; j++) { ph[j * 64] = ctrl[j]; ph[(6 + j) * 64] = q[j]; }
     }
     wg_barrier();   // E0: wave B has published the initial cube pose
-    __builtin_amdgcn_s_setprio(2);   // where two waves share a SIMD the arm wave is the longer chain: it wins the issue arbitration
+    __builtin_amdgcn_s_setprio(LCR_EXP_PRIOA);   // where two waves share a SIMD the arm wave is the longer chain: it wins the issue arbitration
     bool hot = false;                 // this workgroup has had a coupled substep in this step
 
     // profiling aid (lcr_config.diagnostics = 3): cycles of this wave in total / waiting at barriers / before barrier 1, coupled substeps
@@ -612,7 +625,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         if (prof) pf_wait += clock64() - pf_mark;
         const bool c01 = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // wave B: a finger sphere touches a cube in some lane
         const bool coupled = c01 || cube4;
-        if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }   // (see wave B)
+        if (coupled && !hot && LCR_EXP_HOT) { hot = true; __builtin_amdgcn_s_setprio(3); }   // (see wave B)
         if (prof) pf_coupled += coupled ? 1u : 0u;
         if (c01) {   // warm-start forces of the finger<->cube slots act on the arm too: wave B's sum of g_r f_r
 #pragma unroll
@@ -736,22 +749,6 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         };
         using I2 = std::integral_constant<int, 2>; using I5 = std::integral_constant<int, NAS>;
         using I4 = std::integral_constant<int, 4>;
-        float *xcc_ = lds + LL::POSE0 + lane;   // hand-over place of the cube accelerations in coupled sweeps (the pose area is idle then)
-        auto read_cube_acc = [&]() {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const float *pa = xcc_ + (size_t)c * 6 * 64;
-                ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
-            }
-        };
-        auto write_cube_acc = [&]() {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                float *pa = xcc_ + (size_t)c * 6 * 64;
-                pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
-                pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
-            }
-        };
         auto bar = [&]() {
             if (prof) pf_mark = clock64();
             wg_barrier();
@@ -762,44 +759,65 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 limit_rows();
                 arm_rows(std::false_type{}, I2{}, I5{});
             }
-        } else if (c01 && !cube4) {
-            // finger spheres on a cube: the arm acceleration y visits wave B between the limit rows and slots 2-4 (Gauss-Seidel order
-            // limits -> cube rows -> slots 0, 1 -> slots 2-4); wave B's next pass over the cube rows overlaps with slots 2-4 here
-            for (int it = 0; it < P.pgs_iters; it++) {
-                limit_rows();
-#pragma unroll
-                for (int j = 0; j < 6; j++) xacc[j * 64] = y[j];
-                bar();   // S1: y -> wave B
-                bar();   // S2: y <- wave B (after its slots 0, 1)
-#pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = xacc[j * 64];
-                arm_rows(std::false_type{}, I2{}, I5{});
-            }
-        } else if (!c01) {
-            // only a gripper-body proxy (slot 4) touches a cube: the cube accelerations visit this wave for slot 4
-            for (int it = 0; it < P.pgs_iters; it++) {
-                limit_rows();
-                arm_rows(std::false_type{}, I2{}, I4{});
-                bar();   // S1: ca / cal <- wave B (after its cube rows)
-                read_cube_acc();
-                arm_rows(std::true_type{}, I4{}, I5{});
-                write_cube_acc();
-                bar();   // S2: ca / cal -> wave B
-            }
         } else {
+            // A finger sphere (c01) or a gripper-body proxy (cube4) of some lane touches a cube: the two waves' row groups now share unknowns -- the arm acceleration y
+            // (wave B's slots 0, 1) and / or the cube accelerations (this wave's slot 4).  The groups still sweep CONCURRENTLY: each works from the accelerations as
+            // they were at the start of the sweep plus its OWN changes, and the changes are merged at the end of the sweep (block Jacobi between the two groups --
+            // for two blocks of a positive definite problem that always converges; Gauss-Seidel inside each group; the oracle's sweep is defined the same way,
+            // orc_params.jacobi).  Until round 4 such a sweep was serialised (y and the cube accelerations visited the other wave between its row groups), which made
+            // the workgroups with a finger on a cube the slowest of every launch.  Hand-overs, single-buffered between barriers:
+            //   ACC[0..5]          YA   A -> B  this wave's y after its rows (c01) -- then, B -> A, CAN: the merged cube accelerations (cube4; wave B writes them after it
+            //                                   has read YA, this wave never reads YA)
+            //   POSE[0..5]         DYB  B -> A  change of y by slots 0, 1 (c01)
+            //   POSE[6..6+6 NC)    DCA  A -> B  change of the cube accelerations by slot 4 (cube4)
+            // Merged values are formed by the same expression on both sides (yA + DYB, caB + DCA): the two waves' copies of y stay bit-identical.
+            // Before the first sweep the same fields carry the start values the other way round (y: A -> B in POSE[0..5], cube accelerations: B -> A in ACC).
+            // Rule that makes this race-free without further barriers: a field is only ever OVERWRITTEN by the wave that last READ it.
+            float *xdyb = xpose, *xdca = xpose + (size_t)6 * 64;
+            if (c01) {   // (this wave has read dy01 from these fields just above)
+#pragma unroll
+                for (int j = 0; j < 6; j++) xdyb[j * 64] = y[j];
+            }
+            bar();   // P0: y at the start of the first sweep -> wave B; wave B's cube accelerations -> this wave
+            if (cube4) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float *pa = xacc + (size_t)c * 6 * 64;
+                    ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
+                }
+            }
             for (int it = 0; it < P.pgs_iters; it++) {
+                f3 ca_in[NC], cal_in[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) { ca_in[c] = ca[c]; cal_in[c] = cal[c]; }
                 limit_rows();
-#pragma unroll
-                for (int j = 0; j < 6; j++) xacc[j * 64] = y[j];
-                bar();   // S1
-                bar();   // S2: y and ca / cal <- wave B
-#pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = xacc[j * 64];
-                read_cube_acc();
                 arm_rows(std::false_type{}, I2{}, I4{});
-                arm_rows(std::true_type{}, I4{}, I5{});
-                write_cube_acc();
-                bar();   // S3: ca / cal -> wave B
+                if (cube4) arm_rows(std::true_type{}, I4{}, I5{}); else arm_rows(std::false_type{}, I4{}, I5{});
+                if (c01) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) xacc[j * 64] = y[j];
+                }
+                if (cube4) {   // what slot 4 changed
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        float *pa = xdca + (size_t)c * 6 * 64;
+                        const f3 dl = ca[c] - ca_in[c], da = cal[c] - cal_in[c];
+                        pa[0] = dl.x; pa[64] = dl.y; pa[128] = dl.z; pa[192] = da.x; pa[256] = da.y; pa[320] = da.z;
+                    }
+                }
+                bar();   // W: everything of this sweep is written
+                if (c01) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) y[j] += xdyb[j * 64];
+                }
+                bar();   // R: everything is read; with cube4 wave B has left the merged cube accelerations in ACC
+                if (cube4) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const float *pa = xacc + (size_t)c * 6 * 64;
+                        ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
+                    }
+                }
             }
         }
 
@@ -1077,7 +1095,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     bool hot = false;   // this workgroup has had a coupled substep in this step
     for (int sub = 0; sub < P.n_substeps; sub++) {
         Diag DG = {0u, 0u, 0u, 0u};
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(LCR_EXP_PRIOB_PRE);
         // ---- forward kinematics (this wave's own: cheaper than moving 72 floats through LDS) and, unless the arm wave keeps it (two cubes:
         //      this wave is the busier one there), the smooth joint forces tau -> wave A ----
         ArmFrames F;
@@ -1095,7 +1113,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         if (prof) pf_mark = clock64();
         wg_barrier();   // X: tau is in LDS for wave A; wave A's Cholesky factor of the joint-space inertia is in LDS
         if (prof) pf_wait += clock64() - pf_mark;
-        if (!hot) __builtin_amdgcn_s_setprio(0);
+        if (!hot) __builtin_amdgcn_s_setprio(LCR_EXP_PRIOB_POST);
         Chol6 CL;
         {
             const float *pl = lds + LL::LFAC0 + lane;
@@ -1238,6 +1256,57 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             for (int j = 0; j < 6; j++) xpose[j * 64] = dy01[j];
         }
 
+        // (built here, right after the rows of slots 0, 1 -- the last users of the factor L -- and before the floor / cube<->cube / rail rows: the ~50 per-slot constants of
+        //  those rows are then not live across this block, which is where this wave's register demand peaks)
+        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.  What wave A needs for it is
+        // built here and handed over; wave A finishes the solve itself at the end of its sweeps: no round trip, and neither factor outlives this block.
+        Chol6 CL2;
+        float Lf[6][6];
+        {
+            float Mm[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) Lf[i][j] = i == j ? rcp(CL.id[i]) : CL.L[i][j];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int k = 0; k <= j; k++) m = fmaf(Lf[i][k], Lf[j][k], m);
+                    Mm[i][j] = m + (i == j ? H * (DAMPING + KV) : 0.f);
+                }
+            chol6(Mm, CL2);
+        }
+        // (M + hD) = G G^T.  Wave A needs qacc = (M + hD)^-1 L y = G^-T (V y) with V = G^-1 L (lower triangular): this wave hands over V (21) and G (15 + 6
+        // inverse diagonals) -- six forward substitutions on columns that start with zeros, a quarter of the work of Wm = G^-T V -- and wave A finishes with 21 + 21
+        // multiply-adds.  Place (42 fields: V row-major, G's strict lower part row-major, G's inverse diagonal): the idle LDS rows of slots 0, 1; with a finger on a
+        // cube those rows are in use and the record goes to its own LDS place (build for one wave per SIMD) or to this lane's global scratch record (168 B; the build for
+        // two waves per SIMD has no LDS left, and keeping the factors for a solve after the sweeps would cost this wave registers it does not have at the 256-register cap)
+        auto hand_over = [&](auto glob_tag) {
+            constexpr bool GLOB = decltype(glob_tag)::value;
+            float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
+            float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
+            auto put = [&](int f, float v) { if (GLOB) gw[f] = v; else pw[f * 64] = v; };
+#pragma unroll
+            for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of V
+                float col[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) col[i] = i < j ? 0.f : Lf[i][j];
+                fsub(CL2, col);
+#pragma unroll
+                for (int i = j; i < 6; i++) put(i * (i + 1) / 2 + j, col[i]);
+            }
+#pragma unroll
+            for (int i = 1; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < i; j++) put(21 + i * (i - 1) / 2 + j, CL2.L[i][j]);
+#pragma unroll
+            for (int i = 0; i < 6; i++) put(36 + i, CL2.id[i]);
+            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
+        };
+        if (GW && c01) hand_over(std::true_type{}); else hand_over(std::false_type{});
         // ---- collision: floor <-> cube (MuJoCo plane-box: penetrating vertices in index order, at most 4) ----
         FloorSlot FS[NC][4];
 #pragma unroll
@@ -1575,55 +1644,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
 
-        // implicitfast solve at the end of the substep: (M + h (damping + kv) I) qacc = L y, M = L L^T rebuilt from the factor.  What wave A needs for it is
-        // built here and handed over; wave A finishes the solve itself at the end of its sweeps: no round trip, and neither factor outlives this block.
-        Chol6 CL2;
-        float Lf[6][6];
-        {
-            float Mm[6][6];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j <= i; j++) Lf[i][j] = i == j ? rcp(CL.id[i]) : CL.L[i][j];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j <= i; j++) {
-                    float m = 0.f;
-#pragma unroll
-                    for (int k = 0; k <= j; k++) m = fmaf(Lf[i][k], Lf[j][k], m);
-                    Mm[i][j] = m + (i == j ? H * (DAMPING + KV) : 0.f);
-                }
-            chol6(Mm, CL2);
-        }
-        // (M + hD) = G G^T.  Wave A needs qacc = (M + hD)^-1 L y = G^-T (V y) with V = G^-1 L (lower triangular): this wave hands over V (21) and G (15 + 6
-        // inverse diagonals) -- six forward substitutions on columns that start with zeros, a quarter of the work of Wm = G^-T V -- and wave A finishes with 21 + 21
-        // multiply-adds.  Place (42 fields: V row-major, G's strict lower part row-major, G's inverse diagonal): the idle LDS rows of slots 0, 1; with a finger on a
-        // cube those rows are in use and the record goes to its own LDS place (build for one wave per SIMD) or to this lane's global scratch record (168 B; the build for
-        // two waves per SIMD has no LDS left, and keeping the factors for a solve after the sweeps would cost this wave registers it does not have at the 256-register cap)
-        auto hand_over = [&](auto glob_tag) {
-            constexpr bool GLOB = decltype(glob_tag)::value;
-            float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
-            float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
-            auto put = [&](int f, float v) { if (GLOB) gw[f] = v; else pw[f * 64] = v; };
-#pragma unroll
-            for (int j = 0; j < 6; j++) {   // column j of L (zero above the diagonal) -> column j of V
-                float col[6];
-#pragma unroll
-                for (int i = 0; i < 6; i++) col[i] = i < j ? 0.f : Lf[i][j];
-                fsub(CL2, col);
-#pragma unroll
-                for (int i = j; i < 6; i++) put(i * (i + 1) / 2 + j, col[i]);
-            }
-#pragma unroll
-            for (int i = 1; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j < i; j++) put(21 + i * (i - 1) / 2 + j, CL2.L[i][j]);
-#pragma unroll
-            for (int i = 0; i < 6; i++) put(36 + i, CL2.id[i]);
-            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
-        };
-        if (GW && c01) hand_over(std::true_type{}); else hand_over(std::false_type{});
         if (prof) pf_mark = clock64();
         wg_barrier();   // B1: wave A has set up its rows and decided whether this substep is coupled
         if (prof) pf_wait += clock64() - pf_mark;
@@ -1631,7 +1651,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         const bool coupled = c01 || cube4;
         // A workgroup with coupled substeps is the one a launch waits for (its two chains run in series): from its first coupled substep on both its
         // waves take the top issue priority for the rest of the step, so that where two waves share a SIMD the partner fills the gaps instead of halving them.
-        if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }
+        if (coupled && !hot && LCR_EXP_HOT) { hot = true; __builtin_amdgcn_s_setprio(3); }
         if (cube4) {   // warm-start forces of the proxy slot act on the cube too
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -1795,22 +1815,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 }
             }
         };
-        float *xcc_ = lds + LL::POSE0 + lane;   // hand-over place of the cube accelerations when a proxy touches a cube (pose area: idle during the sweeps)
-        auto write_cube_acc = [&]() {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                float *pa = xcc_ + (size_t)c * 6 * 64;
-                pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z;
-                pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
-            }
-        };
-        auto read_cube_acc = [&]() {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const float *pa = xcc_ + (size_t)c * 6 * 64;
-                ca[c] = mk(pa[0], pa[64], pa[128]); cal[c] = mk(pa[192], pa[256], pa[320]);
-            }
-        };
         auto bar = [&]() {
             if (prof) pf_mark = clock64();
             wg_barrier();
@@ -1818,38 +1822,46 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         };
         if (!coupled) {
             for (int it = 0; it < P.pgs_iters; it++) cube_rows();
-        } else if (c01 && !cube4) {
-            for (int it = 0; it < P.pgs_iters; it++) {
-                cube_rows();
-                bar();   // S1: y <- wave A (after its limit rows)
-#pragma unroll
-                for (int j = 0; j < 6; j++) yv[j] = xacc[j * 64];
-                finger_rows();
-#pragma unroll
-                for (int j = 0; j < 6; j++) xacc[j * 64] = yv[j];
-                bar();   // S2: y -> wave A (slots 2-4)
-            }
-        } else if (!c01) {
-            for (int it = 0; it < P.pgs_iters; it++) {
-                cube_rows();
-                write_cube_acc();
-                bar();   // S1: ca / cal -> wave A (slot 4 on a cube)
-                bar();   // S2: ca / cal <- wave A
-                read_cube_acc();
-            }
         } else {
+            // coupled substep: the two row groups sweep concurrently and merge their changes at the end of every sweep (protocol: see wave A)
+            float *xdyb = xpose, *xdca = xpose + (size_t)6 * 64;
+            float ystart[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (cube4) {   // this wave's accelerations after its row set-up (incl. slot 4's warm-start share) -> wave A, which needs them for slot 4 in the first sweep
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    float *pa = xacc + (size_t)c * 6 * 64;
+                    pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z; pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
+                }
+            }
+            bar();   // P0
+            if (c01) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) ystart[j] = xdyb[j * 64];
+            }
             for (int it = 0; it < P.pgs_iters; it++) {
                 cube_rows();
-                bar();   // S1
+                if (c01) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) yv[j] = xacc[j * 64];
-                finger_rows();
+                    for (int j = 0; j < 6; j++) yv[j] = ystart[j];
+                    finger_rows();
 #pragma unroll
-                for (int j = 0; j < 6; j++) xacc[j * 64] = yv[j];
-                write_cube_acc();
-                bar();   // S2: y and ca / cal -> wave A
-                bar();   // S3: ca / cal <- wave A
-                read_cube_acc();
+                    for (int j = 0; j < 6; j++) xdyb[j * 64] = yv[j] - ystart[j];
+                }
+                bar();   // W
+                if (c01) {   // merged y = wave A's y after its rows + this wave's change: the start of the next sweep (the same expression as on wave A)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) ystart[j] = xacc[j * 64] + xdyb[j * 64];
+                }
+                if (cube4) {   // merged cube accelerations = this wave's + slot 4's change; wave A reads them back from ACC after R (YA has been read above)
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const float *pd = xdca + (size_t)c * 6 * 64;
+                        ca[c] = ca[c] + mk(pd[0], pd[64], pd[128]); cal[c] = cal[c] + mk(pd[192], pd[256], pd[320]);
+                        float *pa = xacc + (size_t)c * 6 * 64;
+                        pa[0] = ca[c].x; pa[64] = ca[c].y; pa[128] = ca[c].z; pa[192] = cal[c].x; pa[256] = cal[c].y; pa[320] = cal[c].z;
+                    }
+                }
+                bar();   // R
             }
         }
 

@@ -915,7 +915,7 @@ static int pgs_apex_escape(const real *A, int nr, const real *bvec, const real *
  * second-order cone: y <- P_soc(y - g~ / Lb), g~ = (g_n, mu_j g_j) the block's gradient at the current forces and Lb = trace of the scaled block of A + R (an
  * upper bound of its largest eigenvalue, so the step never overshoots).  Fixed points are exactly the optima of the convex problem (no apex trap, no radial
  * bias), the cost per sweep is that of the row-by-row update, and all rows of a block are evaluated from the same forces (no serial dependence inside it). */
-static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr, real *f, int i0, int dm, const double *mu, int scalar_step, int sep) {
+static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr, real *f, const real *fsee, int i0, int dm, const double *mu, int scalar_step, int sep) {
     /* Projected-gradient step in the metric D = diag(Ln, Lt, .., Lt) of the scaled variables y = (f_n, f_j / mu_j):  y <- P_K^D(y - D^-1 g~).
      * Ln = 2 (A + R)_nn and Lt = 2 sum_j mu_j^2 (A + R)_jj majorise the scaled block (a PSD matrix is below k times its block diagonal for k diagonal blocks,
      * and a PSD block below its trace), so the step never increases the objective; its fixed points are exactly the optima.  The D-projection onto the
@@ -931,7 +931,7 @@ static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr
     const real kf = sep ? 3 : 2;
     for (int j = 0; j < dm; j++) {
         real s = bvec[i0 + j] + Rr[i0 + j] * f[i0 + j];
-        for (int m = 0; m < nr; m++) s += A[(size_t)(i0 + j) * nr + m] * f[m];
+        for (int m = 0; m < nr; m++) s += A[(size_t)(i0 + j) * nr + m] * fsee[m];
         u[j] = s;
         const real d = A[(size_t)(i0 + j) * nr + i0 + j] + Rr[i0 + j];
         if (j == 0) Ln = kf * d;
@@ -1280,6 +1280,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     real J[MAX_ROWS * ORC_NV_MAX], aref[MAX_ROWS], Rr[MAX_ROWS];
     int kind[MAX_ROWS]; /* 0 limit, 1 contact-normal (block start), 2 friction */
     int blk0[MAX_ROWS], blkdim[MAX_ROWS]; /* first row and row count of the contact a row belongs to */
+    int grp[MAX_ROWS];                    /* sweep group of the row (orc_params.jacobi) */
     real *wptr[MAX_ROWS]; /* where this row's force is kept between substeps */
     const double *rowmu[MAX_ROWS];
     int nr = 0;
@@ -1297,7 +1298,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             aref[nr] = (real)(-b * (double)vel - k * imp * (double)pos);
             double r = (1 - imp) / imp * g_inv_dof[j];
             Rr[nr] = (real)(r > MJ_MINVAL ? r : MJ_MINVAL);
-            kind[nr] = 0; rowmu[nr] = 0; blk0[nr] = nr; blkdim[nr] = 1;
+            kind[nr] = 0; rowmu[nr] = 0; blk0[nr] = nr; blkdim[nr] = 1; grp[nr] = 0;
             wptr[nr] = &warm->lim[2 * j + side];
             amask |= 1u << (18 + j);
             choice += (uint32_t)(18 + j + 1) * (uint32_t)(side + 1) * 2654435761u;
@@ -1339,6 +1340,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             kind[nr + r] = r == 0 ? 1 : 2;
             rowmu[nr + r] = ct->mu;
             blk0[nr + r] = nr; blkdim[nr + r] = ct->dim;
+            grp[nr + r] = (ct->slot >= 14 && ct->slot < 24) ? 0 : 1;   /* group A: finger<->floor, arm-link proxies (with the limits); group B: every row of a cube */
             wptr[nr + r] = &warm->slot[ct->slot][r];
         }
         nr += ct->dim;
@@ -1392,33 +1394,27 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                     for (int r = 0; r < blkdim[i]; r++) at_apex = at_apex && f[i + r] == 0;
                     if (at_apex) pgs_apex_escape(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i]);
                 }
+                /* orc_params.jacobi (default, = the kernels): the rows form two groups -- A: joint limits, finger<->floor, arm-link proxies (what the kernels' arm wave
+                 * owns); B: floor<->cube, cube<->cube, rails, finger<->cube (the cube wave) -- that sweep CONCURRENTLY: Gauss-Seidel inside a group, while the other
+                 * group's forces are seen as they were at the start of the sweep (block Jacobi between the two groups; for two blocks of a positive definite problem
+                 * that always converges).  The groups interact only where a finger or a gripper-body proxy touches a cube; everywhere else this IS Gauss-Seidel. */
+                const real *fsee = f;
+                real fmix[MAX_ROWS];
+                if (P->jacobi) {
+                    for (int m = 0; m < nr; m++) fmix[m] = grp[m] == grp[i] ? f[m] : f_start[m];
+                    fsee = fmix;
+                }
                 if ((P->cone == 3 || P->cone == 4) && kind[i] == 2) continue;
-                if ((P->cone == 3 || P->cone == 4) && kind[i] == 1) { pgs_block_pg(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i], P->cone == 4, T->walls); continue; }
+                if ((P->cone == 3 || P->cone == 4) && kind[i] == 1) { pgs_block_pg(A, nr, bvec, Rr, f, fsee, i, blkdim[i], rowmu[i], P->cone == 4, T->walls); continue; }
                 if (P->cone == 1 && kind[i] == 2) continue;                      /* (handled with its block below) */
                 if (P->cone == 1 && kind[i] == 1) { pgs_block_exact(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i]); continue; }
                 real res = bvec[i] + Rr[i] * f[i];
-                for (int j = 0; j < nr; j++) res += A[(size_t)i * nr + j] * f[j];
+                for (int j = 0; j < nr; j++) res += A[(size_t)i * nr + j] * fsee[j];
                 real old = f[i];
                 real nf = f[i] - res / (A[(size_t)i * nr + i] + Rr[i]);
-                if (kind[i] != 2 && nf < 0 && !(P->cone >= 5 && kind[i] == 1)) nf = 0; /* unilateral rows (hybrid study: the contact normal is left to the projection) */
+                if (kind[i] != 2 && nf < 0) nf = 0; /* unilateral rows */
                 f[i] = nf;
                 (void)old;
-                if (P->cone >= 5 && kind[i] == 2 && i == blk0[i] + blkdim[i] - 1) {
-                    /* (study) row-by-row updates as in cone = 0, then the closed-form projection onto the second-order cone in the scaled variables
-                     * (5: Euclidean, w = 1/2; 6: weighted by the diagonal curvatures) instead of the radial scaling with a clamped normal */
-                    const int i0 = blk0[i], dm = blkdim[i];
-                    const double *mu = rowmu[i];
-                    double s2 = 0, dt = 0;
-                    for (int r = 1; r < dm; r++) { const double x = (double)f[i0 + r] / mu[r - 1]; s2 += x * x; dt += mu[r - 1] * mu[r - 1] * ((double)A[(size_t)(i0 + r) * nr + i0 + r] + (double)Rr[i0 + r]); }
-                    const double N = sqrt(s2), d0 = (double)A[(size_t)i0 * nr + i0] + (double)Rr[i0];
-                    const double w = P->cone == 6 ? d0 / (d0 + dt / (dm - 1)) : 0.5;
-                    double y0 = (double)f[i0], a = w * y0 + (1 - w) * N;
-                    if (a > y0) y0 = a;
-                    if (y0 < 0) y0 = 0;
-                    const double sc = N > y0 ? y0 / N : 1.0;
-                    f[i0] = (real)y0;
-                    for (int r = 1; r < dm; r++) f[i0 + r] = (real)((double)f[i0 + r] * sc);
-                } else
                 if (kind[i] == 2 && i == blk0[i] + blkdim[i] - 1) {
                     /* last friction row of this contact: project onto the elliptic cone (D2) */
                     const int i0 = blk0[i], dm = blkdim[i];
@@ -1510,6 +1506,7 @@ void orc_default_params(orc_params *p, int task) {
     p->cone = 3;      /* block projected gradient in the second-order-cone variables: what the kernels run (round 4) */
     p->pgs_cap = 0;   /* 50 */
     p->solver = 0;    /* PGS (what the kernels run) */
+    p->jacobi = 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }

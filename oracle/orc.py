@@ -40,6 +40,7 @@ class OrcParams(ctypes.Structure):
         ("cone", ctypes.c_int32),       # 0: radial projection onto the cone (D2, = the kernels); 1: MuJoCo's per-contact block update with the exact friction QCQP
         ("pgs_cap", ctypes.c_int32),    # most sweeps of the converged mode (0 = 50)
         ("solver", ctypes.c_int32),     # 0: PGS (= the kernels); 1: primal Newton to machine precision (exact optimum of MuJoCo's convex problem)
+        ("jacobi", ctypes.c_int32),     # 1: two row groups (arm-only | cube rows) sweep concurrently (= the kernels' two waves); 0: one Gauss-Seidel pass
     ]
 
 

@@ -3,10 +3,13 @@
 The yard-stick is solver-independent: the CPU oracle's Newton solve of the primal problem (orc_params.solver = 1, the algorithm MuJoCo runs by default --
 follower.xml:3 names no solver), certified by the natural residual of the DUAL problem's KKT conditions (orc_io.kkt).  From identical states incl. the carried
 constraint forces (the product's default mode), ONE control step (20 substeps) is made with
-  default   4 warm-started PGS sweeps + radial cone projection            = what both kernel families and the oracle's default run (deviations D1 + D2)
-  radial*   the same iteration swept until converged (cap 5000)           -> isolates D2: the fixed point of the radial projection vs the optimum
-  exact     the optimum itself
-and |dqpos| of default / radial* against exact is reported per task, together with the KKT residual each variant leaves.
+  default        4 warm-started sweeps of the block projected-gradient step (round 4)  = what both kernel families and the oracle's default run (deviation D1)
+  default8 / *   8 sweeps / swept until converged                                       -> the same fixed point as `exact`
+  rows+radial    rounds 1-3: row-by-row updates + radial cone projection, 4 sweeps      (deviations D1 + D2)
+  rows+radial*   ... swept until converged                                               -> isolates D2: its fixed point is not the optimum
+  qcqp           MuJoCo's PGS block update (ray step + exact friction QCQP), 4 sweeps
+  exact          the optimum itself (primal Newton)
+and |dqpos| of each against `exact` is reported per task, together with the KKT residual each variant leaves.
     python tools/kkt_distance.py [--n 512] [--steps 40] [--json profiles/r04_kkt_distance.json]
 """
 import argparse
@@ -25,20 +28,13 @@ STATE = ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time
 def measure(task, mode, n, steps, seed=5):
     kw = dict(auto_reset=0, max_episode_steps=0, action_mode={"joint": 0, "ee": 1}[mode])
     walk = orc.Oracle(task, n, **kw)                                                  # generates the states (default solver, random policy)
-    var = {"default": orc.Oracle(task, n, kkt=True, **kw),
-           "radial*": orc.Oracle(task, n, kkt=True, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=5000, **kw),
-           "radial+apex": orc.Oracle(task, n, kkt=True, cone=2, **kw),
-           "radial+apex*": orc.Oracle(task, n, kkt=True, cone=2, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=5000, **kw),
-           "qcqp+apex": orc.Oracle(task, n, kkt=True, cone=1, **kw),
-           "legacy": orc.Oracle(task, n, kkt=True, cone=0, **kw),
-           "hyb5": orc.Oracle(task, n, kkt=True, cone=5, **kw),
-           "hyb5*": orc.Oracle(task, n, kkt=True, cone=5, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=5000, **kw),
-           "hyb6": orc.Oracle(task, n, kkt=True, cone=6, **kw),
-           "hyb6*": orc.Oracle(task, n, kkt=True, cone=6, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=5000, **kw),
-           "blockpg": orc.Oracle(task, n, kkt=True, cone=3, **kw),
-           "blockpg8": orc.Oracle(task, n, kkt=True, cone=3, pgs_iters=8, **kw),
-           "blockpgF": orc.Oracle(task, n, kkt=True, cone=4, **kw),
-           "blockpg*": orc.Oracle(task, n, kkt=True, cone=3, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=20000, **kw),
+    var = {"default": orc.Oracle(task, n, kkt=True, **kw),                                                          # block step, 4 sweeps: the product
+           "gs": orc.Oracle(task, n, kkt=True, jacobi=0, **kw),                                                    # the same step, one Gauss-Seidel pass over all rows
+           "default8": orc.Oracle(task, n, kkt=True, pgs_iters=8, **kw),
+           "default*": orc.Oracle(task, n, kkt=True, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=20000, **kw),            # ... swept to convergence
+           "rows+radial": orc.Oracle(task, n, kkt=True, cone=0, **kw),                                              # rounds 1-3, 4 sweeps
+           "rows+radial*": orc.Oracle(task, n, kkt=True, cone=0, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=5000, **kw),  # ... swept to convergence: NOT the optimum
+           "qcqp": orc.Oracle(task, n, kkt=True, cone=1, **kw),                                                    # MuJoCo's PGS block update, 4 sweeps
            "exact": orc.Oracle(task, n, kkt=True, solver=1, **kw)}
     walk.reset(np.arange(n, dtype=np.uint64) + 77)
     rng = np.random.default_rng(seed)
@@ -77,19 +73,14 @@ if __name__ == "__main__":
     for task, mode in (("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("pick_place", "ee"), ("stack", "joint"), ("push_loop", "joint")):
         dq, kkt, touched = measure(task, mode, a.n, a.steps)
         res[f"{task}-{mode}"] = {"env_steps": int(dq["default"].size), "arm_contact_fraction": float(touched.mean()),
-                                 "dqpos_default_vs_exact": pct(dq["default"]), "dqpos_radial_converged_vs_exact": pct(dq["radial*"]),
                                  "dqpos_vs_exact": {k: pct(v) for k, v in dq.items()},
                                  "dqpos_default_vs_exact_where_arm_touches": pct(dq["default"][touched]) if touched.any() else None,
                                  "kkt_residual": {k: pct(v) for k, v in kkt.items()}}
         r = res[f"{task}-{mode}"]
         f = lambda d: "median %.1e  p90 %.1e  p99 %.1e  max %.1e" % (d["median"], d["p90"], d["p99"], d["max"])
         print(f"{task:10s} {mode:5s} {r['env_steps']} env-steps, an arm contact in {100 * r['arm_contact_fraction']:.1f} %\n"
-              f"   |dqpos| default (4 sweeps, radial) vs exact optimum : {f(r['dqpos_default_vs_exact'])}\n"
-              f"   |dqpos| radial projection, converged vs exact      : {f(r['dqpos_radial_converged_vs_exact'])}\n"
-              + "".join(f"   |dqpos| {k:13s} vs exact: {f(pct(v))}\n" for k, v in dq.items() if k not in ("default", "radial*")) +
-              f"   KKT residual  default {f(r['kkt_residual']['default'])}\n"
-              f"                 radial* {f(r['kkt_residual']['radial*'])}\n"
-              f"                 exact   {f(r['kkt_residual']['exact'])}", flush=True)
+              + "".join(f"   |dqpos| {k:13s} vs exact: {f(pct(v))}   KKT residual {f(r['kkt_residual'][k])}\n" for k, v in dq.items())
+              + f"   KKT residual of the exact solve: {f(r['kkt_residual']['exact'])}", flush=True)
     if a.json:
         with open(a.json, "w") as fjs:
             json.dump(res, fjs, indent=1)
