@@ -43,9 +43,10 @@ CONFIGS = {
     5: ("StackTwoCubes-v0", 32768, "both"),      # 262 144 envs over 8 GPUs, state + two ray-cast 240x320x3 frames
 }
 # The step-kernel family is a property of the JOB (lcr_config.global_envs / step_kernel, include/lcr.h), never of the shard size, so that every sharding of a
-# job gives identical bits.  BASELINE's sharded jobs (configs 4, 5) are cut into 32 768-env shards, where the two-cooperating-waves family is the faster
-# one: those jobs PIN it; a run on fewer GPUs than the job names is one (or some) of its shards and makes the same choice.
-JOB = {4: {"global_envs": 131072, "step_kernel": "coop"}, 5: {"global_envs": 262144, "step_kernel": "coop"}}
+# job gives identical bits.  BASELINE's config 5 (StackTwoCubes, 262 144 envs) is cut into 32 768-env shards, where the two-cooperating-waves family is the
+# faster one while a Stack job of that size as ONE shard would run the one-wave family: that job PINS the two-wave family; a run on
+# fewer GPUs than the job names is one (or some) of its shards and makes the same choice.
+JOB = {4: {"global_envs": 131072, "step_kernel": "auto"}, 5: {"global_envs": 262144, "step_kernel": "coop"}}   # (PickPlace runs the two-wave family at every job size)
 
 
 def job_kwargs(config_id, n, world):

@@ -35,19 +35,6 @@
 // :313-348 and the per-task files, reset :297-311); the arithmetic of every block is the one of lcr_kernels.hip, regrouped by owner.
 #include "lcr_step_common.h"
 
-#ifndef LCR_EXP_PRIOA
-#define LCR_EXP_PRIOA 2
-#endif
-#ifndef LCR_EXP_HOT
-#define LCR_EXP_HOT 1
-#endif
-#ifndef LCR_EXP_PRIOB_PRE
-#define LCR_EXP_PRIOB_PRE 3
-#endif
-#ifndef LCR_EXP_PRIOB_POST
-#define LCR_EXP_PRIOB_POST 0
-#endif
-
 #ifndef LCR_PART
 #define LCR_PART (-1)
 #endif
@@ -269,7 +256,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         for (int j = 0; j < 6; j++) { ph[j * 64] = ctrl[j]; ph[(6 + j) * 64] = q[j]; }
     }
     wg_barrier();   // E0: wave B has published the initial cube pose
-    __builtin_amdgcn_s_setprio(LCR_EXP_PRIOA);   // where two waves share a SIMD the arm wave is the longer chain: it wins the issue arbitration
+    __builtin_amdgcn_s_setprio(2);   // where two waves share a SIMD the arm wave is the longer chain: it wins the issue arbitration
     bool hot = false;                 // this workgroup has had a coupled substep in this step
 
     // profiling aid (lcr_config.diagnostics = 3): cycles of this wave in total / waiting at barriers / before barrier 1, coupled substeps
@@ -625,7 +612,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         if (prof) pf_wait += clock64() - pf_mark;
         const bool c01 = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // wave B: a finger sphere touches a cube in some lane
         const bool coupled = c01 || cube4;
-        if (coupled && !hot && LCR_EXP_HOT) { hot = true; __builtin_amdgcn_s_setprio(3); }   // (see wave B)
+        if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }   // (see wave B)
         if (prof) pf_coupled += coupled ? 1u : 0u;
         if (c01) {   // warm-start forces of the finger<->cube slots act on the arm too: wave B's sum of g_r f_r
 #pragma unroll
@@ -1095,7 +1082,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     bool hot = false;   // this workgroup has had a coupled substep in this step
     for (int sub = 0; sub < P.n_substeps; sub++) {
         Diag DG = {0u, 0u, 0u, 0u};
-        __builtin_amdgcn_s_setprio(LCR_EXP_PRIOB_PRE);
+        __builtin_amdgcn_s_setprio(3);
         // ---- forward kinematics (this wave's own: cheaper than moving 72 floats through LDS) and, unless the arm wave keeps it (two cubes:
         //      this wave is the busier one there), the smooth joint forces tau -> wave A ----
         ArmFrames F;
@@ -1113,7 +1100,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         if (prof) pf_mark = clock64();
         wg_barrier();   // X: tau is in LDS for wave A; wave A's Cholesky factor of the joint-space inertia is in LDS
         if (prof) pf_wait += clock64() - pf_mark;
-        if (!hot) __builtin_amdgcn_s_setprio(LCR_EXP_PRIOB_POST);
+        if (!hot) __builtin_amdgcn_s_setprio(0);
         Chol6 CL;
         {
             const float *pl = lds + LL::LFAC0 + lane;
@@ -1651,7 +1638,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         const bool coupled = c01 || cube4;
         // A workgroup with coupled substeps is the one a launch waits for (its two chains run in series): from its first coupled substep on both its
         // waves take the top issue priority for the rest of the step, so that where two waves share a SIMD the partner fills the gaps instead of halving them.
-        if (coupled && !hot && LCR_EXP_HOT) { hot = true; __builtin_amdgcn_s_setprio(3); }
+        if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }
         if (cube4) {   // warm-start forces of the proxy slot act on the cube too
 #pragma unroll
             for (int c = 0; c < NC; c++) {

@@ -933,8 +933,8 @@ def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mod
 
 def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, monkeypatch):
     """lcr_create's choice (lcr_config.step_kernel = 0, no override) is a function of the task, the config and the JOB size (lcr_config.global_envs, ABI v4;
-    0 = the handle is the job) -- never of the shard size: two cooperating waves per 64 envs for jobs of <= 32 768 envs and for ReachCube, the one-wave
-    kernels for larger jobs of the other tasks; the converged solver mode always runs the one-wave kernels.  Which BUILD of the two-wave family a
+    0 = the handle is the job) -- never of the shard size: two cooperating waves per 64 envs for Reach / Lift / Push / PickPlace at every size and for
+    Stack / Loop jobs of <= 32 768 envs, the one-wave kernels for larger Stack / Loop jobs; the converged solver mode always runs the one-wave kernels.  Which BUILD of the two-wave family a
     shard runs (one / two waves per SIMD: 1 / 2) follows the shard size.  (MI355X: 256 CUs -> one wave per SIMD up to 32 768 envs.)"""
     import torch
     from gym_lowcostrobot_amd import VecSim
@@ -946,18 +946,19 @@ def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, mo
     fit = simds // 2 * 64                                  # largest shard with one wave per SIMD
     assert fit == 32768
     #         task, shard envs, job envs (None: the handle is the job), expected family / build
-    expect = [("reach", fit, None, 1), ("reach", 2 * fit, None, 2), ("reach", fit + 64, None, 2), ("push", fit, None, 1), ("push", 2 * fit, None, 0),
-              ("stack", fit, None, 1), ("stack", fit + 64, None, 0), ("pick_place", 2 * fit, None, 0), ("push_loop", fit, None, 1), ("push_loop", 2 * fit, None, 0),
-              # shards of larger jobs run the JOB's family: BASELINE config 4 / 5 shapes (4 x 32 768, 8 x 32 768) and a small shard of a big Reach job
-              ("pick_place", fit, 4 * fit, 0), ("stack", fit, 8 * fit, 0), ("push", 4096, 2 * fit, 0), ("reach", fit, 2 * fit, 1), ("reach", 2 * fit, 8 * fit, 2),
-              ("push", 4096, fit, 1)]
+    expect = [("reach", fit, None, 1), ("reach", 2 * fit, None, 2), ("reach", fit + 64, None, 2), ("push", fit, None, 1), ("push", 2 * fit, None, 2),
+              ("lift", 2 * fit, None, 2), ("pick_place", 4 * fit, None, 2),
+              ("stack", fit, None, 1), ("stack", fit + 64, None, 0), ("push_loop", fit, None, 1), ("push_loop", 2 * fit, None, 0),
+              # shards of larger jobs run the JOB's family: BASELINE config 4 / 5 shapes (4 x 32 768, 8 x 32 768) and small shards of big jobs
+              ("pick_place", fit, 4 * fit, 1), ("stack", fit, 8 * fit, 0), ("push_loop", 4096, 2 * fit, 0), ("reach", fit, 2 * fit, 1), ("reach", 2 * fit, 8 * fit, 2),
+              ("push", 4096, 2 * fit, 1), ("stack", 4096, fit, 1)]
     for task, n, job, fam in expect:
         sim = VecSim(task, n, global_envs=job)
         got = hip_lib.lcr_step_kernel_family(sim.handle)
         assert got == fam, (task, n, job, got, fam, sim.step_kernel_family)
         sim.close()
     for kw, fam in ((dict(step_kernel="coop"), 1), (dict(step_kernel="single"), 0)):      # a pin beats the job size
-        sim = VecSim("pick_place", fit, global_envs=4 * fit, **kw)
+        sim = VecSim("stack", fit, global_envs=8 * fit, **kw)
         assert hip_lib.lcr_step_kernel_family(sim.handle) == fam
         sim.close()
     sim = VecSim("reach", 2 * fit, pgs_iters=-1)
