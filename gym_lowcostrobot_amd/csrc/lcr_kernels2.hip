@@ -349,7 +349,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         for (int c = 0; c < NC; c++) { dca[c] = mk(0.f, 0.f, 0.f); dcal[c] = mk(0.f, 0.f, 0.f); }
         ArmSlot2<NRW> AS[NAS];
         bool slot_any[NAS];
-        bool link_on_cube = false;
+        bool link_on_cube = false, wave_on_cube4 = false;
         int link_nj = 3, link_bi = 0;
         float link_htop = 0.f;   // slot 4 on the floor: height of the surface under the proxy (PushCubeLoop: a rail's top face, D7)
         int slot_cube[3] = {0, 0, 0};
@@ -437,6 +437,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 diag_choice(DG, T.act, 12 + s, sel);
             }
             slot_any[s] = __any(T.act) != 0;
+            if (s == 4) wave_on_cube4 = __any(T.act && oncube) != 0;
 #pragma unroll
             for (int k = 0; k < NRW; k++) { T.aref[k] = 0.f; T.inv[k] = 0.f; }
             if (!slot_any[s]) {   // nobody touches: no force is carried
@@ -490,6 +491,9 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 }
 #pragma unroll
                 for (int r = 0; r < as_rows<ROLL>(s); r++) {
+                    // (slot 4: a link proxy on the FLOOR has three rows, condim 3; the torsion row exists only against a cube.  When no lane of the wave has its
+                    //  proxy on a cube -- almost always -- the row is skipped: it would contribute exact zeros)
+                    if (s == 4 && r == 3 && !wave_on_cube4) { Wf[s][r] = 0.f; continue; }   // (its carried force restarts from zero, as for every row that is off)
                     f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));
                     if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }
                     float g[6];
@@ -596,7 +600,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 
         // ---- does a gripper-body proxy of some lane touch a cube?  (wave-uniform; with wave B's "a finger sphere touches a cube" it
         //      decides the sweep schedule of BOTH waves) ----
-        const bool cube4 = __any(AS[4].act && link_on_cube) != 0;
+        const bool cube4 = wave_on_cube4;
         if (lane == 0) xflag[1] = cube4 ? 1 : 0;
         if (cube4) {   // share of slot 4's warm-start forces that acts on a cube
 #pragma unroll
@@ -652,7 +656,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 ArmSlot2<NRW> &T = AS[s];
                 const bool may_cube = CPL && (s < 2 || s == 4);
                 const bool oncube = s < 2 || (s == 4 && link_on_cube);
-                const int nrow = (ROLL && s < 2) ? 6 : 4;
+                const int nrow = (ROLL && s < 2) ? 6 : ((s == 4 && !cube4) ? 3 : 4);
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
                 float2v g[NRW][3];
