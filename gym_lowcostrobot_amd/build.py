@@ -27,14 +27,14 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# (source, object, extra flags): lcr_kernels.hip is compiled four times, LCR_PART selecting the step-kernel instantiations a unit emits
-# (0 one-cube kernels + dispatcher + small kernels, 1 PushCubeLoop, 2 / 3 the two StackTwoCubes variants) -- 32 kernels of ~50-100 KB
-# code each take 80 s in one unit, ~30 s as four units compiled concurrently
+# (source, object, extra flags): lcr_kernels.hip is compiled three times, LCR_PART selecting the step-kernel instantiations a unit emits
+# (0 one-cube kernels + dispatcher + small kernels, 2 / 3 the two StackTwoCubes variants) -- kernels of ~50-100 KB code each: 80 s in one
+# unit, ~30 s as units compiled concurrently; lcr_kernels_loop.hip is PushCubeLoop's unit
 UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
-         ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels.hip", "lcr_kernels_walls.o", ["-DLCR_PART=1"]),
+         ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels_loop.hip", "lcr_kernels_loop.o", []),
          ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
-         # the two-cooperating-waves family (lcr_kernels2.hip): 10 one cube, 11 PushCubeLoop, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point manifold
-         ("lcr_kernels2.hip", "lcr_kernels2.o", ["-DLCR_PART=10"]), ("lcr_kernels2.hip", "lcr_kernels2_walls.o", ["-DLCR_PART=11"]),
+         # the two-cooperating-waves family (lcr_kernels2.hip): 10 one cube, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point manifold
+         ("lcr_kernels2.hip", "lcr_kernels2.o", ["-DLCR_PART=10"]),
          ("lcr_kernels2.hip", "lcr_kernels2_stack.o", ["-DLCR_PART=12"]), ("lcr_kernels2.hip", "lcr_kernels2_stack_cc8.o", ["-DLCR_PART=13"])]
 
 

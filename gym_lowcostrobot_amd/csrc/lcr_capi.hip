@@ -173,6 +173,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->cc_points == 8 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 runs on the two-wave kernels, diagnostics = 2 (per-wave cycles) on the one-wave kernels");
     if (cfg->cc_points == 8 && cfg->step_kernel == 1) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 is implemented by the two-wave kernels only (step_kernel = 1 pins the one-wave family)");
     if (cfg->step_kernel == 2 && cfg->pgs_iters < 0) return fail(LCR_ERR_UNSUPPORTED, "the converged solver mode (pgs_iters < 0) is implemented by the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
+    if (cfg->step_kernel == 2 && cfg->task == LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_UNSUPPORTED, "PushCubeLoop has the one-wave step kernel only (lcr_kernels_loop.hip); step_kernel = 2 pins the two-wave family");
     if (cfg->step_kernel == 2 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "diagnostics = 2 (per-wave cycles) reads back the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
     if (cfg->global_envs < 0) return fail(LCR_ERR_INVALID, "global_envs must be >= 0 (0 = n_envs)");
     if (cfg->global_envs > 0 && (cfg->env_id_offset < 0 || cfg->env_id_offset + (int64_t)cfg->n_envs > cfg->global_envs))
@@ -305,17 +306,18 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         // the shard size, so that every sharding of a job runs the same arithmetic (bit-identical results for G = 1/2/4/8).  Measured on an
         // MI355X with the job as ONE shard (random policy, round 4): the two-cooperating-waves kernels win or tie at every size for the
         // four one-cube tasks without rails (65 536 envs: ReachCube 0.256 against 0.285 ms, Push / Lift / PickPlace 0.338-0.341 against 0.333-0.336;
-        // 131 072: 0.61-0.63 against 0.62-0.65; 32 768: 0.22-0.23 against 0.33) -- those tasks ALWAYS run them.  StackTwoCubes and PushCubeLoop need more
-        // than 256 registers per lane in their cube wave: up to 32 768 envs (2 x 512 waves: one per SIMD) the two-wave kernels win (0.55 against 0.78,
-        // 0.45 against 0.59 ms), above that the one-wave kernels do (65 536: 0.89 against 0.95, 0.62 against 1.06).  lcr_config.step_kernel pins a family (a
-        // Stack / Loop job cut into shards of <= 32 768 envs pins 2); LCR_STEP_KERNEL=single|coop1|coop2 overrides (tests and profiling exercise every build).
+        // 131 072: 0.61-0.63 against 0.62-0.65; 32 768: 0.22-0.23 against 0.33) -- those tasks ALWAYS run them.  StackTwoCubes needs more
+        // than 256 registers per lane in its cube wave: up to 32 768 envs (2 x 512 waves: one per SIMD) the two-wave kernels win (0.55 against 0.78 ms),
+        // above that the one-wave kernels do (65 536: 0.89 against 0.95).  PushCubeLoop has one kernel (lcr_kernels_loop.hip, one wave per 64 envs).
+        // lcr_config.step_kernel pins a family (a Stack job cut into shards of <= 32 768 envs pins 2); LCR_STEP_KERNEL=single|coop1|coop2 overrides
+        // (tests and profiling exercise every build).
         // WHICH BUILD of the two-wave family a shard runs does follow its size (one wave per SIMD while 2 x ceil(N / 64) waves fit the chip's SIMDs, else the
         // build compiled for two waves per SIMD): same source, same bits.
         {
             const size_t waves2 = 2 * ((N + 63) / 64), simds = 4 * (size_t)prop.multiProcessorCount;
             const int64_t job = cfg->global_envs > 0 ? cfg->global_envs : (int64_t)N;
             D.cc8 = (cfg->task == LCR_TASK_STACK && cfg->cc_points == 8) ? 1 : 0;
-            bool two_wave = job <= 32768 || !(cfg->task == LCR_TASK_STACK || cfg->task == LCR_TASK_PUSH_LOOP);
+            bool two_wave = job <= 32768 || cfg->task != LCR_TASK_STACK;
             if (cfg->step_kernel == 1) two_wave = false;
             else if (cfg->step_kernel == 2) two_wave = true;
             if (D.cc8) two_wave = true;                               // the eight-point manifold lives in the two-wave kernels only
@@ -327,6 +329,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
                 else if (strcmp(ov, "coop2") == 0 && two_wave_possible(cfg)) D.coop = 2;
             }
             if (D.cc8) D.coop = 1;   // (74-80 KiB of LDS per workgroup: its only build is the one-wave-per-SIMD one)
+            if (loop) D.coop = 0;    // PushCubeLoop: one kernel
         }
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

@@ -78,9 +78,10 @@ struct LcrCam {
 
 // launchers implemented in lcr_kernels.hip / lcr_render.hip (plain C++ linkage, same shared object)
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
+// PushCubeLoop (lcr_kernels_loop.hip: one wave per 64 envs, row-wise solver)
+int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
 // two-cooperating-waves family (lcr_kernels2.hip); occ = waves per SIMD the variant is compiled for
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
-int lcr_launch_step2_walls(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_step2_stack_cc8(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,

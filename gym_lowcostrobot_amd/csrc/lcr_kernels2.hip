@@ -137,7 +137,7 @@ template <int NC> constexpr bool rne_on_arm() { return false; }
 // ================================================================================================
 // wave A: the arm
 // ================================================================================================
-template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8, bool GW>
+template <int NC, bool EE, bool ROLL, bool CC8, bool GW>
 DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *lds, const int lane, const int e, const bool valid) {
     using LL = Lds2<NC, ROLL, CC8, !GW>;
     using namespace lcrm;
@@ -351,7 +351,6 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         bool slot_any[NAS];
         bool link_on_cube = false, wave_on_cube4 = false;
         int link_nj = 3, link_bi = 0;
-        float link_htop = 0.f;   // slot 4 on the floor: height of the surface under the proxy (PushCubeLoop: a rail's top face, D7)
         int slot_cube[3] = {0, 0, 0};
         {
         const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
@@ -385,10 +384,9 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 dist = bestd;
                 slot_cube[sp] = cidx;
             } else if (s < 4) {
-                const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
-                dist = sph[sp].z - srad[sp] - htop;
-                pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
-                sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
+                dist = sph[sp].z - srad[sp];
+                pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
+                sel = 0;
             } else if (P.arm_collision) {
                 const int plink[5] = {2, 2, 3, 4, 5};
                 const float px[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, py[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, pz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};
@@ -406,13 +404,8 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 for (int i = 0; i < 5; i++) {
                     const int L = plink[i];
                     const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
-                    float df = cz - pr[i], hi = 0.f;
-                    if constexpr (WALLS) {   // (D7) above a rail's footprint the surface is the rail's top face
-                        const f3 cw_ = local_point(F, L, px[i], py[i], pz[i]);
-                        hi = rail_top(cw_.x, cw_.y);
-                        df -= hi;
-                    }
-                    if (df < bestd) { bestd = df; bi = i; oncube = false; link_htop = hi; }
+                    const float df = cz - pr[i];
+                    if (df < bestd) { bestd = df; bi = i; oncube = false; }
                     if (i >= 3 && wave_near) {
                         const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
 #pragma unroll
@@ -423,7 +416,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                     }
                 }
                 link_bi = bi;
-                if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = link_htop > 0.f ? 1 : 0; }
+                if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
                 sel += 64 * (bi + 1);
                 dist = bestd;
                 link_on_cube = oncube;
@@ -457,7 +450,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                         const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
                         cb = f2v{m, m} * ci + cb;
                     }
-                    if (!oncube) pos = mk(cb.x, cb.y, link_htop + 0.5f * dist);
+                    if (!oncube) pos = mk(cb.x, cb.y, 0.5f * dist);
                 }
                 if (may_cube) make_frame(n, T.t1, T.t2);
                 auto joint_on = [&](int j) -> bool {
@@ -481,7 +474,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 // squared friction coefficients of this slot's rows (finger geoms mu 1.5 / torsional 0.005; a link proxy on the floor mu 1, on a cube the cube's)
                 const float m2_tan = s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f);
                 const float m2_tors = s < 4 ? MU_TORS * MU_TORS : P.mu_ct2;
-                float Ln = 1.f, Lt = 0.f, Ls = 0.f;
+                float Ln = 1.f, Lt = 0.f;
                 f3 jc[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
@@ -534,9 +527,8 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                     {
                         const float arr = gg + diagc + Rr;
                         const float m2r = r == 0 ? 1.f : (r < 3 ? m2_tan : (r == 3 ? m2_tors : P.mu_fcr2));
-                        const float KF = WALLS ? 3.f : 2.f;
+                        const float KF = 2.f;
                     if (r == 0) Ln = KF * arr;
-                    else if (WALLS && r >= 3) Ls = fmaf(row_on ? KF * m2r : 0.f, arr, Ls);
                     else Lt = fmaf(row_on ? KF * m2r : 0.f, arr, Lt);
                     }
                     const float fw = row_on ? Wf[s][r] : 0.f;
@@ -552,7 +544,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                     }
                 }
                 {   // k[] of soc_step: iLn, mu_tan^2 iLt, w, mu_tors^2 iLt
-                    const float iLn = T.act ? rcp(Ln) : 0.f, iLt = T.act ? rcp(Lt) : 0.f, iLs = WALLS ? ((T.act && Ls > 0.f) ? rcp(Ls) : 0.f) : iLt;
+                    const float iLn = T.act ? rcp(Ln) : 0.f, iLt = T.act ? rcp(Lt) : 0.f, iLs = iLt;
                     T.inv[0] = iLn; T.inv[1] = m2_tan * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = (s != 4 || oncube) ? m2_tors * iLs : 0.f;   // (a link proxy on the floor has no torsion row: condim 3)
                     if constexpr (ROLL) { T.inv[4] = P.mu_fcr2 * iLs; T.inv[5] = 0.f; }
                 }
@@ -713,7 +705,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 {
                     const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
                     const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
-                    soc_step<NRW, WALLS>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
+                    soc_step<NRW>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
                 }
 #pragma unroll
                 for (int r = 0; r < NRW; r++) {
@@ -883,7 +875,6 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     f3 target = mk(0.f, 0.f, 0.f);
     if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
     int elapsed = P.elapsed[e];
-    int goal = WALLS ? P.goal[e] : 0;
     EnvState<NC> S;
 #pragma unroll
     for (int j = 0; j < 6; j++) { S.q[j] = q[j]; S.qd[j] = qd[j]; }
@@ -904,19 +895,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         else { a3 = lag_cube[0]; b3 = target; }
         f3 df = a3 - b3;
         float d = sqrtf(dot(df, df));
-        if (task == 5) {  // PushCubeLoop get_reward / get_cube_overlap (push_cube_loop_env.py:334-383), FRESH cube position
-            const float xc = S.cp[0].x, yc = S.cp[0].y, wc = 0.0075f;
-            const float gx = goal ? -0.06f : 0.06f, gy = 0.135f;
-            const float gh0 = 0.0095f, gh1 = 0.0145f;
-            const float xo = fmaxf(0.f, fminf(xc + wc, gx + gh0) - fmaxf(xc - wc, gx - gh0));
-            const float yo = fmaxf(0.f, fminf(yc + wc, gy + gh1) - fmaxf(yc - wc, gy - gh1));
-            const float overlap = xo * yo * (1.f / (4.f * 0.0075f * 0.0075f));
-            success = overlap > 0.95f;
-            terminated = false;
-            const float edge = -gh1 + gy;
-            reward = success ? 5.f : (overlap > 0.f ? overlap - 1.f : clampf(-fabsf(yc - edge) * (1.f / 0.16f) - 1.f, -2.f, -1.f));
-            if (success) goal = 1 - goal;
-        } else if (task == 1) {
+        if (task == 1) {
             reward = (lag_cube[0].z - P.height_thr) + d;
             success = false; terminated = false;
         } else {
@@ -958,7 +937,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 for (int k = 0; k < 4; k++) P.term_quat[(size_t)(4 * c + k) * N + e] = S.cq[c][k];
         }
         Pcg g = load_rng(P, e);
-        reset_env<NC>(P, S, g, target, lag_ee, goal);
+        reset_env<NC>(P, S, g, target, lag_ee, 0);
         if (diverged) {
 #pragma unroll
             for (int j = 0; j < 6; j++) S.qd[j] = 0.f;
@@ -975,7 +954,6 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         store_state<NC>(P, e, S);
         P.elapsed[e] = elapsed;
         P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
-        if (WALLS) P.goal[e] = goal;
         if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);
     }
     if (carry && valid) {
@@ -992,7 +970,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 // ================================================================================================
 // wave B: the cubes
 // ================================================================================================
-template <int NC, bool EE, bool WALLS, bool ROLL, bool CC8, bool GW>
+template <int NC, bool EE, bool ROLL, bool CC8, bool GW>
 DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, const bool valid) {
     using LL = Lds2<NC, ROLL, CC8, !GW>;
     // cube<->cube manifold points kept (Stack): 4 = the extremes along the diagonals of the reference face; CC8 (lcr_config.cc_points = 8,
@@ -1038,7 +1016,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
     };
     const bool carry = P.warm != nullptr;
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
-    float Wfloor[NC][4][4], Wwall[4][4];
+    float Wfloor[NC][4][4];
     bool cc_prev[NCC];
 #pragma unroll
     for (int s = 0; s < NCC; s++) cc_prev[s] = false;
@@ -1048,10 +1026,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         for (int s = 0; s < 4; s++)
 #pragma unroll
             for (int k = 0; k < 4; k++) Wfloor[c][s][k] = wld(WARM_FLOOR + 16 * c + 4 * s + k);
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) Wwall[s][k] = WALLS ? wld(WARM_WALL + 4 * s + k) : 0.f;
     constexpr int NRW = ROLL ? 6 : 4;
     float Wf01[2][NRW];   // carried forces of the finger<->cube slots 0, 1 (this wave owns them: they need the cube state)
 #pragma unroll
@@ -1178,7 +1152,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 const float Rt = Rf * P.rt_fc;
                 T.Rn = Rn;
                 const int nj = sp == 0 ? 5 : 6;   // joints that move the sphere (link_5 / link_6)
-                float Ln01 = 1.f, Lt01 = 0.f, Ls01 = 0.f;
+                float Ln01 = 1.f, Lt01 = 0.f;
                 f3 jc[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) jc[j] = j < nj ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
@@ -1218,9 +1192,8 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     {   // metric of the block step (soc_step)
                         const float arr = gg + diagc + Rr;
                         const float m2r = r == 0 ? 1.f : (r < 3 ? P.mu_fc2 : (r == 3 ? P.mu_fct2 : P.mu_fcr2));
-                        const float KF = WALLS ? 3.f : 2.f;
+                        const float KF = 2.f;
                         if (r == 0) Ln01 = KF * arr;
-                        else if (WALLS && r >= 3) Ls01 = fmaf(KF * m2r, arr, Ls01);
                         else Lt01 = fmaf(KF * m2r, arr, Lt01);
                     }
                     const float fw = T.act ? Wf01[sp][r] : 0.f;       // warm start: previous substep's force of this slot
@@ -1233,7 +1206,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
                 }
                 {   // k[] of soc_step (a slot that is off in this lane: zeros -> its updates are exact zeros)
-                    const float iLn = T.act ? rcp(Ln01) : 0.f, iLt = T.act ? rcp(Lt01) : 0.f, iLs = WALLS ? (T.act ? rcp(Ls01) : 0.f) : iLt;
+                    const float iLn = T.act ? rcp(Ln01) : 0.f, iLt = T.act ? rcp(Lt01) : 0.f, iLs = iLt;
                     T.inv[0] = iLn; T.inv[1] = P.mu_fc2 * iLt; T.inv[2] = Ln01 * rcp(Ln01 + Lt01); T.inv[3] = P.mu_fct2 * iLs;
                     if constexpr (ROLL) { T.inv[4] = P.mu_fcr2 * iLs; T.inv[5] = 0.f; }
                 }
@@ -1360,12 +1333,12 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 T.aref[2] = B_DEF * vp.x;
                 T.aref[3] = -B_DEF * cww[c].z;
                 {   // k[] of soc_step: Ln = 2 (A + R)_nn, Lt = 2 (mu^2 ((A + R)_11 + (A + R)_22) + mu_tors^2 (A + R)_33)
-                    const float KF = WALLS ? 3.f : 2.f;   // (PushCubeLoop: three groups, see soc_step)
+                    const float KF = 2.f;   // (two groups, see soc_step)
                     const float Ln = KF * (minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn);
                     const float a12 = 2.f * minv + iinv * (2.f * T.r.z * T.r.z + T.r.x * T.r.x + T.r.y * T.r.y) + 2.f * Rf;
                     const float Ls = KF * P.mu_ct2 * (iinv + Rt);
-                    const float Lt = WALLS ? KF * P.mu_c2 * a12 : fmaf(KF * P.mu_c2, a12, Ls);
-                    const float iLt = T.act ? rcp(Lt) : 0.f, iLs = WALLS ? (T.act ? rcp(Ls) : 0.f) : iLt;
+                    const float Lt = fmaf(KF * P.mu_c2, a12, Ls);
+                    const float iLt = T.act ? rcp(Lt) : 0.f, iLs = iLt;
                     T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
                 }
                 float (&Tf)[4] = Wfloor[c][s];   // the carried forces ARE this slot's forces from here on (zero if the slot is off)
@@ -1542,99 +1515,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
 
-        // ---- collision: PushCubeLoop rails (inner faces of the four wall boxes, see lcr_kernels.hip) ----
-        FloorSlot WS[4];
-        float wsg[2] = {1.f, 1.f};
-        bool wall_any = false;
-        if constexpr (WALLS) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) { WS[s].act = false; WS[s].r = mk(0.f, 0.f, 0.f); WS[s].Rn = 1.f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { WS[s].f[k] = 0.f; WS[s].aref[k] = 0.f; WS[s].inv[k] = 0.f; } }
-            f3 vw[8];
-            float worst = 1.f;
-            bool lo_x = false, lo_y = false;
-            const bool inpen = cube_in_pen(cp[0]);   // (a cube outside the rails' outer rectangle touches no rail)
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
-                vw[i] = axpy(sx, CR[0].X, axpy(sy, CR[0].Y, sz * CR[0].Z));
-                const f3 p = vw[i] + cp[0];
-                const bool low = p.z < WALL_TOP;
-                const float dmin = fminf(fminf(p.x + WALL_X, WALL_X - p.x), fminf(p.y - WALL_Y0, WALL_Y1 - p.y));
-                worst = fminf(worst, (low && inpen) ? dmin : 1.f);
-                lo_x = lo_x || (low && inpen && p.x + WALL_X < 0.f);
-                lo_y = lo_y || (low && inpen && p.y - WALL_Y0 < 0.f);
-            }
-            wall_any = __any(worst < 0.f) != 0;
-            if (wall_any) {
-                wsg[0] = lo_x ? 1.f : -1.f;
-                wsg[1] = lo_y ? 1.f : -1.f;
-#pragma unroll
-                for (int pr = 0; pr < 2; pr++) {
-                    const float sg = wsg[pr];
-                    const float off = pr == 0 ? WALL_X : (sg > 0.f ? -WALL_Y0 : WALL_Y1);
-                    float d1 = 0.f, d2 = 0.f;
-                    bool h1 = false, h2 = false;
-                    f3 r1 = mk(0.f, 0.f, 0.f), r2 = mk(0.f, 0.f, 0.f);
-                    int i1 = 0, i2 = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const f3 p = vw[i] + cp[0];
-                        const float dist = fmaf(sg, pr == 0 ? p.x : p.y, off);
-                        const bool pen = dist < 0.f && p.z < WALL_TOP && inpen;
-                        const bool first = pen && (!h1 || dist < d1);
-                        const bool second = pen && !first && (!h2 || dist < d2);
-                        if (P.diag) { i2 = first ? i1 : (second ? i : i2); i1 = first ? i : i1; }
-                        d2 = first ? d1 : (second ? dist : d2);
-                        r2 = first ? r1 : (second ? vw[i] : r2);
-                        h2 = first ? h1 : (second ? true : h2);
-                        d1 = first ? dist : d1;
-                        r1 = first ? vw[i] : r1;
-                        h1 = h1 || first;
-                    }
-                    const f3 v = pr == 0 ? cv[0] : mk(cv[0].y, cv[0].z, cv[0].x);
-                    const f3 w = pr == 0 ? cww[0] : mk(cww[0].y, cww[0].z, cww[0].x);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        FloorSlot &T = WS[2 * pr + c];
-                        const float dist = c == 0 ? d1 : d2;
-                        const f3 rw = c == 0 ? r1 : r2;
-                        T.act = c == 0 ? h1 : h2;
-                        if (P.diag) diag_choice(DG, T.act, 8 + 2 * pr + c, (c == 0 ? i1 : i2) + 8 * (2 * pr + (sg > 0.f ? 0 : 1)));
-                        f3 r = pr == 0 ? rw : mk(rw.y, rw.z, rw.x);
-                        r.x = fmaf(-0.5f * dist, sg, r.x);
-                        T.r = r;
-                        float imp = impedance(dist, D0_DEF, DW_DEF, 1.0f / W_DEF);
-                        float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
-                        float Rf = Rn * P.inv_impratio;
-                        float Rt = Rf * P.rt_cube;
-                        T.Rn = Rn;
-                        const f3 vp = v + cross(w, r);
-                        T.aref[0] = -B_DEF * sg * vp.x - K_DEF * imp * dist;
-                        T.aref[1] = -B_DEF * vp.y;
-                        T.aref[2] = -B_DEF * sg * vp.z;
-                        T.aref[3] = -B_DEF * sg * w.x;
-                        {   // k[] of soc_step
-                            const float Ln = 3.f * (minv + iinv * (r.y * r.y + r.z * r.z) + Rn);   // (three groups: soc_step SEP)
-                            const float a12 = 2.f * minv + iinv * (2.f * r.x * r.x + r.z * r.z + r.y * r.y) + 2.f * Rf;
-                            const float Lt = 3.f * P.mu_c2 * a12, Ls = 3.f * P.mu_ct2 * (iinv + Rt);
-                            const float iLt = T.act ? rcp(Lt) : 0.f, iLs = T.act ? rcp(Ls) : 0.f;
-                            T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; k++) T.f[k] = T.act ? Wwall[2 * pr + c][k] : 0.f;
-                        const float la = minv * sg * T.f[0], lb = minv * T.f[1], lc = minv * sg * T.f[2];
-                        const float aa = iinv * (-r.z * T.f[1] + sg * r.y * T.f[2] + sg * T.f[3]);
-                        const float ab = iinv * sg * (r.z * T.f[0] - r.x * T.f[2]);
-                        const float ac = iinv * (-sg * r.y * T.f[0] + r.x * T.f[1]);
-                        if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
-                        else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
-                    }
-                }
-            }
-        }
-
         if (prof) pf_mark = clock64();
         wg_barrier();   // B1: wave A has set up its rows and decided whether this substep is coupled
         if (prof) pf_wait += clock64() - pf_mark;
@@ -1668,7 +1548,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     const float u3 = cal[c].z - T.aref[3] + Rt * Tf[3];
                     const float uu[4] = {u0, u1, u2, u3};
                     float nf[4];
-                    soc_step<4, WALLS>(Tf, uu, T.inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                    soc_step<4>(Tf, uu, T.inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
                     const float d0 = nf[0] - Tf[0], d1 = nf[1] - Tf[1], d2 = nf[2] - Tf[2], d3 = nf[3] - Tf[3];
                     Tf[0] = nf[0]; Tf[1] = nf[1]; Tf[2] = nf[2]; Tf[3] = nf[3];
                     ca[c].z = fmaf(minv, d0, ca[c].z);
@@ -1703,7 +1583,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                         const float u3 = dot(ccn, Wr) - aref[3] + Rt * f[3];
                         const float uu[4] = {u0, u1, u2, u3};
                         float nf[4];
-                        soc_step<4, WALLS>(f, uu, inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
+                        soc_step<4>(f, uu, inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
                         const float d0 = nf[0] - f[0], e1 = nf[1] - f[1], e2 = nf[2] - f[2], e3 = nf[3] - f[3];
                         ccl[(size_t)(s * CC_REC + 3) * CS] = nf[0]; ccl[(size_t)(s * CC_REC + 4) * CS] = nf[1];
                         ccl[(size_t)(s * CC_REC + 5) * CS] = nf[2]; ccl[(size_t)(s * CC_REC + 6) * CS] = nf[3];
@@ -1711,35 +1591,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                         const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
                         ca[1] = axpy(minv, Fd, ca[1]); ca[0] = axpy(-minv, Fd, ca[0]);
                         cal[1] = axpy(iinv, T1, cal[1]); cal[0] = axpy(-iinv, T0, cal[0]);
-                    }
-                }
-            }
-            if constexpr (WALLS) {
-                if (wall_any) {
-#pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        FloorSlot &T = WS[s];
-                        const int pr = s >> 1;
-                        const float sg = wsg[pr];
-                        const f3 r = T.r;
-                        const float Rf = T.Rn * P.inv_impratio, Rt = Rf * P.rt_cube;
-                        const f3 a = pr == 0 ? ca[0] : mk(ca[0].y, ca[0].z, ca[0].x);
-                        const f3 w = pr == 0 ? cal[0] : mk(cal[0].y, cal[0].z, cal[0].x);
-                        const float u0 = sg * (a.x + r.z * w.y - r.y * w.z) - T.aref[0] + T.Rn * T.f[0];
-                        const float u1 = a.y - r.z * w.x + r.x * w.z - T.aref[1] + Rf * T.f[1];
-                        const float u2 = sg * (a.z + r.y * w.x - r.x * w.y) - T.aref[2] + Rf * T.f[2];
-                        const float u3 = sg * w.x - T.aref[3] + Rt * T.f[3];
-                        const float uu[4] = {u0, u1, u2, u3};
-                        float nf[4];
-                        soc_step<4, WALLS>(T.f, uu, T.inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
-                        const float d0 = nf[0] - T.f[0], d1 = nf[1] - T.f[1], d2 = nf[2] - T.f[2], d3 = nf[3] - T.f[3];
-                        T.f[0] = nf[0]; T.f[1] = nf[1]; T.f[2] = nf[2]; T.f[3] = nf[3];
-                        const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
-                        const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
-                        const float ab = iinv * sg * (r.z * d0 - r.x * d2);
-                        const float ac = iinv * (-sg * r.y * d0 + r.x * d1);
-                        if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
-                        else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
                     }
                 }
             }
@@ -1784,7 +1635,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                     if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
                     u[r] = gy + jc_a - T.aref[r] + Rr * fcur[r];
                 }
-                soc_step<NRW, WALLS>(fcur, u, T.inv, 1.f / (MU_FINGER * MU_FINGER), P.inv_mu_fct2, P.inv_mu_fcr2, NRW, nf);   // (finger<->cube pair: max rule, the finger's 1.5 is the largest cube friction of any task)
+                soc_step<NRW>(fcur, u, T.inv, 1.f / (MU_FINGER * MU_FINGER), P.inv_mu_fct2, P.inv_mu_fcr2, NRW, nf);   // (finger<->cube pair: max rule, the finger's 1.5 is the largest cube friction of any task)
 #pragma unroll
                 for (int r = 0; r < NRW; r++) {
                     const float dlt = nf[r] - fcur[r];
@@ -1859,12 +1710,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         // ---- keep the forces for the next substep's warm start (inactive slots hold zero) ----------------
 #pragma unroll
         for (int s = 0; s < NCC; s++) cc_prev[s] = cc_act[s];
-        if constexpr (WALLS) {
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) Wwall[s][k] = WS[s].f[k];
-        }
         if (P.diag) {
             unsigned m = 0u;
 #pragma unroll
@@ -1874,7 +1719,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
-                if (WALLS) m |= WS[s].act ? (1u << (8 + s)) : 0u;
             }
             if constexpr (CC8) {
 #pragma unroll
@@ -1943,12 +1787,6 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int k = 0; k < NRW; k++) wst(WARM_ARM + 6 * s + k, Wf01[s][k]);
-        if constexpr (WALLS) {
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) wst(WARM_WALL + 4 * s + k, Wwall[s][k]);
-        }
         if constexpr (NC == 2) {
 #pragma unroll
             for (int s = 0; s < NCC; s++) {
@@ -1964,7 +1802,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 // the kernel: workgroup = 2 waves x 64 lanes over 64 envs.  OCC = waves per SIMD the register budget must allow
 // (1: up to 512 registers per lane -- shards that put at most one wave on a SIMD; 2: <= 256)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool WALLS, bool ROLL, int OCC, bool CC8>
+template <int NC, bool EE, bool ROLL, int OCC, bool CC8>
 __global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const float *__restrict__ action) {
     constexpr bool GW = OCC == 2 || CC8;   // where V and G travel in substeps with a finger on a cube: global scratch record (true) or their own LDS place
     __shared__ float lds[Lds2<NC, ROLL, CC8, !GW>::TOTAL];
@@ -1974,29 +1812,29 @@ __global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const flo
     const bool valid = e_raw < P.n;
     const int e = valid ? e_raw : P.n - 1;   // tail lanes shadow the last env, their stores are masked
 #if defined(LCR2_ONLY_ARM)        // (register-budget study only: one role compiled alone; such a kernel must not be launched)
-    arm_program<NC, EE, WALLS, ROLL, CC8, GW>(P, action, lds, lane, e, valid);
+    arm_program<NC, EE, ROLL, CC8, GW>(P, action, lds, lane, e, valid);
 #elif defined(LCR2_ONLY_CUBE)
-    cube_program<NC, EE, WALLS, ROLL, CC8, GW>(P, lds, lane, e, valid);
+    cube_program<NC, EE, ROLL, CC8, GW>(P, lds, lane, e, valid);
 #else
-    if (wave == 0) arm_program<NC, EE, WALLS, ROLL, CC8, GW>(P, action, lds, lane, e, valid);
-    else cube_program<NC, EE, WALLS, ROLL, CC8, GW>(P, lds, lane, e, valid);
+    if (wave == 0) arm_program<NC, EE, ROLL, CC8, GW>(P, action, lds, lane, e, valid);
+    else cube_program<NC, EE, ROLL, CC8, GW>(P, lds, lane, e, valid);
 #endif
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// launchers.  build.py compiles this file once per LCR_PART (10: one cube, 11: PushCubeLoop, 12: StackTwoCubes)
+// launchers.  build.py compiles this file once per LCR_PART (10: one cube, 12: StackTwoCubes, 13: StackTwoCubes with the eight-point manifold)
 // ------------------------------------------------------------------------------------------------
 static int check_launch2() {
     hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : (int)err;
 }
 
-template <int NC, bool WALLS, bool CC8>
+template <int NC, bool CC8>
 static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode, int occ, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
-#define LCR2_GO(EE, ROLL, OCC) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, WALLS, ROLL, OCC, CC8>), dim3(blocks), dim3(128), 0, st, P, action_dev)
+#define LCR2_GO(EE, ROLL, OCC) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, ROLL, OCC, CC8>), dim3(blocks), dim3(128), 0, st, P, action_dev)
     if (occ >= 2) {
         if (ee_mode) { if (P.roll) LCR2_GO(true, true, 2); else LCR2_GO(true, false, 2); }
         else { if (P.roll) LCR2_GO(false, true, 2); else LCR2_GO(false, false, 2); }
@@ -2010,21 +1848,16 @@ static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode,
 
 #if LCR_HAS_PART(10)
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<1, false, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
-}
-#endif
-#if LCR_HAS_PART(11)
-int lcr_launch_step2_walls(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<1, true, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+    return launch2_family<1, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
 }
 #endif
 #if LCR_HAS_PART(12)
 int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<2, false, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+    return launch2_family<2, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
 }
 #endif
 #if LCR_HAS_PART(13)
 int lcr_launch_step2_stack_cc8(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {   // eight-point cube<->cube manifold
-    return launch2_family<2, false, true>(P, action_dev, ee_mode, 1, (hipStream_t)stream);   // (74-80 KiB of LDS per workgroup: one wave per SIMD at most)
+    return launch2_family<2, true>(P, action_dev, ee_mode, 1, (hipStream_t)stream);   // (74-80 KiB of LDS per workgroup: one wave per SIMD at most)
 }
 #endif

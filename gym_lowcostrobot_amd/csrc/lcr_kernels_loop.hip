@@ -1,39 +1,32 @@
-// lcr_kernels.hip -- hand-written gfx950 kernels of the batched low-cost-robot simulator.
+// lcr_kernels_loop.hip -- the step kernel of PushCubeLoop (task 5: the four rails of push_cube_loop.xml:44-47, a 15-mm cube of 50 g whose
+// torsional and rolling friction coefficients are 1.5 m, push_cube_loop.xml:31).
 //
-// Mapping: ONE wavefront lane == ONE environment.  A workgroup is one wave (64 lanes), so nothing in the
-// step kernel needs a barrier; 65 536 envs = 1024 waves = one wave per SIMD of the 256 CUs.
-// State is SoA [component][env] in HBM: every per-lane scalar load/store is one fully coalesced 256-B
-// wave transaction.  State is read once at kernel entry, kept in VGPRs across all n_substeps physics
-// substeps, and written once at exit; reward / termination / TimeLimit / auto-reset are fused at the tail.
-// LDS holds the per-lane contact rows that couple into the arm (g = L^-1 J^T, 5 slots x 4..6 rows x 6 floats, laid out
-// [slot][row][k][lane] => bank-conflict free), the parked constants of the floor slots and, for Stack, the cube<->cube
-// contact records: 38-52 KiB per wave (LdsSize).  MFMA is not used: the largest contraction is 6x6.
-// Template variants of the step kernel: NC cubes (1|2), EE (ee-IK action mode), ADAPT (converged
-// solver mode), ROLL (six-row finger<->cube contacts), BIG (Stack shards of <= 3 waves per CU: every row in LDS).
+// Same mapping as lcr_kernels.hip (ONE wavefront lane == ONE environment, one wave per workgroup, state SoA [component][env], read once, kept in
+// VGPRs across the n_substeps physics substeps, written once; reward / goal switching / TimeLimit / auto-reset fused at the tail) and the same
+// contact model -- but its own CONSTRAINT SOLVER: four Gauss-Seidel sweeps that update a contact's rows ONE AT A TIME (each with its exact
+// one-row step) and then scale the friction rows radially onto the elliptic cone, all rows in one sequence (oracle:
+// orc_params.cone = 0, jacobi = 0, the defaults of this task).  The other five tasks (lcr_kernels.hip, lcr_kernels2.hip) take one projected-gradient
+// step per contact BLOCK in the second-order-cone variables with the rows in two concurrently swept groups; that step's group-wise step sizes
+// are governed, for this cube, by the 1.5-m coefficients (scaled curvature mu^2 / I four orders of magnitude above the tangential rows'), and four of
+// its sweeps leave the normal forces of a pinched cube so far from converged that cubes are thrown (oracle, 2048 envs x 200 random steps: fastest
+// cube 14 m/s, 650 rad/s, centres 20 mm under the floor; row-wise sweeps: 3.3 m/s, 57 rad/s, none under the floor; MuJoCo's optimum 3.1 m/s,
+// 66 rad/s -- tools/loop_solver_study.py).  Hence this unit.  The substep below is written for the general template parameters it shares its
+// structure with (NC, ADAPT, ROLL, BIG); only NC = 1, WALLS = true, BIG = false are instantiated (launcher at the end of the file).
 //
 // What is restated here (reference file:line, relative to /root/reference/gym_lowcostrobot/):
-//   apply_action joint mode   envs/reach_cube_env.py:248-273 (+ lift_cube_env.py:258-282 gripper)
-//   apply_action ee mode + IK envs/reach_cube_env.py:236-247, 148-221 (incl. the qpos overwrite)
-//   20 x mujoco.mj_step       envs/reach_cube_env.py:276-279 -> substep() below; the MuJoCo pipeline itself
-//                             (CRBA+armature, RNE, position actuators, soft contacts, implicitfast) follows
-//                             MuJoCo's public documentation; constants from assets/low_cost_robot_6dof/*.xml
-//   reward / success / done   envs/reach_cube_env.py:313-348, lift:322-346, push:330-361, pick_place:338-369,
-//                             stack_two_cubes_env.py:326-363; TimeLimit(50) from __init__.py:9-43
-//   reset                     envs/reach_cube_env.py:297-311, push:308-328, pick_place:316-336, stack:307-324
+//   apply_action joint / ee   envs/push_cube_loop_env.py:224-275 (as reach_cube_env.py:224-273)
+//   20 x mujoco.mj_step       envs/push_cube_loop_env.py:277-279 -> substep() below; the MuJoCo pipeline itself follows MuJoCo's public
+//                             documentation; constants from assets/low_cost_robot_6dof/push_cube_loop.xml, follower.xml
+//   step / reward / goals     envs/push_cube_loop_env.py:319-383; TimeLimit(50) from __init__.py:37-42
+//   reset                     envs/push_cube_loop_env.py:299-317
 #include "lcr_step_common.h"
-
-// translation-unit selection, see the launchers at the end of the file
-#ifndef LCR_PART
-#define LCR_PART (-1)
-#endif
-#define LCR_HAS_PART(k) (LCR_PART == -1 || LCR_PART == (k))
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool ADAPT, bool ROLL, bool BIG>
+template <int NC, bool WALLS, bool ADAPT, bool ROLL, bool BIG>
 DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
@@ -211,15 +204,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             T.aref[2] = B_DEF * vp.x;       // t2 = -x
             T.aref[3] = -B_DEF * cww[c].z;  // torsion about n
             // (an inactive slot gets inv = 0: with f = 0 its row updates then come out as exactly zero in the sweeps, no per-sweep selects)
-            {   // k[] of the block step (lcr_step_common.h soc_step): Ln = 2 (A + R)_nn, Lt = 2 (mu^2 ((A + R)_11 + (A + R)_22) + mu_tors^2 (A + R)_33)
-                const float KF = 2.f;   // (two groups, see soc_step)
-                const float Ln = KF * (minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn);
-                const float a12 = 2.f * minv + iinv * (2.f * T.r.z * T.r.z + T.r.x * T.r.x + T.r.y * T.r.y) + 2.f * Rf;
-                const float Ls = KF * P.mu_ct2 * (iinv + Rt);
-                const float Lt = fmaf(KF * P.mu_c2, a12, Ls);
-                const float iLt = T.act ? rcp(Lt) : 0.f, iLs = iLt;
-                T.inv[0] = T.act ? rcp(Ln) : 0.f; T.inv[1] = P.mu_c2 * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = P.mu_ct2 * iLs;
-            }
+            T.inv[0] = T.act ? rcp(minv + iinv * (T.r.x * T.r.x + T.r.y * T.r.y) + Rn) : 0.f;
+            T.inv[1] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.x * T.r.x) + Rf) : 0.f;
+            T.inv[2] = T.act ? rcp(minv + iinv * (T.r.z * T.r.z + T.r.y * T.r.y) + Rf) : 0.f;
+            T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
             if (c == 0 && NC == 1 && !ROLL) {
                 float4v *pk = reinterpret_cast<float4v *>(lds + LDS_G_FLOATS) + (size_t)(s * 2) * 64 + lane;
                 pk[0] = float4v{T.aref[0], T.aref[1], T.aref[2], T.aref[3]};
@@ -369,7 +357,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 f3 vrel = (S.cv[1] + cross(cww[1], r1)) - (S.cv[0] + cross(cww[0], r0));
                 f3 wrel = cww[1] - cww[0];
                 ccl[(size_t)(s * CC_REC + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CC_REC + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CC_REC + 2) * CS] = cpos[s].z;
-                float ccLn = 1.f, ccLt = 0.f;   // metric of the block step (soc_step)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const f3 d = r == 0 ? ccn : (r == 1 ? cct1 : (r == 2 ? cct2 : ccn));
@@ -389,16 +376,106 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                         } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
                     }
                     ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
-                    if (r == 0) ccLn = 2.f * (diag + Rr); else ccLt = fmaf(2.f * (r == 3 ? P.mu_ct2 : P.mu_c2), diag + Rr, ccLt);
-                }
-                {   // k[] of soc_step in the record's four "inverse diagonal" fields
-                    const float iLt = cc_act[s] ? rcp(ccLt) : 0.f;
-                    ccl[(size_t)(s * CC_REC + 11) * CS] = cc_act[s] ? rcp(ccLn) : 0.f;
-                    ccl[(size_t)(s * CC_REC + 12) * CS] = P.mu_c2 * iLt;
-                    ccl[(size_t)(s * CC_REC + 13) * CS] = ccLn * rcp(ccLn + ccLt);
-                    ccl[(size_t)(s * CC_REC + 14) * CS] = P.mu_ct2 * iLt;
+                    ccl[(size_t)(s * CC_REC + 11 + r) * CS] = cc_act[s] ? rcp(diag + Rr) : 0.f;
                 }
                 ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
+            }
+        }
+    }
+
+    // ---- collision: PushCubeLoop rails.  The four wall boxes act as their inner faces (vertical half-spaces below the wall
+    //      top).  The pen is wider than the cube in both directions, so at most one x rail and one y rail can be touched:
+    //      slots 0,1 belong to the x pair (left rail if any vertex is beyond it, else right), slots 2,3 to the y pair
+    //      (bottom if touched, else top); each pair keeps its two deepest vertices.  With axis-aligned normals the rows
+    //      have the closed form of the floor rows; the y pair is the x pair under the cyclic relabelling x->y->z->x. ----
+    FloorSlot WS[4];   // r holds the contact point in the pair's (cyclically permuted) coordinates
+    float wsg[2] = {1.f, 1.f};   // sign of the pair's normal along its axis
+    bool wall_any = false;
+    if constexpr (WALLS) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { WS[s].act = false; WS[s].r = mk(0.f, 0.f, 0.f); WS[s].Rn = 1.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { WS[s].f[k] = 0.f; WS[s].aref[k] = 0.f; WS[s].inv[k] = 0.f; } }
+        f3 vw[8];
+        float worst = 1.f;
+        bool lo_x = false, lo_y = false;
+        const bool inpen = cube_in_pen(S.cp[0]);   // (a cube outside the rails' outer rectangle touches no rail)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float sx = (i & 1) ? CH : -CH, sy = (i & 2) ? CH : -CH, sz = (i & 4) ? CH : -CH;
+            vw[i] = axpy(sx, CR[0].X, axpy(sy, CR[0].Y, sz * CR[0].Z));   // relative to the cube centre
+            const f3 p = vw[i] + S.cp[0];
+            const bool low = p.z < WALL_TOP;
+            const float dmin = fminf(fminf(p.x + WALL_X, WALL_X - p.x), fminf(p.y - WALL_Y0, WALL_Y1 - p.y));
+            worst = fminf(worst, (low && inpen) ? dmin : 1.f);
+            lo_x = lo_x || (low && inpen && p.x + WALL_X < 0.f);
+            lo_y = lo_y || (low && inpen && p.y - WALL_Y0 < 0.f);
+        }
+        wall_any = __any(worst < 0.f) != 0;
+        if (wall_any) {
+            wsg[0] = lo_x ? 1.f : -1.f;
+            wsg[1] = lo_y ? 1.f : -1.f;
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) {
+                const float sg = wsg[pr];
+                const float off = pr == 0 ? WALL_X : (sg > 0.f ? -WALL_Y0 : WALL_Y1);
+                // the two deepest vertices beyond this face (ties: lower vertex index first)
+                float d1 = 0.f, d2 = 0.f;
+                bool h1 = false, h2 = false;
+                f3 r1 = mk(0.f, 0.f, 0.f), r2 = mk(0.f, 0.f, 0.f);
+                int i1 = 0, i2 = 0;   // vertex indices of the two (diagnostics only)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const f3 p = vw[i] + S.cp[0];
+                    const float dist = fmaf(sg, pr == 0 ? p.x : p.y, off);
+                    const bool pen = dist < 0.f && p.z < WALL_TOP && inpen;
+                    const bool first = pen && (!h1 || dist < d1);
+                    const bool second = pen && !first && (!h2 || dist < d2);
+                    if (P.diag) { i2 = first ? i1 : (second ? i : i2); i1 = first ? i : i1; }
+                    d2 = first ? d1 : (second ? dist : d2);
+                    r2 = first ? r1 : (second ? vw[i] : r2);
+                    h2 = first ? h1 : (second ? true : h2);
+                    d1 = first ? dist : d1;
+                    r1 = first ? vw[i] : r1;
+                    h1 = h1 || first;
+                }
+                // pair coordinates (a, b, c) = (x, y, z) for the x pair, (y, z, x) for the y pair
+                const f3 v = pr == 0 ? S.cv[0] : mk(S.cv[0].y, S.cv[0].z, S.cv[0].x);
+                const f3 w = pr == 0 ? cww[0] : mk(cww[0].y, cww[0].z, cww[0].x);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    FloorSlot &T = WS[2 * pr + c];
+                    const float dist = c == 0 ? d1 : d2;
+                    const f3 rw = c == 0 ? r1 : r2;
+                    T.act = c == 0 ? h1 : h2;
+                    if (P.diag) diag_choice(DG, T.act, 8 + 2 * pr + c, (c == 0 ? i1 : i2) + 8 * (2 * pr + (sg > 0.f ? 0 : 1)));
+                    f3 r = pr == 0 ? rw : mk(rw.y, rw.z, rw.x);
+                    r.x = fmaf(-0.5f * dist, sg, r.x);   // contact point midway between vertex and face
+                    T.r = r;
+                    float imp = impedance(dist, D0_DEF, DW_DEF, 1.0f / W_DEF);
+                    float Rn = fmaxf((1.f - imp) * rcp(imp) * minv, 1e-15f);
+                    float Rf = Rn * P.inv_impratio;
+                    float Rt = Rf * P.rt_cube;
+                    T.Rn = Rn;
+                    const f3 vp = v + cross(w, r);   // velocity of the contact point; n = (sg,0,0), t1 = (0,1,0), t2 = (0,0,sg)
+                    T.aref[0] = -B_DEF * sg * vp.x - K_DEF * imp * dist;
+                    T.aref[1] = -B_DEF * vp.y;
+                    T.aref[2] = -B_DEF * sg * vp.z;
+                    T.aref[3] = -B_DEF * sg * w.x;
+                    T.inv[0] = T.act ? rcp(minv + iinv * (r.y * r.y + r.z * r.z) + Rn) : 0.f;
+                    T.inv[1] = T.act ? rcp(minv + iinv * (r.x * r.x + r.z * r.z) + Rf) : 0.f;
+                    T.inv[2] = T.act ? rcp(minv + iinv * (r.x * r.x + r.y * r.y) + Rf) : 0.f;
+                    T.inv[3] = T.act ? rcp(iinv + Rt) : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) T.f[k] = T.act ? W.wall[2 * pr + c][k] : 0.f;   // warm start
+                    // a += M^-1 J^T f in pair coordinates
+                    const float la = minv * sg * T.f[0], lb = minv * T.f[1], lc = minv * sg * T.f[2];
+                    const float aa = iinv * (-r.z * T.f[1] + sg * r.y * T.f[2] + sg * T.f[3]);
+                    const float ab = iinv * sg * (r.z * T.f[0] - r.x * T.f[2]);
+                    const float ac = iinv * (-sg * r.y * T.f[0] + r.x * T.f[1]);
+                    if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
+                    else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
+                }
             }
         }
     }
@@ -410,6 +487,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool link_on_cube = false;       // slot 4: this lane's contact is against a cube (else the floor)
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
     int link_bi = 0;             // slot 4: which proxy
+    float link_htop = 0.f;       // slot 4 on the floor: height of the surface under the proxy (PushCubeLoop: a rail's top face, D7)
     int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
@@ -443,9 +521,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             dist = bestd;
             slot_cube[sp] = cidx;
         } else if (s < 4) {
-            dist = sph[sp].z - srad[sp];
-            pos = mk(sph[sp].x, sph[sp].y, 0.5f * dist);
-            sel = 0;
+            const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
+            dist = sph[sp].z - srad[sp] - htop;
+            pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
+            sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
         } else if (P.arm_collision) {
             // arm-link proxies (D3): both ends of link_3, link_4 motor, link_5 motor body, link_6 jaw root.  One contact: the
             // deepest candidate in the order proxy 0 floor, proxy 1 floor, proxy 2 floor, proxy 3 floor, proxy 3 cubes, proxy 4
@@ -467,8 +546,13 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int i = 0; i < 5; i++) {
                 const int L = plink[i];
                 const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
-                const float df = cz - pr[i];
-                if (df < bestd) { bestd = df; bi = i; oncube = false; }
+                float df = cz - pr[i], hi = 0.f;
+                if constexpr (WALLS) {   // (D7) above a rail's footprint the surface is the rail's top face
+                    const f3 cw_ = local_point(F, L, px[i], py[i], pz[i]);
+                    hi = rail_top(cw_.x, cw_.y);
+                    df -= hi;
+                }
+                if (df < bestd) { bestd = df; bi = i; oncube = false; link_htop = hi; }
                 if (i >= 3 && wave_near) {
                     const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
 #pragma unroll
@@ -479,7 +563,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
             link_bi = bi;
-            if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = 0; }
+            if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = link_htop > 0.f ? 1 : 0; }
             sel += 64 * (bi + 1);
             dist = bestd;
             link_on_cube = oncube;
@@ -510,7 +594,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
                     cb = f2v{m, m} * ci + cb;
                 }
-                if (!oncube) pos = mk(cb.x, cb.y, 0.5f * dist);
+                if (!oncube) pos = mk(cb.x, cb.y, link_htop + 0.5f * dist);
             }
             if (may_cube) make_frame(n, T.t1, T.t2);   // (for n = +z this is the floor frame t1 = +y, t2 = -x)
             // joints that move the contact point: the finger spheres sit on link_5 / link_6, the proxies on link_3..link_6
@@ -532,11 +616,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             float Rf = Rn * P.inv_impratio;
             float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
             T.Rn = Rn;
-            // squared friction coefficients of this slot's rows (finger<->cube pair: max rule; finger geoms mu 1.5 / torsional 0.005; a link proxy on the
-            // floor mu 1, on a cube the cube's) and the metric of the block step (soc_step)
-            const float m2_tan = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
-            const float m2_tors = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : P.mu_ct2);
-            float Ln = 1.f, Lt = 0.f;
             // point Jacobian columns of the link at the contact point
             f3 jc[6];
 #pragma unroll
@@ -588,13 +667,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
                 const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
-                {
-                    const float arr = gg + diagc + Rr;
-                    const float m2r = r == 0 ? 1.f : (r < 3 ? m2_tan : (r == 3 ? m2_tors : P.mu_fcr2));
-                    const float KF = 2.f;
-                    if (r == 0) Ln = KF * arr;
-                    else Lt = fmaf(row_on ? KF * m2r : 0.f, arr, Lt);
-                }
+                T.inv[r] = row_on ? rcp(gg + diagc + Rr) : 0.f;              // (a row that is off: f = 0 and inv = 0 -> its updates are exactly 0)
                 const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
 #pragma unroll
@@ -606,11 +679,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
                     else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
                 }
-            }
-            {   // k[] of soc_step: iLn, mu_tan^2 iLt, w, mu_tors^2 iLt (, mu_roll^2 iLt)
-                const float iLn = T.act ? rcp(Ln) : 0.f, iLt = T.act ? rcp(Lt) : 0.f, iLs = iLt;
-                T.inv[0] = iLn; T.inv[1] = m2_tan * iLt; T.inv[2] = Ln * rcp(Ln + Lt); T.inv[3] = (s != 4 || oncube) ? m2_tors * iLs : 0.f;   // (a link proxy on the floor has no torsion row: condim 3)
-                if constexpr (ROLL) { T.inv[4] = P.mu_fcr2 * iLs; T.inv[5] = 0.f; }
             }
         }
     }
@@ -656,121 +724,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 fmx = fmaxf(fmaxf(fmx, fmaxf(fabsf(f0), fabsf(f1))), fmaxf(fabsf(f2), fabsf(f3_)));
             }
         };
-        // ---- one arm-coupled slot (finger spheres, arm-link proxies): a block step on its rows ----
-        // The rows of a sweep form two groups that are swept as if concurrently (what the two-wave kernels do with two waves; oracle: orc_params.jacobi) --
-        //   A: joint limits, finger<->floor (slots 2, 3), arm-link proxies (slot 4)          B: floor<->cube, cube<->cube, rails, finger<->cube (slots 0, 1)
-        // Gauss-Seidel inside a group; a group sees the other group's effect on the shared unknowns (the arm acceleration y through slots 0, 1; the cube
-        // accelerations through slot 4) as of the START of the sweep.  In program order group A runs first: y then carries A's changes, yB keeps the sweep-start
-        // value for slots 0, 1 (whose changes go to both copies), and slot 4's change of the cube accelerations is held back in dcaA until the end of the sweep.
-        float yB[6];
-        f3 dcaA[NC], dcalA[NC];
-#pragma unroll
-        for (int k = 0; k < 6; k++) yB[k] = y[k];
-#pragma unroll
-        for (int c = 0; c < NC; c++) { dcaA[c] = mk(0.f, 0.f, 0.f); dcalA[c] = mk(0.f, 0.f, 0.f); }
-        auto arm_slot = [&](auto s_tag) {
-            constexpr int s = decltype(s_tag)::value;
-            if (!wave_arm || !slot_any[s]) return;
-            ArmSlot<NRW> &T = AS[s];
-            const bool may_cube = s < 2 || s == 4;
-            const bool oncube = s < 2 || (s == 4 && link_on_cube);
-            constexpr bool roll = ROLL;
-            const int nrow = (roll && s < 2) ? 6 : 4;
-            const float Rf = T.Rn * P.inv_impratio;
-            const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
-            // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
-            float2v g[NRW][3];
-#pragma unroll
-            for (int r = 0; r < nrow; r++)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    g[r][k] = (NC == 2 && !BIG && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
-                              : (NC == 2 && !BIG && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
-                                                  : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
-            // group B (finger<->cube, s < 2) works from y as of the start of the sweep (yB) and its changes go to BOTH copies; group A (s >= 2) works on y
-            float2v yp[3] = {{s < 2 ? yB[0] : y[0], s < 2 ? yB[1] : y[1]}, {s < 2 ? yB[2] : y[2], s < 2 ? yB[3] : y[3]}, {s < 2 ? yB[4] : y[4], s < 2 ? yB[5] : y[5]}};
-            float2v yq[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
-            float arefv[NRW], invv[NRW], f_in[NRW];
-#pragma unroll
-            for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; f_in[r] = T.f[r]; }
-            // pick the cube this slot talks to (wave-divergent only for Stack)
-            f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
-            const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
-            if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
-            // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
-            const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
-            // the cube's share of the gradient rows: v_r = d_r . (acceleration of the cube's contact point), wn / w1 / w2 = (n, t1, t2) . (angular acceleration)
-            float vq[3] = {0.f, 0.f, 0.f}, wn = 0.f, w1 = 0.f, w2 = 0.f;
-            if (may_cube) {
-                const f3 Ac = a_lin + cross(a_ang, T.rc);
-                vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
-                wn = dot(T.n, a_ang);
-                if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
-                if (s == 4) {   // floor lanes: no cube share in the rows
-#pragma unroll
-                    for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
-                    wn = oncube ? wn : 0.f;
-                }
-            }
-            // gradient rows of the block from the SAME forces (no serial dependence inside the block), one projected-gradient step (soc_step), then y follows
-            float u[NRW], fcur[NRW], nf[NRW];
-#pragma unroll
-            for (int r = 0; r < NRW; r++) {
-                fcur[r] = T.f[r];
-                u[r] = 0.f;
-                if (r < nrow) {
-                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
-                    const float gy = acc.x + acc.y;
-                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
-                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
-                    if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
-                    u[r] = gy + jc_a - arefv[r] + Rr * fcur[r];
-                }
-            }
-            {   // (finger geoms: mu 1.5 / torsional 0.005; finger<->cube pair: max rule; a link proxy on the floor: mu 1, on a cube: the cube's friction)
-                const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
-                const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
-                soc_step<NRW>(fcur, u, invv, imu2, imt2, P.inv_mu_fcr2, nrow, nf);
-            }
-#pragma unroll
-            for (int r = 0; r < NRW; r++) {
-                if (r < nrow) {
-                    const float dlt = nf[r] - fcur[r];
-                    T.f[r] = nf[r];
-                    const float2v d2 = {dlt, dlt};
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { yp[k] = g[r][k] * d2 + yp[k]; if (s < 2) yq[k] = g[r][k] * d2 + yq[k]; }
-                }
-            }
-            // (converged mode: the net force change of this sweep)
-            track(T.f[0] - f_in[0], T.f[1] - f_in[1], T.f[2] - f_in[2], T.f[3] - f_in[3], T.f[0], T.f[1], T.f[2], T.f[3]);
-            if constexpr (ROLL) { if (nrow == 6) track(T.f[4] - f_in[4], T.f[5] - f_in[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
-            f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
-            if (may_cube) {
-                const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
-                const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
-                dl_lin = (-minv_e) * Fd;
-                f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
-                if constexpr (ROLL) { if (nrow == 6) Td = axpy(T.f[4] - f_in[4], T.t1, axpy(T.f[5] - f_in[5], T.t2, Td)); }
-                dl_ang = (-iinv_e) * Td;
-            }
-            if (s < 2) {
-                yB[0] = yp[0].x; yB[1] = yp[0].y; yB[2] = yp[1].x; yB[3] = yp[1].y; yB[4] = yp[2].x; yB[5] = yp[2].y;
-                y[0] = yq[0].x; y[1] = yq[0].y; y[2] = yq[1].x; y[3] = yq[1].y; y[4] = yq[2].x; y[5] = yq[2].y;
-            } else {
-                y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
-            }
-            if (may_cube) {
-                // slots 0, 1 (group B) change the cube accelerations the group is sweeping; slot 4 (group A) read them as of the start of the sweep (it runs
-                // before group B's rows) and its change is held back until the end of the sweep
-                f3 (&tca)[NC] = s == 4 ? dcaA : ca;
-                f3 (&tcal)[NC] = s == 4 ? dcalA : cal;
-                if (NC == 2) {
-                    if (second) { tca[NC - 1] = tca[NC - 1] + dl_lin; tcal[NC - 1] = tcal[NC - 1] + dl_ang; }
-                    else { tca[0] = tca[0] + dl_lin; tcal[0] = tcal[0] + dl_ang; }
-                } else { tca[0] = tca[0] + dl_lin; tcal[0] = tcal[0] + dl_ang; }
-            }
-        };
         if (wave_lim) {
 #pragma unroll
             for (int j = 0; j < 6; j++) {
@@ -797,10 +750,6 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], dl, y[k]);
             }
         }
-        // group A: finger<->floor, arm-link proxies (after the joint limits above)
-        arm_slot(std::integral_constant<int, 2>{});
-        arm_slot(std::integral_constant<int, 3>{});
-        arm_slot(std::integral_constant<int, 4>{});
         // floor <-> cube
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -810,7 +759,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const f3 r = T.r;
                 const float Rf = T.Rn * P.inv_impratio;
                 const float Rt = Rf * P.rt_cube;
-                // rows J_r = [d_r ; c_r], d = (z, y, -x, 0), c = (r x d) resp. z for the torsion row: the gradient rows u_r against the CURRENT accelerations
+                // Block form of the four Gauss-Seidel row updates of this contact (same arithmetic as row-by-row GS):
+                // rows J_r = [d_r ; c_r], d = (z, y, -x, 0), c = (r x d) resp. z for the torsion row.  The row residuals
+                // against the CURRENT acceleration (u_r) are independent of each other; the coupling inside the contact is
+                // the 4x4 block B = J M^-1 J^T, so the dependent chain is 4 short steps instead of 4 full row sweeps.
                 float aref0 = T.aref[0], aref1 = T.aref[1], aref2 = T.aref[2], aref3 = T.aref[3];
                 float inv0 = T.inv[0], inv1 = T.inv[1], inv2 = T.inv[2], inv3 = T.inv[3];
                 if (c == 0 && NC == 1 && !ROLL) {
@@ -823,12 +775,19 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const float u1 = ca[c].y - r.z * cal[c].x + r.x * cal[c].z - aref1 + Rf * T.f[1];
                 const float u2 = -ca[c].x - r.z * cal[c].y + r.y * cal[c].z - aref2 + Rf * T.f[2];
                 const float u3 = cal[c].z - aref3 + Rt * T.f[3];
-                // one projected-gradient step of the whole block (soc_step): the four gradient rows above are taken from the same accelerations
-                const float uu[4] = {u0, u1, u2, u3}, kk[4] = {inv0, inv1, inv2, inv3};
-                float nf[4];
-                soc_step<4>(T.f, uu, kk, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);
-                const float d0 = nf[0] - T.f[0], d1 = nf[1] - T.f[1], d2 = nf[2] - T.f[2], d3 = nf[3] - T.f[3];   // (inactive slot: f = 0, k = 0 -> every delta is 0)
-                T.f[0] = nf[0]; T.f[1] = nf[1]; T.f[2] = nf[2]; T.f[3] = nf[3];
+                const float B01 = -iinv * r.y * r.z, B02 = iinv * r.x * r.z, B12 = iinv * r.x * r.y, B13 = iinv * r.x, B23 = iinv * r.y;
+                float nf = fmaxf(T.f[0] - u0 * inv0, 0.f);
+                const float d0 = nf - T.f[0];                               // (inactive slot: f = 0, inv = 0 -> every delta is 0)
+                const float d1a = -(u1 + B01 * d0) * inv1;
+                const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv2;
+                const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv3;
+                // elliptic cone: radial projection of the friction part
+                const float fn = T.f[0] + d0;
+                const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
+                T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
                 track(d0, d1, d2, d3, T.f[0], T.f[1], T.f[2], T.f[3]);   // (converged mode: net change of the sweep, after the cone projection)
                 // a += M^-1 J^T delta
                 ca[c].z = fmaf(minv, d0, ca[c].z);
@@ -864,13 +823,24 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float u1 = dot(cct1, A) - aref[1] + Rf * f[1];
                     const float u2 = dot(cct2, A) - aref[2] + Rf * f[2];
                     const float u3 = dot(ccn, Wr) - aref[3] + Rt * f[3];
-                    const float uu[4] = {u0, u1, u2, u3};
-                    float nf[4];
-                    soc_step<4>(f, uu, inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);   // one projected-gradient step of the block (lcr_step_common.h)
-                    const float d0 = nf[0] - f[0], e1 = nf[1] - f[1], e2 = nf[2] - f[2], e3 = nf[3] - f[3];
-                    track(d0, e1, e2, e3, nf[0], nf[1], nf[2], nf[3]);
-                    ccl[(size_t)(s * CC_REC + 3) * CS] = nf[0]; ccl[(size_t)(s * CC_REC + 4) * CS] = nf[1];
-                    ccl[(size_t)(s * CC_REC + 5) * CS] = nf[2]; ccl[(size_t)(s * CC_REC + 6) * CS] = nf[3];
+                    const float p00 = dot(r0, ccn), p01 = dot(r0, cct1), p02 = dot(r0, cct2);
+                    const float p10 = dot(r1, ccn), p11 = dot(r1, cct1), p12 = dot(r1, cct2);
+                    const float B01 = -iinv * (p00 * p01 + p10 * p11), B02 = -iinv * (p00 * p02 + p10 * p12), B12 = -iinv * (p01 * p02 + p11 * p12);
+                    const float B13 = -iinv * (p02 + p12), B23 = iinv * (p01 + p11);   // n.((r0+r1) x t1) = -(r0+r1).t2, n.((r0+r1) x t2) = (r0+r1).t1
+                    const float nf = fmaxf(f[0] - u0 * inv[0], 0.f);
+                    const float d0 = nf - f[0];
+                    const float d1a = -(u1 + B01 * d0) * inv[1];
+                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * inv[2];
+                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * inv[3];
+                    // elliptic cone: radial projection of the friction part
+                    const float fn = f[0] + d0;
+                    const float g1 = f[1] + d1a, g2 = f[2] + d2a, g3 = f[3] + d3a;
+                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                    const float e1 = g1 * sc - f[1], e2 = g2 * sc - f[2], e3 = g3 * sc - f[3];
+                    track(d0, e1, e2, e3, fn, f[1] + e1, f[2] + e2, f[3] + e3);
+                    ccl[(size_t)(s * CC_REC + 3) * CS] = fn; ccl[(size_t)(s * CC_REC + 4) * CS] = f[1] + e1;
+                    ccl[(size_t)(s * CC_REC + 5) * CS] = f[2] + e2; ccl[(size_t)(s * CC_REC + 6) * CS] = f[3] + e3;
                     // a += M^-1 J^T delta: the force change F acts at the contact point on cube 1 and, negated, on cube 0
                     const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
                     const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
@@ -879,11 +849,185 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
         }
-        // group B, second part: finger<->cube
-        arm_slot(std::integral_constant<int, 0>{});
-        arm_slot(std::integral_constant<int, 1>{});
+        // rails (PushCubeLoop): block form of the four rows of each contact, as for the floor
+        if constexpr (WALLS) {
+            if (wall_any) {
 #pragma unroll
-        for (int c = 0; c < NC; c++) { ca[c] = ca[c] + dcaA[c]; cal[c] = cal[c] + dcalA[c]; }   // group A's share of the cube accelerations (slot 4)
+                for (int s = 0; s < 4; s++) {
+                    FloorSlot &T = WS[s];
+                    const int pr = s >> 1;
+                    const float sg = wsg[pr];
+                    const f3 r = T.r;
+                    const float Rf = T.Rn * P.inv_impratio, Rt = Rf * P.rt_cube;
+                    const f3 a = pr == 0 ? ca[0] : mk(ca[0].y, ca[0].z, ca[0].x);
+                    const f3 w = pr == 0 ? cal[0] : mk(cal[0].y, cal[0].z, cal[0].x);
+                    const float u0 = sg * (a.x + r.z * w.y - r.y * w.z) - T.aref[0] + T.Rn * T.f[0];
+                    const float u1 = a.y - r.z * w.x + r.x * w.z - T.aref[1] + Rf * T.f[1];
+                    const float u2 = sg * (a.z + r.y * w.x - r.x * w.y) - T.aref[2] + Rf * T.f[2];
+                    const float u3 = sg * w.x - T.aref[3] + Rt * T.f[3];
+                    const float B01 = -sg * iinv * r.x * r.y, B02 = -iinv * r.x * r.z, B12 = -sg * iinv * r.y * r.z;
+                    const float B13 = -sg * iinv * r.z, B23 = iinv * r.y;
+                    const float nf = fmaxf(T.f[0] - u0 * T.inv[0], 0.f);
+                    const float d0 = nf - T.f[0];
+                    const float d1a = -(u1 + B01 * d0) * T.inv[1];
+                    const float d2a = -(u2 + B02 * d0 + B12 * d1a) * T.inv[2];
+                    const float d3a = -(u3 + B13 * d1a + B23 * d2a) * T.inv[3];
+                    // elliptic cone: radial projection of the friction part
+                    const float fn = T.f[0] + d0;
+                    const float g1 = T.f[1] + d1a, g2 = T.f[2] + d2a, g3 = T.f[3] + d3a;
+                    const float s2 = (g1 * g1 + g2 * g2) * P.inv_mu_c2 + g3 * g3 * P.inv_mu_ct2;
+                    const float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+                    const float d1 = g1 * sc - T.f[1], d2 = g2 * sc - T.f[2], d3 = g3 * sc - T.f[3];
+                    T.f[0] = fn; T.f[1] += d1; T.f[2] += d2; T.f[3] += d3;
+                    track(d0, d1, d2, d3, T.f[0], T.f[1], T.f[2], T.f[3]);
+                    const float la = minv * sg * d0, lb = minv * d1, lc = minv * sg * d2;
+                    const float aa = iinv * (-r.z * d1 + sg * r.y * d2 + sg * d3);
+                    const float ab = iinv * sg * (r.z * d0 - r.x * d2);
+                    const float ac = iinv * (-sg * r.y * d0 + r.x * d1);
+                    if (pr == 0) { ca[0] = ca[0] + mk(la, lb, lc); cal[0] = cal[0] + mk(aa, ab, ac); }
+                    else { ca[0] = ca[0] + mk(lc, la, lb); cal[0] = cal[0] + mk(ac, aa, ab); }
+                }
+            }
+        }
+        // arm-coupled slots: finger spheres, arm-link proxies
+        if (wave_arm) {
+#pragma unroll
+            for (int s = 0; s < NAS; s++) {
+                if (!slot_any[s]) continue;
+                ArmSlot<NRW> &T = AS[s];
+                const bool may_cube = s < 2 || s == 4;
+                const bool oncube = s < 2 || (s == 4 && link_on_cube);
+                constexpr bool roll = ROLL;
+                const int nrow = (roll && s < 2) ? 6 : 4;
+                const float Rf = T.Rn * P.inv_impratio;
+                const float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
+                // the six arm components travel as three float2 pairs: dot products and updates become v_pk_mul/v_pk_fma
+                float2v g[NRW][3];
+#pragma unroll
+                for (int r = 0; r < nrow; r++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        g[r][k] = (NC == 2 && !BIG && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
+                                  : (NC == 2 && !BIG && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
+                                                      : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                float2v yp[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
+                float arefv[NRW], invv[NRW], f_in[NRW];
+#pragma unroll
+                for (int r = 0; r < NRW; r++) { arefv[r] = T.aref[r]; invv[r] = T.inv[r]; f_in[r] = T.f[r]; }
+                // pick the cube this slot talks to (wave-divergent only for Stack)
+                f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
+                const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
+                if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+                // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
+                const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
+                // The cube's share of the four row residuals is tracked as SCALARS: v_r = d_r . (acceleration of the contact
+                // point of the cube), wn = n . (angular acceleration).  A force change dlt on row j moves them by closed-form
+                // couplings, because (rc x d_i).(rc x d_j) = |rc|^2 delta_ij - (rc.d_i)(rc.d_j) for the orthonormal frame:
+                //   v_i -= dlt (k delta_ij - iinv p_i p_j), k = minv + iinv |rc|^2, p_i = rc . d_i;   wn -= iinv dlt n.(rc x d_j)
+                // and the summed force is applied to the cube once at the end of the slot.
+                // (ROLL: the rolling rows need the angular acceleration about t1 and t2 as well: wq = (n, t1, t2) . alpha, wn = wq[0])
+                float vq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f}, wn = 0.f, kq = 0.f, w1 = 0.f, w2 = 0.f;
+                if (may_cube) {
+                    const f3 Ac = a_lin + cross(a_ang, T.rc);
+                    vq[0] = dot(T.n, Ac); vq[1] = dot(T.t1, Ac); vq[2] = dot(T.t2, Ac);
+                    pq[0] = dot(T.rc, T.n); pq[1] = dot(T.rc, T.t1); pq[2] = dot(T.rc, T.t2);
+                    wn = dot(T.n, a_ang);
+                    if (nrow == 6) { w1 = dot(T.t1, a_ang); w2 = dot(T.t2, a_ang); }
+                    kq = fmaf(iinv_e, dot(T.rc, T.rc), minv_e);
+                    if (s == 4) {   // floor lanes: no cube share in the residuals
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = oncube ? vq[i] : 0.f;
+                        wn = oncube ? wn : 0.f;
+                    }
+                }
+                // effect of a force change dlt on row j on the tracked scalars
+                auto couple = [&](int j, float dlt) {
+                    if (j < 3) {
+                        const float c = iinv_e * pq[j] * dlt;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) vq[i] = fmaf(c, pq[i], vq[i]);
+                        vq[j] = fmaf(-kq, dlt, vq[j]);
+                        // n.(rc x t1) = -rc.t2, n.(rc x t2) = rc.t1, n.(rc x n) = 0
+                        if (j == 1) wn = fmaf(iinv_e * dlt, pq[2], wn);
+                        if (j == 2) wn = fmaf(-iinv_e * dlt, pq[1], wn);
+                        if (nrow == 6) {   // d_i . (rc x d_j) = rc . (d_j x d_i), right-handed frame n x t1 = t2, t1 x t2 = n, t2 x n = t1
+                            if (j == 0) { w1 = fmaf(-iinv_e * dlt, pq[2], w1); w2 = fmaf(iinv_e * dlt, pq[1], w2); }
+                            if (j == 1) w2 = fmaf(-iinv_e * dlt, pq[0], w2);
+                            if (j == 2) w1 = fmaf(iinv_e * dlt, pq[0], w1);
+                        }
+                    } else if (j == 3) {   // torsion: angular acceleration changes by -iinv dlt n; contact point by (-iinv dlt n) x rc
+                        wn = fmaf(-iinv_e, dlt, wn);
+                        vq[1] = fmaf(iinv_e * dlt, pq[2], vq[1]);    // t1.(n x rc) = -p_2
+                        vq[2] = fmaf(-iinv_e * dlt, pq[1], vq[2]);   // t2.(n x rc) =  p_1
+                    } else if (j == 4) {   // rolling about t1: alpha -= iinv dlt t1; point acceleration += (-iinv dlt t1) x rc
+                        w1 = fmaf(-iinv_e, dlt, w1);
+                        vq[0] = fmaf(-iinv_e * dlt, pq[2], vq[0]);   // n.(t1 x rc)  =  p_2
+                        vq[2] = fmaf(iinv_e * dlt, pq[0], vq[2]);    // t2.(t1 x rc) = -p_0
+                    } else {               // rolling about t2
+                        w2 = fmaf(-iinv_e, dlt, w2);
+                        vq[0] = fmaf(iinv_e * dlt, pq[1], vq[0]);    // n.(t2 x rc)  = -p_1
+                        vq[1] = fmaf(-iinv_e * dlt, pq[0], vq[1]);   // t1.(t2 x rc) =  p_0
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < nrow; r++) {
+                    const float2v acc = g[r][0] * yp[0] + g[r][1] * yp[1] + g[r][2] * yp[2];
+                    const float gy = acc.x + acc.y;
+                    float jc_a = may_cube ? (r < 3 ? -vq[r] : -wn) : 0.f;
+                    float Rr = r == 0 ? T.Rn : (r == 3 ? Rt : Rf);
+                    if (ROLL && r > 3) { jc_a = r == 4 ? -w1 : -w2; Rr = Rf * P.rr_fc; }
+                    float res = gy + jc_a - arefv[r] + Rr * T.f[r];
+                    float nf = T.f[r] - res * invv[r];
+                    if (r == 0) nf = fmaxf(nf, 0.f);
+                    float dlt = nf - T.f[r];
+                    T.f[r] += dlt;
+                    {
+                        const float2v d2 = {dlt, dlt};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                    }
+                    if (may_cube) couple(r, dlt);
+                }
+                // cone projection (finger geoms: mu 1.5; a link proxy on the floor: mu 1; on a cube: the cube's friction)
+                {
+                    float fn = T.f[0];
+                    const float imu2 = s < 4 ? 1.f / (MU_FINGER * MU_FINGER) : (oncube ? P.inv_mu_c2 : 1.f);
+                    const float imt2 = s < 2 ? P.inv_mu_fct2 : (s < 4 ? 1.f / (MU_TORS * MU_TORS) : P.inv_mu_ct2);
+                    float s2 = (T.f[1] * T.f[1] + T.f[2] * T.f[2]) * imu2 + (nrow >= 4 ? T.f[3] * T.f[3] * imt2 : 0.f);
+                    if constexpr (ROLL) { if (nrow == 6) s2 = fmaf(T.f[4] * T.f[4] + T.f[5] * T.f[5], P.inv_mu_fcr2, s2); }
+                    float sc = clampf(fn * rsq(fmaxf(s2, 1e-30f)), 0.f, 1.f);
+#pragma unroll
+                    for (int r = 1; r < nrow; r++) {
+                        float dlt = T.f[r] * sc - T.f[r];
+                        T.f[r] += dlt;
+                        const float2v d2 = {dlt, dlt};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) yp[k] = g[r][k] * d2 + yp[k];
+                        // (the tracked scalars are not needed any more: the next slot starts from the updated accelerations)
+                    }
+                }
+                // (converged mode: the NET force change of this sweep, after the cone projection -- a sliding contact at its projected fixed
+                //  point has a non-zero raw tangential update every sweep, which is then scaled back)
+                track(T.f[0] - f_in[0], T.f[1] - f_in[1], T.f[2] - f_in[2], T.f[3] - f_in[3], T.f[0], T.f[1], T.f[2], T.f[3]);
+                if constexpr (ROLL) { if (nrow == 6) track(T.f[4] - f_in[4], T.f[5] - f_in[5], 0.f, 0.f, T.f[4], T.f[5], 0.f, 0.f); }
+                f3 dl_lin = mk(0.f, 0.f, 0.f), dl_ang = mk(0.f, 0.f, 0.f);  // change of the cube acceleration by this slot
+                if (may_cube) {
+                    const float e0 = T.f[0] - f_in[0], e1 = T.f[1] - f_in[1], e2 = T.f[2] - f_in[2], e3 = T.f[3] - f_in[3];
+                    const f3 Fd = axpy(e0, T.n, axpy(e1, T.t1, e2 * T.t2));   // force change on the arm; the cube gets -Fd at rc
+                    dl_lin = (-minv_e) * Fd;
+                    f3 Td = axpy(e3, T.n, cross(T.rc, Fd));
+                    if constexpr (ROLL) { if (nrow == 6) Td = axpy(T.f[4] - f_in[4], T.t1, axpy(T.f[5] - f_in[5], T.t2, Td)); }
+                    dl_ang = (-iinv_e) * Td;
+                }
+                y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
+                if (may_cube) {
+                    if (NC == 2) {
+                        if (second) { ca[NC - 1] = ca[NC - 1] + dl_lin; cal[NC - 1] = cal[NC - 1] + dl_ang; }
+                        else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
+                    } else { ca[0] = ca[0] + dl_lin; cal[0] = cal[0] + dl_ang; }
+                }
+            }
+        }
         sweeps_done = it + 1;
         if (ADAPT) {
             if (__all(chg <= P.pgs_tol * (1.f + fmx))) break;
@@ -912,6 +1056,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
+            if (WALLS) m |= WS[s].act ? (1u << (8 + s)) : 0u;
         }
         m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u;
         m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;
@@ -925,6 +1070,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = flim[j];
+    if constexpr (WALLS) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) W.wall[s][k] = WS[s].f[k];
+    }
 
     // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y -------------------
     float rhs[6];
@@ -975,9 +1126,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG>
+template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL, bool BIG>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[LdsSize<NC, false, ROLL, BIG>::value];
+    __shared__ float lds[LdsSize<NC, WALLS, ROLL, BIG>::value];
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -990,6 +1141,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     f3 target = mk(0.f, 0.f, 0.f);
     if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
     int elapsed = P.elapsed[e];
+    int goal = WALLS ? P.goal[e] : 0;
 
     // ---- apply_action (reach_cube_env.py:223-273) ------------------------------------------------
     float act[6];
@@ -1084,6 +1236,10 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = wld(WARM_LIM + j);
 #pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) W.wall[s][k] = WALLS ? wld(WARM_WALL + 4 * s + k) : 0.f;
+#pragma unroll
     for (int s = 0; s < 4; s++) W.cc_prev[s] = false;
     if constexpr (NC == 2) {   // cube<->cube forces live in their LDS records between substeps
         float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;
@@ -1095,7 +1251,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         }
     }
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, ADAPT, ROLL, BIG>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
@@ -1116,7 +1272,19 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         else { a3 = lag_cube[0]; b3 = target; }
         f3 df = a3 - b3;
         float d = sqrtf(dot(df, df));
-        if (task == 1) {  // lift:341-345: (cube_z - height_threshold) + distance, never terminates, info = {}
+        if (task == 5) {  // PushCubeLoop get_reward / get_cube_overlap (push_cube_loop_env.py:334-383), FRESH cube position
+            const float xc = S.cp[0].x, yc = S.cp[0].y, wc = 0.0075f;            // cube_size = 0.015 / 2 (:124)
+            const float gx = goal ? -0.06f : 0.06f, gy = 0.135f;                 // push_cube_loop.xml:38,41
+            const float gh0 = 0.0095f, gh1 = 0.0145f;                            // goal_region_high[:2] (:133-134)
+            const float xo = fmaxf(0.f, fminf(xc + wc, gx + gh0) - fmaxf(xc - wc, gx - gh0));
+            const float yo = fmaxf(0.f, fminf(yc + wc, gy + gh1) - fmaxf(yc - wc, gy - gh1));
+            const float overlap = xo * yo * (1.f / (4.f * 0.0075f * 0.0075f));
+            success = overlap > 0.95f;
+            terminated = false;
+            const float edge = -gh1 + gy;
+            reward = success ? 5.f : (overlap > 0.f ? overlap - 1.f : clampf(-fabsf(yc - edge) * (1.f / 0.16f) - 1.f, -2.f, -1.f));
+            if (success) goal = 1 - goal;                                         // the goal side switches and PERSISTS (:341)
+        } else if (task == 1) {  // lift:341-345: (cube_z - height_threshold) + distance, never terminates, info = {}
             reward = (lag_cube[0].z - P.height_thr) + d;
             success = false; terminated = false;
         } else {
@@ -1159,7 +1327,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
                 for (int k = 0; k < 4; k++) P.term_quat[(size_t)(4 * c + k) * N + e] = S.cq[c][k];   // completes the terminal pose (frames of recordings)
         }
         Pcg g = load_rng(P, e);
-        reset_env<NC>(P, S, g, target, lag_ee, 0);
+        reset_env<NC>(P, S, g, target, lag_ee, goal);
         if (diverged) {
 #pragma unroll
             for (int j = 0; j < 6; j++) S.qd[j] = 0.f;
@@ -1176,6 +1344,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         store_state<NC>(P, e, S);
         P.elapsed[e] = elapsed;
         P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
+        if (WALLS) P.goal[e] = goal;
         if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);  // data.time advances in mj_step only
     }
     if (carry && valid) {   // forces for the next control step's first substep; an env that was just reset starts from zero
@@ -1192,6 +1361,12 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
             for (int k = 0; k < (ROLL ? 6 : 4); k++) wst(WARM_ARM + 6 * s + k, W.arm[s][k]);
 #pragma unroll
         for (int j = 0; j < 6; j++) wst(WARM_LIM + j, W.lim[j]);
+        if constexpr (WALLS) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) wst(WARM_WALL + 4 * s + k, W.wall[s][k]);
+        }
         if constexpr (NC == 2) {
             const float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;
 #pragma unroll
@@ -1203,163 +1378,26 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         }
     }
 }
-
-// ------------------------------------------------------------------------------------------------
-// explicit reset kernel
-// ------------------------------------------------------------------------------------------------
-template <int NC>
-__global__ __launch_bounds__(256) void lcr_reset_kernel(LcrDev P, const unsigned char *mask, const unsigned long long *seeds,
-                                                          int seed_from_base, unsigned long long base_seed) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P.n) return;
-    if (mask && !mask[e]) return;
-    const int N = P.n;
-    EnvState<NC> S;
-    load_state<NC>(P, e, S);
-    Pcg g;
-    if (seeds) g = pcg_seed(seeds[e]);
-    else if (seed_from_base) g = pcg_seed(base_seed + (unsigned long long)(P.env_off + e));
-    else g = load_rng(P, e);
-    f3 target = mk(0.f, 0.f, 0.f), ee;
-    if (P.has_target) target = mk(P.target[e], P.target[N + e], P.target[2 * N + e]);
-    reset_env<NC>(P, S, g, target, ee, P.walls ? P.goal[e] : 0);
-    store_rng(P, e, g);
-    store_state<NC>(P, e, S);
-    if (P.has_target) { P.target[e] = target.x; P.target[N + e] = target.y; P.target[2 * N + e] = target.z; }
-    P.ee_lag[e] = ee.x; P.ee_lag[N + e] = ee.y; P.ee_lag[2 * N + e] = ee.z;
-    P.elapsed[e] = 0;
-    if (P.warm)
-        for (int i = 0; i < LCR_DEV_NWARM; i++) P.warm[(size_t)i * N + e] = 0.f;   // no constraint forces carried into a new episode
-}
-
-#if LCR_HAS_PART(0)
-// ------------------------------------------------------------------------------------------------
-// synthetic policy: U(-1,1) from Philox4x32-10 keyed (seed, global env id, step)
-// ------------------------------------------------------------------------------------------------
-DEV void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__global__ __launch_bounds__(256) void lcr_fill_actions_kernel(float *action, int n, int k, long long env_off, unsigned long long seed,
-                                                                 unsigned long long step) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const unsigned long long gid = (unsigned long long)(env_off + e);
-    for (int blk = 0; blk * 4 < k; blk++) {
-        uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)blk << 24)};
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; r++) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int comp = blk * 4 + i;
-            if (comp < k) action[(size_t)comp * n + e] = (float)(c[i] >> 8) * (2.0f / 16777216.0f) - 1.0f;
-        }
-    }
-}
-
-// measurement support: one dword per lane copy (the step kernel's access pattern) with a known byte count,
-// used to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section)
-__global__ __launch_bounds__(64) void lcr_calib_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
-    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i < n) dst[i] = src[i] + 1.0f;
-}
-
-#endif   // LCR_HAS_PART(0)
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// launchers
+// launcher: solver mode (fixed sweeps | converged) x finger<->cube rows (4 | 6) x action mode
 // ------------------------------------------------------------------------------------------------
-static int check_launch() {
-    hipError_t err = hipGetLastError();
+template <bool ADAPT, bool ROLL>
+static void launch_loop_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
+    const int blocks = (P.n + 63) / 64;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+}
+int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
+    const hipStream_t st = (hipStream_t)stream;
+    if (P.pgs_iters < 0) {   // converged mode
+        if (P.roll) launch_loop_t<true, true>(P, action_dev, ee_mode, st);
+        else launch_loop_t<true, false>(P, action_dev, ee_mode, st);
+    } else {
+        if (P.roll) launch_loop_t<false, true>(P, action_dev, ee_mode, st);
+        else launch_loop_t<false, false>(P, action_dev, ee_mode, st);
+    }
+    const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : (int)err;
 }
-
-// The step kernel has 24 instantiations.  gym_lowcostrobot_amd/build.py compiles this file three times in parallel, -DLCR_PART=0|2|3
-// selecting which launchers -- and hence which instantiations -- a translation unit emits: 0 the one-cube kernels (+ the dispatcher and
-// the small kernels), 2 / 3 the two StackTwoCubes variants.  Without the macro (tools/) everything is in one unit.  (PushCubeLoop:
-// lcr_kernels_loop.hip.)
-// the four solver-mode / contact-row variants of one launcher
-#define LCR_DISPATCH_MODES(fn)                                              \
-    do {                                                                    \
-        if (P.pgs_iters < 0) {   /* converged mode */                       \
-            if (P.roll) fn<true, true>(P, action_dev, ee_mode, st);         \
-            else fn<true, false>(P, action_dev, ee_mode, st);               \
-        } else {                                                            \
-            if (P.roll) fn<false, true>(P, action_dev, ee_mode, st);   /* six-row finger<->cube contacts */ \
-            else fn<false, false>(P, action_dev, ee_mode, st);              \
-        }                                                                   \
-    } while (0)
-
-int lcr_launch_step_stack(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st);
-int lcr_launch_step_stack_big(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st);
-
-#if LCR_HAS_PART(2)
-template <bool ADAPT, bool ROLL>
-static void launch_stack_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
-    const int blocks = (P.n + 63) / 64;
-    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<2, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-}
-int lcr_launch_step_stack(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
-    LCR_DISPATCH_MODES(launch_stack_t);
-    return check_launch();
-}
-#endif
-#if LCR_HAS_PART(3)
-template <bool ADAPT, bool ROLL>
-static void launch_stack_big_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {   // shard of at most three waves per CU: every g row in LDS
-    const int blocks = (P.n + 63) / 64;
-    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<2, true, ADAPT, ROLL, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-}
-int lcr_launch_step_stack_big(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
-    LCR_DISPATCH_MODES(launch_stack_big_t);
-    return check_launch();
-}
-#endif
-
-#if LCR_HAS_PART(0)
-template <bool ADAPT, bool ROLL>
-static void launch_one_cube_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
-    const int blocks = (P.n + 63) / 64;
-    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    else hipLaunchKernelGGL((lcr_step_kernel<1, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-}
-int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
-    const hipStream_t st = (hipStream_t)stream;
-    if (P.walls) return lcr_launch_step_loop(P, action_dev, ee_mode, stream);   // PushCubeLoop: its own unit and solver (lcr_kernels_loop.hip)
-    if (P.coop && P.pgs_iters >= 0 && P.diag != 2) {   // two cooperating waves per 64 envs (no converged mode, no per-wave cycle read-back)
-        if (P.task == 4) return P.cc8 ? lcr_launch_step2_stack_cc8(P, action_dev, ee_mode, P.coop, stream) : lcr_launch_step2_stack(P, action_dev, ee_mode, P.coop, stream);
-        return lcr_launch_step2_one_cube(P, action_dev, ee_mode, P.coop, stream);
-    }
-    if (P.task == 4) return P.big_lds ? lcr_launch_step_stack_big(P, action_dev, ee_mode, st) : lcr_launch_step_stack(P, action_dev, ee_mode, st);
-    LCR_DISPATCH_MODES(launch_one_cube_t);
-    return check_launch();
-}
-
-int lcr_launch_reset(const LcrDev &P, const unsigned char *mask_dev, const unsigned long long *seeds_dev, int seed_from_base,
-                     unsigned long long base_seed, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const int blocks = (P.n + 255) / 256;
-    if (P.task == 4) hipLaunchKernelGGL((lcr_reset_kernel<2>), dim3(blocks), dim3(256), 0, st, P, mask_dev, seeds_dev, seed_from_base, base_seed);
-    else hipLaunchKernelGGL((lcr_reset_kernel<1>), dim3(blocks), dim3(256), 0, st, P, mask_dev, seeds_dev, seed_from_base, base_seed);
-    return check_launch();
-}
-
-int lcr_launch_fill_actions(float *action_dev, int n, int k, long long env_off, unsigned long long seed, unsigned long long step,
-                            void *stream) {
-    hipLaunchKernelGGL(lcr_fill_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, action_dev, n, k, env_off, seed, step);
-    return check_launch();
-}
-
-int lcr_launch_calib_copy(const float *src, float *dst, size_t n, void *stream) {
-    hipLaunchKernelGGL(lcr_calib_copy_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, src, dst, n);
-    return check_launch();
-}
-#endif   // LCR_HAS_PART(0)

@@ -65,11 +65,9 @@ DEV float impedance(float dist, float d0, float dw, float inv_width) {
 // All rows of a block are evaluated from the same forces: no serial dependence inside a block.  In force units, select-free:
 //     f_n' = f_n - u_n iLn,  f_j' = f_j - (mu_j^2 iLt) u_j,  N = |(f_j' / mu_j)|,  f_n = max(f_n', w f_n' + (1 - w) N, 0),  f_j = f_j' min(1, f_n / N)
 // k[0] = iLn, k[1] = mu_tan^2 iLt, k[2] = w, k[3] = mu_tors^2 iLt (, k[4] = mu_roll^2 iLt); a block that is off has k = 0 and f = 0: its updates are exact zeros.
-// ------------------------------------------------------------------------------------------------
-// SEP (the PushCubeLoop kernels: that task's cube has torsional and rolling coefficients of 1.5 m, push_cube_loop.xml:31, whose scaled curvature mu^2 / I would set the
-// step of every friction row): torsional and rolling rows form a third group with their own Ls (k[3], k[4] = mu^2 / Ls; all three L scaled by 3); the cone is enforced on
-// (normal, tangential) as above and the third group is limited to what it leaves, |y_s| <= sqrt(y_n^2 - |y_t|^2) -- the exact D-projection whenever that limit is not reached.
-template <int NR, bool SEP = false>
+// PushCubeLoop keeps the row-wise sweeps (lcr_kernels_loop.hip): its cube has torsional and rolling coefficients of 1.5 m (push_cube_loop.xml:31) whose scaled curvature
+// mu^2 / I would set Lt, i.e. the step of every friction row of the block.
+template <int NR>
 DEV void soc_step(const float (&f)[NR], const float (&u)[NR], const float (&k)[NR], float im_tan2, float im_tors2, float im_roll2, int nrow, float (&nf)[NR]) {
     float fp[NR];
     fp[0] = fmaf(-u[0], k[0], f[0]);
@@ -82,19 +80,14 @@ DEV void soc_step(const float (&f)[NR], const float (&u)[NR], const float (&k)[N
         fp[5] = nrow > 4 ? fmaf(-u[5], k[4], f[5]) : 0.f;
         s2s = fmaf(fp[4] * fp[4] + fp[5] * fp[5], im_roll2, s2s);
     }
-    if (!SEP) s2 += s2s;
+    s2 += s2s;
     const float rs = rsq(fmaxf(s2, 1e-30f)), N = s2 * rs;
     const float a = fmaf(k[2], fp[0] - N, N);
     const float y0 = fmaxf(fmaxf(fp[0], a), 0.f);
     const float sc = fminf(y0 * rs, 1.f);
-    float scs = sc;
-    if (SEP) {   // nothing is left for the third group when (normal, tangential) was projected onto the cone's surface (N > y0); else y0^2 - N^2
-        const float lim2 = (y0 - N) * (y0 + N);
-        scs = N > y0 ? 0.f : fminf(sqrtf(fmaxf(lim2, 0.f) * rcp(fmaxf(s2s, 1e-30f))), 1.f);
-    }
     nf[0] = y0;
 #pragma unroll
-    for (int r = 1; r < NR; r++) nf[r] = fp[r] * (r >= 3 ? scs : sc);
+    for (int r = 1; r < NR; r++) nf[r] = fp[r] * sc;
 }
 
 // contact frame from unit normal (MuJoCo mju_makeFrame): t1, t2

@@ -99,14 +99,16 @@ typedef struct lcr_config {
                                   StackTwoCubes (light cubes), 4 for the other tasks (effect below the parity tolerance: deviation D4,
                                   DESIGN.md).  0 = the task's default */
     int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by task and JOB size (global_envs below, never the shard size n_envs): two
-                                  cooperating waves per 64 envs for ReachCube / LiftCube / PushCube / PickPlaceCube at every size and for StackTwoCubes /
-                                  PushCubeLoop jobs of <= 32 768 envs, one wave per 64 envs for larger Stack / Loop jobs -- the faster family when the job
-                                  runs as ONE shard on an MI355X; 1 = one wave per 64 envs always; 2 = two cooperating waves always (the faster family on
-                                  shards of <= 32 768 envs whatever the job size: a Stack / Loop job sharded that finely pins 2).  The families regroup the same
-                                  arithmetic and agree to fp32 rounding (~1e-7 per control step), not bit for bit; WITHIN a family results are bit-identical
-                                  for every sharding.  Because 0 looks at the job and not at the shard, every sharding of a job whose shards declare the
-                                  same global_envs runs the same family and gives identical bits; which build of the family a shard runs
-                                  (one / two waves per SIMD, rows in LDS / global scratch) does follow its size and does not change a bit. */
+                                  cooperating waves per 64 envs for ReachCube / LiftCube / PushCube / PickPlaceCube at every size and for StackTwoCubes
+                                  jobs of <= 32 768 envs, one wave per 64 envs for larger Stack jobs -- the faster family when the job runs as ONE shard
+                                  on an MI355X; 1 = one wave per 64 envs always; 2 = two cooperating waves always (the faster family on shards of
+                                  <= 32 768 envs whatever the job size: a Stack job sharded that finely pins 2).  PushCubeLoop has ONE kernel (one wave
+                                  per 64 envs, its own row-wise solver): 0 and 1 run it, 2 is LCR_ERR_UNSUPPORTED.  The families
+                                  regroup the same arithmetic and agree to fp32 rounding (~1e-7 per control step), not bit for bit; WITHIN a family
+                                  results are bit-identical for every sharding.  Because 0 looks at the job and not at the shard, every sharding of a
+                                  job whose shards declare the same global_envs runs the same family and gives identical bits; which
+                                  build of the family a shard runs (one / two waves per SIMD, rows in LDS / global scratch) does follow its size and
+                                  does not change a bit. */
     int32_t cc_points;         /* StackTwoCubes: cube<->cube manifold points kept per substep.  4 (default, 0 = default): the extremes along the diagonals
                                   of the reference face; 8: also the extremes along its two axes -- as many points as MuJoCo's box-box
                                   collider may return (stack_two_cubes.xml:25-35; narrows deviation D5).  8 runs on the

@@ -922,11 +922,11 @@ static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr
      * second-order cone is closed-form for this two-group metric: with v = y - D^-1 g~, N = |v_t|:
      *     inside (N <= v_n): v;   else  y_n = max(0, w v_n + (1 - w) N),  y_t = v_t y_n / N,  w = Ln / (Ln + Lt).
      * In force units:  v_n = f_n - u_n / Ln,  v_j mu_j = f_j - mu_j^2 u_j / Lt  (u = gradient rows).
-     * sep (PushCubeLoop, whose cube has torsional and rolling coefficients of 1.5 m, push_cube_loop.xml:31: their scaled curvature mu^2 / I is four orders of
-     * magnitude above the tangential rows' and would set the step of all friction rows): the torsional and rolling rows form a THIRD group with their own
-     * Ls (all three scaled by 3 instead of 2); the cone is enforced on (normal, tangential) in closed form as above and the third group is then limited to what
-     * the cone leaves, |y_s| <= sqrt(y_n^2 - |y_t|^2) -- the exact D-projection whenever that limit is not reached, which with coefficients of 1.5 m it never is in
-     * practice (a torque of mu_s f_n = 1.5 m x f_n would be needed). */
+     * sep (study only: PushCubeLoop's default is cone = 0.  Its cube has torsional and rolling coefficients of 1.5 m, push_cube_loop.xml:31: their scaled
+     * curvature mu^2 / I is four orders of magnitude above the tangential rows' and would set the step of all friction rows): the torsional and rolling rows
+     * form a THIRD group with their own Ls (all three scaled by 3 instead of 2) and the D-projection is the exact one for three weights (one-dimensional
+     * root, below).  Converges to the optimum, but slowly: four sweeps leave a pinched cube's normal forces so far off that cubes are thrown
+     * (tools/loop_solver_study.py) -- which is why the loop task keeps the row-wise sweeps. */
     real u[6], Ln = 0, Lt = 0, Ls = 0;
     const real kf = sep ? 3 : 2;
     for (int j = 0; j < dm; j++) {
@@ -948,21 +948,43 @@ static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr
         else { fp[j] = f[i0 + j] - m2 * u[j] * iLt; s2 += fp[j] * fp[j] / m2; }
     }
     const real N = (real)sqrt((double)s2);
+    if (sep && Ls > 0) {
+        /* exact D-projection onto the cone for three weights: stationarity gives  y_n = Ln p_n / (Ln - lam),  y_t = p_t Lt / (Lt + lam),  y_s = p_s Ls / (Ls + lam)
+         * and lam >= 0 is the root of  phi(lam) = (Ln - lam) r(lam) - Ln p_n,  r = sqrt((Lt T / (Lt + lam))^2 + (Ls S / (Ls + lam))^2)  (decreasing; phi(0) > 0
+         * outside the cone, phi(inf) < 0 outside the polar cone). */
+        const real S = (real)sqrt((double)s2s), p0 = fp[0];
+        real y0, sct, scs2;
+        if (p0 >= 0 && s2 + s2s <= p0 * p0) { y0 = p0; sct = 1; scs2 = 1; }
+        else if (Ln * p0 <= -(real)sqrt((double)(Lt * Lt * s2 + Ls * Ls * s2s))) { y0 = 0; sct = 0; scs2 = 0; }
+        else {
+            real lam = 0;
+            for (int it = 0; it < 60; it++) {
+                const real at = Lt / (Lt + lam), as = Ls / (Ls + lam);
+                const real r2 = at * at * s2 + as * as * s2s, r = (real)sqrt((double)r2);
+                const real phi = (Ln - lam) * r - Ln * p0;
+                /* r' = -(at^2 s2 / (Lt + lam) + as^2 s2s / (Ls + lam)) / r */
+                const real dr = -(at * at * s2 / (Lt + lam) + as * as * s2s / (Ls + lam)) / r;
+                const real dphi = -r + (Ln - lam) * dr;
+                real step = phi / dphi;
+                lam -= step;
+                if (lam < 0) lam = 0;
+                if (fabs((double)step) <= 1e-14 * (double)(Ln + lam)) break;
+            }
+            sct = Lt / (Lt + lam); scs2 = Ls / (Ls + lam);
+            y0 = (real)sqrt((double)(sct * sct * s2 + scs2 * scs2 * s2s));
+        }
+        f[i0] = y0;
+        for (int j = 1; j < dm; j++) f[i0 + j] = fp[j] * (j >= 3 ? scs2 : sct);
+        (void)S; (void)N; (void)w;
+        return;
+    }
     real a = w * fp[0] + ((real)1 - w) * N, y0 = fp[0];
     if (a > y0) y0 = a;
     if (y0 < 0) y0 = 0;
     real sc = 1;
     if (N > y0) sc = y0 / N;
     f[i0] = y0;
-    real scs = 1;
-    if (sep) {   /* what the cone leaves for the third group: nothing when (normal, tangential) was projected onto the cone's surface; else y_n^2 - N^2 */
-        if (N > y0) scs = 0;
-        else {
-            const real lim2 = (y0 - N) * (y0 + N);
-            if (s2s > lim2) scs = (real)sqrt((double)(lim2 / s2s));
-        }
-    }
-    for (int j = 1; j < dm; j++) f[i0 + j] = fp[j] * ((sep && j >= 3) ? scs : sc);
+    for (int j = 1; j < dm; j++) f[i0 + j] = fp[j] * sc;
 }
 /* natural residual of the KKT conditions of  min_{f in K} 1/2 f'(A + R) f + f'b  (orc_io.kkt) */
 static double kkt_residual(const real *A, int nr, const real *bvec, const real *Rr, const real *f, const int *kind, const int *blkdim, const double *const *rowmu) {
@@ -1503,10 +1525,12 @@ void orc_default_params(orc_params *p, int task) {
     p->arm_collision = 1;
     p->pgs_tol = 1e-6;
     p->cc_points = 4;
-    p->cone = 3;      /* block projected gradient in the second-order-cone variables: what the kernels run (round 4) */
+    /* what the kernels run: block projected gradient in the second-order-cone variables with the rows in two concurrently swept groups (round 4) -- except
+     * PushCubeLoop, which keeps the row-wise Gauss-Seidel sweeps with the radial projection, one sequence (lcr_kernels_loop.hip; deviation D2) */
+    p->cone = task == ORC_TASK_PUSH_LOOP ? 0 : 3;
     p->pgs_cap = 0;   /* 50 */
     p->solver = 0;    /* PGS (what the kernels run) */
-    p->jacobi = 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
+    p->jacobi = task == ORC_TASK_PUSH_LOOP ? 0 : 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }

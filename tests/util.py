@@ -209,7 +209,11 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
                         os.environ.pop("LCR_STEP_KERNEL", None)
                     else:
                         os.environ["LCR_STEP_KERNEL"] = old
+                if (alt.L.lcr_step_kernel_family(alt.handle) > 0) == (sim.L.lcr_step_kernel_family(sim.handle) > 0):
+                    alt.close(); alt = False                    # the task has one kernel (PushCubeLoop) or the override did not apply: no second witness
                 sim._alt_family = alt
+        if (~ok & ~flip & ~ill).any() and getattr(sim, "_alt_family", None):
+            alt = sim._alt_family
             alt.set_state(**pre)
             alt.step(a)
             sa = pull_state(alt)
