@@ -37,10 +37,10 @@ class OrcParams(ctypes.Structure):
         ("condim6", ctypes.c_int32),
         ("proxy_groups", ctypes.c_int32),
         ("cc_points", ctypes.c_int32),
-        ("cone", ctypes.c_int32),       # 0: radial projection onto the cone (D2, = the kernels); 1: MuJoCo's per-contact block update with the exact friction QCQP
+        ("cone", ctypes.c_int32),       # 3 (default, five tasks): block projected-gradient step; 0 (default of push_loop): rows + radial projection (D2); 1: MuJoCo's PGS block update (QCQP)
         ("pgs_cap", ctypes.c_int32),    # most sweeps of the converged mode (0 = 50)
         ("solver", ctypes.c_int32),     # 0: PGS (= the kernels); 1: primal Newton to machine precision (exact optimum of MuJoCo's convex problem)
-        ("jacobi", ctypes.c_int32),     # 1: two row groups (arm-only | cube rows) sweep concurrently (= the kernels' two waves); 0: one Gauss-Seidel pass
+        ("jacobi", ctypes.c_int32),     # 1 (default; push_loop: 0): two row groups (arm-only | cube rows) sweep concurrently (= the kernels' two waves); 0: one Gauss-Seidel pass
     ]
 
 

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--out")
     a = ap.parse_args()
     res = {}
-    for src in ("lcr_kernels.hip", "lcr_kernels2.hip", "lcr_render.hip"):
+    for src in ("lcr_kernels.hip", "lcr_kernels_loop.hip", "lcr_kernels2.hip", "lcr_render.hip"):
         co = os.path.join(tempfile.gettempdir(), src + ".co")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["--cuda-device-only", "--no-gpu-bundle-output", "-c", os.path.join(B.CSRC, src), "-o", co], stderr=subprocess.DEVNULL)
         txt = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], text=True)

@@ -111,7 +111,7 @@ def kernels(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm", nargs="?")
-    ap.add_argument("--kernel", default="lcr_step_kernelILi1ELb0ELb0ELb0ELb0ELb0E", help="substring of the mangled name (default: the bench kernel: one cube, joint, no rails, fixed sweeps, four-row contacts)")
+    ap.add_argument("--kernel", default="lcr_step2_kernelILi1ELb0ELb0ELi2ELb0E", help="substring of the mangled name (default: the bench kernel: two-wave family, one cube, joint, four-row contacts, two waves per SIMD)")
     ap.add_argument("--out")
     a = ap.parse_args()
     path = a.asm
@@ -119,9 +119,10 @@ def main():
         sys.path.insert(0, ROOT)
         from gym_lowcostrobot_amd import build as B
 
-        path = os.path.join(tempfile.gettempdir(), "lcr_kernels.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-S", "--cuda-device-only", "-o", path,
-                                                                   os.path.join(B.CSRC, "lcr_kernels.hip")], stderr=subprocess.DEVNULL)
+        src, part = ("lcr_kernels2.hip", ["-DLCR_PART=10"]) if "step2" in a.kernel else ("lcr_kernels.hip", ["-DLCR_PART=0"])
+        path = os.path.join(tempfile.gettempdir(), src.replace(".hip", ".s"))
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + part + ["-S", "--cuda-device-only", "-o", path, os.path.join(B.CSRC, src)],
+                              stderr=subprocess.DEVNULL)
     res = {}
     for name, body in kernels(path).items():
         if a.kernel in name:
