@@ -687,8 +687,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     g[r][k] = (NC == 2 && !BIG && s == 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2])
                               : (NC == 2 && !BIG && r >= 4) ? *reinterpret_cast<const float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2])
                                                   : *reinterpret_cast<const float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
-            // group B (finger<->cube, s < 2) works from y as of the start of the sweep (yB) and its changes go to BOTH copies; group A (s >= 2) works on y
-            float2v yp[3] = {{s < 2 ? yB[0] : y[0], s < 2 ? yB[1] : y[1]}, {s < 2 ? yB[2] : y[2], s < 2 ? yB[3] : y[3]}, {s < 2 ? yB[4] : y[4], s < 2 ? yB[5] : y[5]}};
+            // one cube: the finger<->cube slots (s < 2) belong to group B -- they work from y as of the start of the sweep (yB) and their changes go to BOTH copies;
+            // group A (s >= 2; with two cubes every arm slot: "all rows that touch the arm" -- Stack's group B has two cubes' floor rows and the cube<->cube rows already) works on y
+            constexpr bool inB = s < 2 && NC == 1;
+            float2v yp[3] = {{inB ? yB[0] : y[0], inB ? yB[1] : y[1]}, {inB ? yB[2] : y[2], inB ? yB[3] : y[3]}, {inB ? yB[4] : y[4], inB ? yB[5] : y[5]}};
             float2v yq[3] = {{y[0], y[1]}, {y[2], y[3]}, {y[4], y[5]}};
             float arefv[NRW], invv[NRW], f_in[NRW];
 #pragma unroll
@@ -697,6 +699,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             f3 a_lin = mk(0.f, 0.f, 0.f), a_ang = mk(0.f, 0.f, 0.f);
             const bool second = may_cube && NC == 2 && slot_cube[s == 4 ? 2 : (s & 1)] == 1;
             if (may_cube) { a_lin = second ? ca[NC - 1] : ca[0]; a_ang = second ? cal[NC - 1] : cal[0]; }
+            if (may_cube && !inB) {   // group A sees the cube accelerations as of the start of the sweep plus its OWN changes so far (Gauss-Seidel inside the group)
+                a_lin = a_lin + (second ? dcaA[NC - 1] : dcaA[0]); a_ang = a_ang + (second ? dcalA[NC - 1] : dcalA[0]);
+            }
             // cube-side inverse inertia of this lane's contact (zero when the proxy slot touches the floor: the cube terms vanish)
             const float minv_e = (s == 4 && !oncube) ? 0.f : minv, iinv_e = (s == 4 && !oncube) ? 0.f : iinv;
             // the cube's share of the gradient rows: v_r = d_r . (acceleration of the cube's contact point), wn / w1 / w2 = (n, t1, t2) . (angular acceleration)
@@ -739,7 +744,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     T.f[r] = nf[r];
                     const float2v d2 = {dlt, dlt};
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { yp[k] = g[r][k] * d2 + yp[k]; if (s < 2) yq[k] = g[r][k] * d2 + yq[k]; }
+                    for (int k = 0; k < 3; k++) { yp[k] = g[r][k] * d2 + yp[k]; if (inB) yq[k] = g[r][k] * d2 + yq[k]; }
                 }
             }
             // (converged mode: the net force change of this sweep)
@@ -754,17 +759,17 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 if constexpr (ROLL) { if (nrow == 6) Td = axpy(T.f[4] - f_in[4], T.t1, axpy(T.f[5] - f_in[5], T.t2, Td)); }
                 dl_ang = (-iinv_e) * Td;
             }
-            if (s < 2) {
+            if (inB) {
                 yB[0] = yp[0].x; yB[1] = yp[0].y; yB[2] = yp[1].x; yB[3] = yp[1].y; yB[4] = yp[2].x; yB[5] = yp[2].y;
                 y[0] = yq[0].x; y[1] = yq[0].y; y[2] = yq[1].x; y[3] = yq[1].y; y[4] = yq[2].x; y[5] = yq[2].y;
             } else {
                 y[0] = yp[0].x; y[1] = yp[0].y; y[2] = yp[1].x; y[3] = yp[1].y; y[4] = yp[2].x; y[5] = yp[2].y;
             }
             if (may_cube) {
-                // slots 0, 1 (group B) change the cube accelerations the group is sweeping; slot 4 (group A) read them as of the start of the sweep (it runs
-                // before group B's rows) and its change is held back until the end of the sweep
-                f3 (&tca)[NC] = s == 4 ? dcaA : ca;
-                f3 (&tcal)[NC] = s == 4 ? dcalA : cal;
+                // group B's slots change the cube accelerations the group is sweeping; group A's read them as of the start of the sweep (they run
+                // before group B's rows) and their change is held back until the end of the sweep
+                f3 (&tca)[NC] = inB ? ca : dcaA;
+                f3 (&tcal)[NC] = inB ? cal : dcalA;
                 if (NC == 2) {
                     if (second) { tca[NC - 1] = tca[NC - 1] + dl_lin; tcal[NC - 1] = tcal[NC - 1] + dl_ang; }
                     else { tca[0] = tca[0] + dl_lin; tcal[0] = tcal[0] + dl_ang; }
@@ -797,7 +802,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 for (int k = 0; k < 6; k++) y[k] = fmaf(g[k], dl, y[k]);
             }
         }
-        // group A: finger<->floor, arm-link proxies (after the joint limits above)
+        // group A: (two cubes: finger<->cube,) finger<->floor, arm-link proxies (after the joint limits above)
+        if constexpr (NC == 2) { arm_slot(std::integral_constant<int, 0>{}); arm_slot(std::integral_constant<int, 1>{}); }
         arm_slot(std::integral_constant<int, 2>{});
         arm_slot(std::integral_constant<int, 3>{});
         arm_slot(std::integral_constant<int, 4>{});
@@ -880,8 +886,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
         }
         // group B, second part: finger<->cube
-        arm_slot(std::integral_constant<int, 0>{});
-        arm_slot(std::integral_constant<int, 1>{});
+        if constexpr (NC == 1) { arm_slot(std::integral_constant<int, 0>{}); arm_slot(std::integral_constant<int, 1>{}); }
 #pragma unroll
         for (int c = 0; c < NC; c++) { ca[c] = ca[c] + dcaA[c]; cal[c] = cal[c] + dcalA[c]; }   // group A's share of the cube accelerations (slot 4)
         sweeps_done = it + 1;

@@ -223,10 +223,12 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     const bool carry = P.warm != nullptr;
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
     // (the same registers hold a slot's forces during the sweeps: Wf[s][r] is row r of slot s, Wlim[j] the limit force of joint j)
-    // (this wave owns slots 2-4: finger<->floor and the arm-link proxies; the finger<->cube slots 0, 1 belong to wave B)
+    // (this wave owns slots 2-4: finger<->floor and the arm-link proxies; the finger<->cube slots 0, 1 belong to wave B when there is one cube and to this wave
+    //  when there are two: StackTwoCubes' cube wave already carries two cubes' floor rows and the cube<->cube rows -- lcr_step_common.h "row groups")
+    constexpr int S0 = NC == 2 ? 0 : 2;   // first arm slot of this wave
     float Wf[NAS][NRW], Wlim[6];
 #pragma unroll
-    for (int s = 2; s < NAS; s++)
+    for (int s = S0; s < NAS; s++)
 #pragma unroll
         for (int k = 0; k < NRW; k++) Wf[s][k] = wld(WARM_ARM + 6 * s + k);
 #pragma unroll
@@ -357,7 +359,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         const float srad[2] = {SPH0r, SPH1r};
         slot_any[0] = false; slot_any[1] = false;
 #pragma unroll
-        for (int s = 2; s < NAS; s++) {
+        for (int s = S0; s < NAS; s++) {
             const int sp = s & 1;
             const bool may_cube = s < 2 || s == 4;
             ArmSlot2<NRW> &T = AS[s];
@@ -472,8 +474,8 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 float Rt = Rf * (s < 2 ? P.rt_fc : (s < 4 ? RT_FF : P.rt_cube));
                 T.Rn = Rn;
                 // squared friction coefficients of this slot's rows (finger geoms mu 1.5 / torsional 0.005; a link proxy on the floor mu 1, on a cube the cube's)
-                const float m2_tan = s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f);
-                const float m2_tors = s < 4 ? MU_TORS * MU_TORS : P.mu_ct2;
+                const float m2_tan = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
+                const float m2_tors = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : P.mu_ct2);
                 float Ln = 1.f, Lt = 0.f;
                 f3 jc[6];
 #pragma unroll
@@ -588,13 +590,15 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 lim_inv[j] = rcp(gg + lim_R[j]);
             }
         }
-        const bool wave_arm = slot_any[2] || slot_any[3] || slot_any[4];
+        const bool wave_arm = slot_any[0] || slot_any[1] || slot_any[2] || slot_any[3] || slot_any[4];
 
         // ---- does a gripper-body proxy of some lane touch a cube?  (wave-uniform; with wave B's "a finger sphere touches a cube" it
         //      decides the sweep schedule of BOTH waves) ----
         const bool cube4 = wave_on_cube4;
-        if (lane == 0) xflag[1] = cube4 ? 1 : 0;
-        if (cube4) {   // share of slot 4's warm-start forces that acts on a cube
+        // two cubes: the finger<->cube slots are this wave's too -- towards wave B they behave exactly like a proxy on a cube (this wave changes cube accelerations)
+        const bool cubeA = cube4 || (NC == 2 && (slot_any[0] || slot_any[1]));
+        if (lane == 0) xflag[1] = cubeA ? 1 : 0;
+        if (cubeA) {   // share of the warm-start forces of this wave's slots that acts on a cube
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 // (pose area behind wave B's dy01: the ACC area may be overwritten by this wave's y hand-over before wave B has read it)
@@ -607,7 +611,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         wg_barrier();   // B1
         if (prof) pf_wait += clock64() - pf_mark;
         const bool c01 = __builtin_amdgcn_readfirstlane(xflag[0]) != 0;   // wave B: a finger sphere touches a cube in some lane
-        const bool coupled = c01 || cube4;
+        const bool coupled = c01 || cubeA;
         if (coupled && !hot) { hot = true; __builtin_amdgcn_s_setprio(3); }   // (see wave B)
         if (prof) pf_coupled += coupled ? 1u : 0u;
         if (c01) {   // warm-start forces of the finger<->cube slots act on the arm too: wave B's sum of g_r f_r
@@ -731,7 +735,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
             }
         };
         using I2 = std::integral_constant<int, 2>; using I5 = std::integral_constant<int, NAS>;
-        using I4 = std::integral_constant<int, 4>;
+        using I4 = std::integral_constant<int, 4>; using I0 = std::integral_constant<int, 0>;
         auto bar = [&]() {
             if (prof) pf_mark = clock64();
             wg_barrier();
@@ -762,7 +766,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 for (int j = 0; j < 6; j++) xdyb[j * 64] = y[j];
             }
             bar();   // P0: y at the start of the first sweep -> wave B; wave B's cube accelerations -> this wave
-            if (cube4) {
+            if (cubeA) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     const float *pa = xacc + (size_t)c * 6 * 64;
@@ -774,13 +778,14 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
 #pragma unroll
                 for (int c = 0; c < NC; c++) { ca_in[c] = ca[c]; cal_in[c] = cal[c]; }
                 limit_rows();
+                if constexpr (NC == 2) arm_rows(std::true_type{}, I0{}, I2{});   // (two cubes: finger<->cube, first of this wave's slots as in the oracle's row order)
                 arm_rows(std::false_type{}, I2{}, I4{});
                 if (cube4) arm_rows(std::true_type{}, I4{}, I5{}); else arm_rows(std::false_type{}, I4{}, I5{});
                 if (c01) {
 #pragma unroll
                     for (int j = 0; j < 6; j++) xacc[j * 64] = y[j];
                 }
-                if (cube4) {   // what slot 4 changed
+                if (cubeA) {   // what this wave's slots changed
 #pragma unroll
                     for (int c = 0; c < NC; c++) {
                         float *pa = xdca + (size_t)c * 6 * 64;
@@ -794,7 +799,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                     for (int j = 0; j < 6; j++) y[j] += xdyb[j * 64];
                 }
                 bar();   // R: everything is read; with cube4 wave B has left the merged cube accelerations in ACC
-                if (cube4) {
+                if (cubeA) {
 #pragma unroll
                     for (int c = 0; c < NC; c++) {
                         const float *pa = xacc + (size_t)c * 6 * 64;
@@ -807,7 +812,8 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         // (the forces stay in Wf / Wlim for the next substep's warm start; slots nobody touched were zeroed at set-up)
         if (P.diag) {
             unsigned m = 0u;
-            m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;   // (bits 12, 13: wave B)
+            m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;   // (bits 12, 13: wave B; two cubes: here)
+            if constexpr (NC == 2) { m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u; }
             m |= AS[4].act ? (1u << 16) : 0u;
 #pragma unroll
             for (int j = 0; j < 6; j++) m |= lim_act[j] ? (1u << (18 + j)) : 0u;
@@ -823,7 +829,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         auto final_solve = [&](auto glob_tag) {
             constexpr bool GLOB = decltype(glob_tag)::value;
             if (GLOB) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
+            const float *pw = lds + ((c01 || NC == 2) ? LL::WM0 : LL::G0) + lane;   // (two cubes: the rows of slots 0, 1 are this wave's, V and G always travel apart)
             const float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
             auto get = [&](int f) -> float { return GLOB ? gw[f] : pw[f * 64]; };
 #pragma unroll
@@ -841,7 +847,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
                 qacc[i] = sacc * get(36 + i);
             }
         };
-        if (GW && c01) final_solve(std::true_type{}); else final_solve(std::false_type{});
+        if (GW && (c01 || NC == 2)) final_solve(std::true_type{}); else final_solve(std::false_type{});
 #pragma unroll
         for (int j = 0; j < 6; j++) xacc[j * 64] = qacc[j];   // wave B integrates its copy of the arm state with the same values
         if (prof) pf_mark = clock64();
@@ -959,7 +965,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     if (carry && valid) {
         auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
 #pragma unroll
-        for (int s = 2; s < NAS; s++)
+        for (int s = S0; s < NAS; s++)
 #pragma unroll
             for (int k = 0; k < NRW; k++) wst(WARM_ARM + 6 * s + k, Wf[s][k]);
 #pragma unroll
@@ -1027,11 +1033,11 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 #pragma unroll
             for (int k = 0; k < 4; k++) Wfloor[c][s][k] = wld(WARM_FLOOR + 16 * c + 4 * s + k);
     constexpr int NRW = ROLL ? 6 : 4;
-    float Wf01[2][NRW];   // carried forces of the finger<->cube slots 0, 1 (this wave owns them: they need the cube state)
+    float Wf01[2][NRW];   // carried forces of the finger<->cube slots 0, 1 (one cube: this wave owns them; two cubes: wave A does)
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int k = 0; k < NRW; k++) Wf01[s][k] = wld(WARM_ARM + 6 * s + k);
+        for (int k = 0; k < NRW; k++) Wf01[s][k] = NC == 1 ? wld(WARM_ARM + 6 * s + k) : 0.f;
     float *ccl = lds + LL::CC0 + lane;   // Stack: record field k of slot s at ccl[(s * CC_REC + k) * 64]
     const size_t CS = 64;
     if constexpr (NC == 2) {
@@ -1106,7 +1112,8 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         bool s01_any[2];
         int s01_cube[2] = {0, 0};
         float dy01[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sum of g_r f_r of the warm-start forces: wave A adds it to y
-        {
+        s01_any[0] = false; s01_any[1] = false;
+        if constexpr (NC == 1) {   // (two cubes: wave A owns these slots -- this wave then carries two cubes' floor rows and the cube<->cube rows)
         const float srad[2] = {SPH0r, SPH1r};
 #pragma unroll
         for (int sp = 0; sp < 2; sp++) {
@@ -1213,7 +1220,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             }
         }
         }
-        const bool c01 = s01_any[0] || s01_any[1];
+        const bool c01 = NC == 1 && (s01_any[0] || s01_any[1]);
         if (lane == 0) const_cast<int *>(xflag)[0] = c01 ? 1 : 0;
         if (c01) {   // (wave A has read the pose before barrier X2: its first six fields carry dy01 until the sweeps start)
 #pragma unroll
@@ -1250,7 +1257,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
         // two waves per SIMD has no LDS left, and keeping the factors for a solve after the sweeps would cost this wave registers it does not have at the 256-register cap)
         auto hand_over = [&](auto glob_tag) {
             constexpr bool GLOB = decltype(glob_tag)::value;
-            float *pw = lds + (c01 ? LL::WM0 : LL::G0) + lane;
+            float *pw = lds + ((c01 || NC == 2) ? LL::WM0 : LL::G0) + lane;
             float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
             auto put = [&](int f, float v) { if (GLOB) gw[f] = v; else pw[f * 64] = v; };
 #pragma unroll
@@ -1270,7 +1277,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             for (int i = 0; i < 6; i++) put(36 + i, CL2.id[i]);
             if (GLOB) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
         };
-        if (GW && c01) hand_over(std::true_type{}); else hand_over(std::false_type{});
+        if (GW && (c01 || NC == 2)) hand_over(std::true_type{}); else hand_over(std::false_type{});
         // ---- collision: floor <-> cube (MuJoCo plane-box: penetrating vertices in index order, at most 4) ----
         FloorSlot FS[NC][4];
 #pragma unroll
@@ -1724,7 +1731,7 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
 #pragma unroll
                 for (int s = 4; s < 8; s++) m |= cc_act[s] ? (1u << (24 + (s - 4))) : 0u;
             }
-            m |= AS01[0].act ? (1u << 12) : 0u; m |= AS01[1].act ? (1u << 13) : 0u;
+            if constexpr (NC == 1) { m |= AS01[0].act ? (1u << 12) : 0u; m |= AS01[1].act ? (1u << 13) : 0u; }   // (two cubes: wave A's bits)
             DGtot.mask |= m;
             DGtot.count += (unsigned)__popc(m);
             DGtot.choice += DG.choice * (unsigned)(2 * sub + 1);
@@ -1783,10 +1790,12 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) wst(WARM_FLOOR + 16 * c + 4 * s + k, Wfloor[c][s][k]);
+        if constexpr (NC == 1) {
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int k = 0; k < NRW; k++) wst(WARM_ARM + 6 * s + k, Wf01[s][k]);
+        }
         if constexpr (NC == 2) {
 #pragma unroll
             for (int s = 0; s < NCC; s++) {

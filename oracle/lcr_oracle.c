@@ -1362,7 +1362,10 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             kind[nr + r] = r == 0 ? 1 : 2;
             rowmu[nr + r] = ct->mu;
             blk0[nr + r] = nr; blkdim[nr + r] = ct->dim;
-            grp[nr + r] = (ct->slot >= 14 && ct->slot < 24) ? 0 : 1;   /* group A: finger<->floor, arm-link proxies (with the limits); group B: every row of a cube */
+            /* group A (with the limits): finger<->floor, arm-link proxies -- and, with TWO cubes, the finger<->cube contacts too: group A is then "every row that touches the
+             * arm", group B "rows between cubes and floor / cube and cube" (StackTwoCubes: its group B carries two cubes' floor rows and the cube<->cube rows, so the kernels'
+             * cube wave is the long one; measured on the oracle the assignment does not change the distance to the optimum).  One cube: finger<->cube rows stay in B. */
+            grp[nr + r] = ((ct->slot >= 14 && ct->slot < 24) || (nc == 2 && (ct->slot == 12 || ct->slot == 13))) ? 0 : 1;
             wptr[nr + r] = &warm->slot[ct->slot][r];
         }
         nr += ct->dim;
