@@ -828,7 +828,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
         // place / this lane's global scratch record.  qacc = G^-T (V y).
         auto final_solve = [&](auto glob_tag) {
             constexpr bool GLOB = decltype(glob_tag)::value;
-            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const float *pw = lds + ((c01 || NC == 2) ? LL::WM0 : LL::G0) + lane;   // (two cubes: the rows of slots 0, 1 are this wave's, V and G always travel apart)
             const float *gw = P.scratch + ((size_t)blockIdx.x * 64 + lane) * 48;
             auto get = [&](int f) -> float { return GLOB ? gw[f] : pw[f * 64]; };
@@ -1275,7 +1275,10 @@ DEV void cube_program(const LcrDev &P, float *lds, const int lane, const int e, 
                 for (int j = 0; j < i; j++) put(21 + i * (i - 1) / 2 + j, CL2.L[i][j]);
 #pragma unroll
             for (int i = 0; i < 6; i++) put(36 + i, CL2.id[i]);
-            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a workgroup barrier alone does not order global stores)
+            // (the barrier's own fence does not cover these global stores; WORKGROUP scope is what the hand-over needs -- both waves run on one CU and share its vector L1
+            //  (no threadgroup-split mode), so nothing has to be written back or invalidated.  Until late in round 4 this was an agent-scope fence pair: `buffer_wbl2` here and
+            //  `buffer_inv` on wave A's side, an L2 write-back and an invalidate per coupled substep and workgroup -- Push / Lift / PickPlace at 65 536 envs 0.337-0.340 -> 0.307-0.312 ms)
+            if (GLOB) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         };
         if (GW && (c01 || NC == 2)) hand_over(std::true_type{}); else hand_over(std::false_type{});
         // ---- collision: floor <-> cube (MuJoCo plane-box: penetrating vertices in index order, at most 4) ----
