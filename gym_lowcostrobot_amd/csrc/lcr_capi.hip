@@ -304,11 +304,11 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         D.walls = loop ? 1 : 0;
         // step-kernel family: a function of the task, the config and the size of the JOB (lcr_config.global_envs; 0 = this handle is the job) -- never of
         // the shard size, so that every sharding of a job runs the same arithmetic (bit-identical results for G = 1/2/4/8).  Measured on an
-        // MI355X with the job as ONE shard (random policy, round 4): the two-cooperating-waves kernels win or tie at every size for the
-        // four one-cube tasks without rails (65 536 envs: ReachCube 0.256 against 0.285 ms, Push / Lift / PickPlace 0.338-0.341 against 0.333-0.336;
-        // 131 072: 0.61-0.63 against 0.62-0.65; 32 768: 0.22-0.23 against 0.33) -- those tasks ALWAYS run them.  StackTwoCubes needs more
-        // than 256 registers per lane in its cube wave: up to 32 768 envs (2 x 512 waves: one per SIMD) the two-wave kernels win (0.55 against 0.78 ms),
-        // above that the one-wave kernels do (65 536: 0.89 against 0.95).  PushCubeLoop has one kernel (lcr_kernels_loop.hip, one wave per 64 envs).
+        // MI355X with the job as ONE shard (random policy, round 4): the two-cooperating-waves kernels win at every size for the
+        // four one-cube tasks without rails (65 536 envs: ReachCube 0.257 against 0.285 ms, Push / Lift / PickPlace 0.308-0.312 against 0.333-0.336;
+        // 32 768: 0.205-0.229 against 0.33) -- those tasks ALWAYS run them.  StackTwoCubes needs more than 256 registers per lane in its waves: up to
+        // 32 768 envs (2 x 512 waves: one per SIMD) the two-wave kernels win (0.43 against 0.70 ms), above that one round of one-wave workgroups beats two
+        // rounds of two-wave ones (65 536: 0.78 against 0.82).  PushCubeLoop has one kernel (lcr_kernels_loop.hip, one wave per 64 envs).
         // lcr_config.step_kernel pins a family (a Stack job cut into shards of <= 32 768 envs pins 2); LCR_STEP_KERNEL=single|coop1|coop2 overrides
         // (tests and profiling exercise every build).
         // WHICH BUILD of the two-wave family a shard runs does follow its size (one wave per SIMD while 2 x ceil(N / 64) waves fit the chip's SIMDs, else the

@@ -658,7 +658,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         };
         // ---- one arm-coupled slot (finger spheres, arm-link proxies): a block step on its rows ----
         // The rows of a sweep form two groups that are swept as if concurrently (what the two-wave kernels do with two waves; oracle: orc_params.jacobi) --
-        //   A: joint limits, finger<->floor (slots 2, 3), arm-link proxies (slot 4)          B: floor<->cube, cube<->cube, rails, finger<->cube (slots 0, 1)
+        //   A: joint limits, finger<->floor (slots 2, 3), arm-link proxies (slot 4)          B: floor<->cube, cube<->cube, finger<->cube (slots 0, 1; two cubes: group A)
         // Gauss-Seidel inside a group; a group sees the other group's effect on the shared unknowns (the arm acceleration y through slots 0, 1; the cube
         // accelerations through slot 4) as of the START of the sweep.  In program order group A runs first: y then carries A's changes, yB keeps the sweep-start
         // value for slots 0, 1 (whose changes go to both copies), and slot 4's change of the cube accelerations is held back in dcaA until the end of the sweep.

@@ -9,19 +9,21 @@
 //                    only the arm (finger spheres <-> floor, arm-link proxies: slots 2-4; joint limits) and their sweeps, qacc = G^-T (V y),
 //                    integration of the arm; the action head (incl. the IK loop of ee mode) and the fused tail (reward, termination,
 //                    TimeLimit, auto-reset, write-back);
-//   wave B ("cubes") its own forward kinematics, RNE bias + actuation + damping = tau (-> wave A), the finger spheres <-> cube slots 0, 1
-//                    (it has the cube state, the kinematics and L), floor <-> cube / cube <-> cube / rail contacts, their rows and
+//   wave B ("cubes") its own forward kinematics, RNE bias + actuation + damping = tau (-> wave A), with ONE cube the finger spheres <-> cube slots 0, 1
+//                    (it has the cube state, the kinematics and L; with TWO cubes they are wave A's: this wave then carries two cubes' floor rows and the
+//                    cube <-> cube rows), floor <-> cube / cube <-> cube contacts, their rows and
 //                    sweeps, the implicit-damping factor G ((M + hD) = G G^T) and V = G^-1 L (-> wave A), integration of the cubes and of its copy of the arm state.
 //
-// The two constraint sets touch disjoint unknowns (the arm's scaled acceleration y vs the cube accelerations ca / cal) unless a finger sphere
-// or a gripper-body proxy touches a cube, so their Gauss-Seidel sweeps are INDEPENDENT chains in almost every (workgroup, substep) pair and
-// run concurrently -- the result is the same as the oracle's sequential order limits -> floor -> cube<->cube -> rails -> slots 0-4.  When some
-// lane of the 64 couples them (wave-uniform flags exchanged at barrier 1: c01 = a finger sphere on a cube, cube4 = a proxy on a cube) the
-// sweep is serialised in exactly that order: y visits wave B between the limit rows and slots 2-4, the cube accelerations visit wave A for
-// slot 4.  Barriers per substep (uncoupled: five):
+// The two row groups touch disjoint unknowns (the arm's scaled acceleration y vs the cube accelerations ca / cal) unless a finger sphere
+// or a gripper-body proxy touches a cube, so their sweeps are INDEPENDENT chains in almost every (workgroup, substep) pair and run concurrently.
+// When some lane of the 64 couples them (wave-uniform flags exchanged at barrier 1: c01 = a row of wave B touches the arm -- a finger sphere on
+// the cube, one-cube tasks; cube4 = a row of wave A touches a cube -- a proxy on a cube, with two cubes also a finger sphere on a cube) the groups
+// STILL sweep concurrently (round 4): each works from the shared unknowns as of the start of the sweep plus its own changes, and the changes are
+// merged at the end of every sweep (block Jacobi between the groups, Gauss-Seidel inside; the oracle's sweep is defined the same way, orc_params.jacobi;
+// DESIGN.md section 4 D1).  Barriers per substep (uncoupled: five; coupled: one more before the first sweep and two per sweep):
 //
 //   A: FK, M, L -> LDS          -X-  y0 = L^-1 tau; pose <- LDS  -X2-  rows of slots 2-4, limits | cube4  -B1-  sweeps: limits, 2-4      | qacc = G^-T V y -> LDS  -E-  integrate arm
-//   B: FK, tau -> LDS           -X-  L <- LDS                    -X2-  slots 0, 1; V, G -> LDS; cube rows | c01 -B1-  sweeps: floor, cc, rails | integrate cubes, pose -> LDS  -E-  integrate arm copy
+//   B: FK, tau -> LDS           -X-  L <- LDS                    -X2-  slots 0, 1; V, G -> LDS; cube rows | c01 -B1-  sweeps: floor, cc, 0-1    | integrate cubes, pose -> LDS  -E-  integrate arm copy
 //
 // Every LDS hand-over and the barrier that orders it is listed in DESIGN.md section 3.1b; the rule when changing this file: a place may be
 // rewritten only after a barrier that its reader has also passed AFTER reading (tests/test_gpu_parity.py::test_kernel_families_agree_and_are_race_free
@@ -29,7 +31,7 @@
 //
 // At 32 768 envs per GPU the 1024 waves occupy all 1024 SIMDs (one each, up to 512 registers per lane: variant OCC = 1, what lcr_create
 // dispatches for such shards); at 65 536 envs two waves share a SIMD (<= 256 registers per lane, variant OCC = 2: same source, same bits;
-// faster than the one-wave kernels for Reach only -- DESIGN.md section 5).
+// since round 4 faster than the one-wave kernels for every one-cube task -- DESIGN.md section 5; PushCubeLoop: lcr_kernels_loop.hip).
 //
 // Reference map: identical to lcr_kernels.hip (apply_action reach_cube_env.py:223-273, 20 x mj_step :276-279, reward / termination
 // :313-348 and the per-task files, reset :297-311); the arithmetic of every block is the one of lcr_kernels.hip, regrouped by owner.
@@ -43,7 +45,7 @@
 namespace {
 
 // ---- LDS layout of a workgroup: float index = field * 64 + lane (bank = lane mod 32: conflict-free) ----
-//  [0, GR * LDS_ROW)            g rows of the arm-coupled slots: slots 0, 1 written and read by wave B, slots 2-4 by wave A
+//  [0, GR * LDS_ROW)            g rows of the arm-coupled slots: slots 0, 1 written and read by wave B (two cubes: wave A), slots 2-4 by wave A
 //  [.., + CC records)           Stack: cube<->cube contact records (wave B only; four, or eight with CC8)
 //  POSE: NC * 13 fields         cube pose and velocity at the top of a substep: cp3 cq4 cv3 cw3 (B -> A; written before barrier E, read before X2)
 //  ACC : NC * 6 fields          y in coupled sweeps (A <-> B), qacc (A -> B at barrier E); after the last substep: B's diagnostics words
@@ -224,7 +226,7 @@ DEV void arm_program(const LcrDev &P, const float *__restrict__ action, float *l
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
     // (the same registers hold a slot's forces during the sweeps: Wf[s][r] is row r of slot s, Wlim[j] the limit force of joint j)
     // (this wave owns slots 2-4: finger<->floor and the arm-link proxies; the finger<->cube slots 0, 1 belong to wave B when there is one cube and to this wave
-    //  when there are two: StackTwoCubes' cube wave already carries two cubes' floor rows and the cube<->cube rows -- lcr_step_common.h "row groups")
+    //  when there are two: StackTwoCubes' cube wave already carries two cubes' floor rows and the cube<->cube rows -- DESIGN.md section 4 D1 "sweep order")
     constexpr int S0 = NC == 2 ? 0 : 2;   // first arm slot of this wave
     float Wf[NAS][NRW], Wlim[6];
 #pragma unroll
