@@ -1,4 +1,4 @@
-"""Tail census of the cube state under the benchmark's random policy (GPU box):  python tools/rail_census.py [steps]
+"""Tail census of the cube state under the benchmark's random policy (GPU box):  python tools/rail_census.py [steps [tasks [key=value ...]]]
 For every task: how fast / how deep / how far does the cube get in 65 536 envs, sampled every 7th step.  PushCubeLoop also counts the cubes
 outside the rails.  (Round 3: with the rails as half-spaces, D7, 0.5 % of the PushCubeLoop states had the cube beyond a rail's outer face,
 459 of 5.6e6 moved faster than 5 m/s, the fastest at 1 240 m/s -- ejected by a 'penetration' of decimetres; with the rails acting only
@@ -11,9 +11,16 @@ import numpy as np  # noqa: E402
 from gym_lowcostrobot_amd import VecSim  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None          # e.g. stack,lift
+kw = {}
+for a in sys.argv[3:]:                                                 # e.g. pgs_iters=8 step_kernel=single
+    k, v = a.split("=")
+    kw[k] = int(v) if v.lstrip("-").isdigit() else v
 n = 65536
 for task, mode in (("push_loop", "joint"), ("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("pick_place", "ee"), ("stack", "joint")):
-    sim = VecSim(task, n, action_mode=mode)
+    if only and task not in only:
+        continue
+    sim = VecSim(task, n, action_mode=mode, **kw)
     act = sim.alloc_actions()
     tot = fast5 = fast50 = outside = sunk = 0
     vmax = wmax = 0.0
