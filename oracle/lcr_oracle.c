@@ -938,7 +938,17 @@ static void pgs_block_pg(const real *A, int nr, const real *bvec, const real *Rr
         else if (sep && j >= 3) Ls += kf * (real)(mu[j - 1] * mu[j - 1]) * d;
         else Lt += kf * (real)(mu[j - 1] * mu[j - 1]) * d;
     }
-    if (scalar_step) { Ln = (real)0.5 * (Ln + Lt); Lt = Ln; }   /* (study, cone = 4) one scalar step 1 / trace for the whole block */
+    if (!sep && scalar_step == 2) {   /* (study, cone = 5) factor 1 + rho instead of the worst case 2: D = (1 + rho) diag(a, T, .., T) majorises the scaled block as soon as rho^2 >= |b|^2 / (a T), b_j = mu_j A_nj
+                   * (Schur complement of [[rho a, -b'], [-b, rho T I]]); rho <= 1 for a positive semi-definite block.  Measured: 6 x closer to the optimum at
+                   * the 90th percentile, but in the kernels 3 % slower and with a heavier extreme tail for Lift (a cube 36 mm under the floor in 5.6e6 states): not adopted. */
+        real b2 = 0;
+        for (int j = 1; j < dm; j++) { const real a = A[(size_t)i0 * nr + i0 + j]; b2 += (real)(mu[j - 1] * mu[j - 1]) * a * a; }
+        const real ann = Ln / kf, trt = Lt / kf;
+        real rho = trt > 0 ? (real)sqrt((double)(b2 / (ann * trt))) : 0;
+        if (rho > 1) rho = 1;
+        Ln = ((real)1 + rho) * ann; Lt = ((real)1 + rho) * trt;
+    }
+    if (scalar_step == 1) { Ln = (real)0.5 * (Ln + Lt); Lt = Ln; }   /* (study, cone = 4) one scalar step 1 / trace for the whole block */
     const real iLn = (real)1 / Ln, iLt = (real)1 / Lt, iLs = Ls > 0 ? (real)1 / Ls : 0, w = Ln / (Ln + Lt);
     real fp[6], s2 = 0, s2s = 0;
     fp[0] = f[i0] - u[0] * iLn;
@@ -1429,8 +1439,8 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                     for (int m = 0; m < nr; m++) fmix[m] = grp[m] == grp[i] ? f[m] : f_start[m];
                     fsee = fmix;
                 }
-                if ((P->cone == 3 || P->cone == 4) && kind[i] == 2) continue;
-                if ((P->cone == 3 || P->cone == 4) && kind[i] == 1) { pgs_block_pg(A, nr, bvec, Rr, f, fsee, i, blkdim[i], rowmu[i], P->cone == 4, T->walls); continue; }
+                if ((P->cone == 3 || P->cone == 4 || P->cone == 5) && kind[i] == 2) continue;
+                if ((P->cone == 3 || P->cone == 4 || P->cone == 5) && kind[i] == 1) { pgs_block_pg(A, nr, bvec, Rr, f, fsee, i, blkdim[i], rowmu[i], P->cone == 4 ? 1 : (P->cone == 5 ? 2 : 0), T->walls); continue; }
                 if (P->cone == 1 && kind[i] == 2) continue;                      /* (handled with its block below) */
                 if (P->cone == 1 && kind[i] == 1) { pgs_block_exact(A, nr, bvec, Rr, f, i, blkdim[i], rowmu[i]); continue; }
                 real res = bvec[i] + Rr[i] * f[i];
