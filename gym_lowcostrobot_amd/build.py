@@ -30,12 +30,18 @@ def _newer(target, deps):
 # (source, object, extra flags): lcr_kernels.hip is compiled three times, LCR_PART selecting the step-kernel instantiations a unit emits
 # (0 one-cube kernels + dispatcher + small kernels, 2 / 3 the two StackTwoCubes variants) -- kernels of ~50-100 KB code each: 80 s in one
 # unit, ~30 s as units compiled concurrently; lcr_kernels_loop.hip is PushCubeLoop's unit
+NO_POST_RA = ["-mllvm", "-enable-post-misched=0"]
+ITER_ILP = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
          ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels_loop.hip", "lcr_kernels_loop.o", []),
          ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
-         # the two-cooperating-waves family (lcr_kernels2.hip): 10 one cube, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point manifold
-         ("lcr_kernels2.hip", "lcr_kernels2.o", ["-DLCR_PART=10"]),
-         ("lcr_kernels2.hip", "lcr_kernels2_stack.o", ["-DLCR_PART=12"]), ("lcr_kernels2.hip", "lcr_kernels2_stack_cc8.o", ["-DLCR_PART=13"])]
+         # the two-cooperating-waves family (lcr_kernels2.hip): 10 / 14 one cube built for one / two waves per SIMD, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point
+         # manifold.  Instruction-scheduling flags per unit, each measured on the MI355X against the default (tools/quick_times.py; results are bit-identical, the flags only
+         # reorder instructions): no post-RA scheduler for the 256-register build (Reach 65 536 envs 0.2578 -> 0.2554 ms, Push 0.3128 -> 0.3064, PickPlace-ee 0.3106 -> 0.3068);
+         # no post-RA scheduler + the iterative-ILP strategy for the one-wave-per-SIMD build (PickPlace-ee 32 768 envs 0.2292 -> 0.2180); iterative-ILP for Stack (0.4307 -> 0.4202).
+         # The one-wave kernels lose with each of them (Stack 65 536 envs 0.779 -> 0.90 / 1.16): default scheduling there.
+         ("lcr_kernels2.hip", "lcr_kernels2.o", ["-DLCR_PART=10"] + NO_POST_RA + ITER_ILP), ("lcr_kernels2.hip", "lcr_kernels2_occ2.o", ["-DLCR_PART=14"] + NO_POST_RA),
+         ("lcr_kernels2.hip", "lcr_kernels2_stack.o", ["-DLCR_PART=12"] + ITER_ILP), ("lcr_kernels2.hip", "lcr_kernels2_stack_cc8.o", ["-DLCR_PART=13"])]
 
 
 def build(force=False, verbose=False):
@@ -44,7 +50,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    deps = [os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]   # (the per-unit flags live in this file)
     objs, jobs = [], []
     for src, obj, extra in UNITS:
         s = os.path.join(CSRC, src)

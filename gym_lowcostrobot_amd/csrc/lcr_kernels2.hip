@@ -1838,31 +1838,39 @@ __global__ __launch_bounds__(128, OCC) void lcr_step2_kernel(LcrDev P, const flo
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// launchers.  build.py compiles this file once per LCR_PART (10: one cube, 12: StackTwoCubes, 13: StackTwoCubes with the eight-point manifold)
+// launchers.  build.py compiles this file once per LCR_PART (10 / 14: one cube, built for one / two waves per SIMD; 12: StackTwoCubes, 13: StackTwoCubes with the eight-point manifold)
 // ------------------------------------------------------------------------------------------------
 static int check_launch2() {
     hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : (int)err;
 }
 
-template <int NC, bool CC8>
-static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode, int occ, hipStream_t st) {
+template <int NC, bool CC8, int OCC>
+static int launch2_build(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
-#define LCR2_GO(EE, ROLL, OCC) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, ROLL, OCC, CC8>), dim3(blocks), dim3(128), 0, st, P, action_dev)
-    if (occ >= 2) {
-        if (ee_mode) { if (P.roll) LCR2_GO(true, true, 2); else LCR2_GO(true, false, 2); }
-        else { if (P.roll) LCR2_GO(false, true, 2); else LCR2_GO(false, false, 2); }
-    } else {
-        if (ee_mode) { if (P.roll) LCR2_GO(true, true, 1); else LCR2_GO(true, false, 1); }
-        else { if (P.roll) LCR2_GO(false, true, 1); else LCR2_GO(false, false, 1); }
-    }
+#define LCR2_GO(EE, ROLL) hipLaunchKernelGGL((lcr_step2_kernel<NC, EE, ROLL, OCC, CC8>), dim3(blocks), dim3(128), 0, st, P, action_dev)
+    if (ee_mode) { if (P.roll) LCR2_GO(true, true); else LCR2_GO(true, false); }
+    else { if (P.roll) LCR2_GO(false, true); else LCR2_GO(false, false); }
 #undef LCR2_GO
     return check_launch2();
 }
+template <int NC, bool CC8>
+static int launch2_family(const LcrDev &P, const float *action_dev, int ee_mode, int occ, hipStream_t st) {
+    return occ >= 2 ? launch2_build<NC, CC8, 2>(P, action_dev, ee_mode, st) : launch2_build<NC, CC8, 1>(P, action_dev, ee_mode, st);
+}
 
+// The one-cube kernels' two builds are separate units (10: one wave per SIMD, 14: two) because they want different instruction-scheduling flags
+// (gym_lowcostrobot_amd/build.py, measured: DESIGN.md section 5) -- same source, same bits.
+int lcr_launch_step2_one_cube_occ2(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
 #if LCR_HAS_PART(10)
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream) {
-    return launch2_family<1, false>(P, action_dev, ee_mode, occ, (hipStream_t)stream);
+    if (occ >= 2) return lcr_launch_step2_one_cube_occ2(P, action_dev, ee_mode, stream);
+    return launch2_build<1, false, 1>(P, action_dev, ee_mode, (hipStream_t)stream);
+}
+#endif
+#if LCR_HAS_PART(14)
+int lcr_launch_step2_one_cube_occ2(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
+    return launch2_build<1, false, 2>(P, action_dev, ee_mode, (hipStream_t)stream);
 }
 #endif
 #if LCR_HAS_PART(12)

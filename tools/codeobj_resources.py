@@ -24,9 +24,12 @@ def main():
     ap.add_argument("--out")
     a = ap.parse_args()
     res = {}
-    for src in ("lcr_kernels.hip", "lcr_kernels_loop.hip", "lcr_kernels2.hip", "lcr_render.hip"):
-        co = os.path.join(tempfile.gettempdir(), src + ".co")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["--cuda-device-only", "--no-gpu-bundle-output", "-c", os.path.join(B.CSRC, src), "-o", co], stderr=subprocess.DEVNULL)
+    for src, obj, extra in B.UNITS:          # every unit with the flags build.py gives it (scheduling flags differ per unit)
+        if src == "lcr_capi.hip":
+            continue
+        co = os.path.join(tempfile.gettempdir(), obj + ".co")
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + extra + ["--cuda-device-only", "--no-gpu-bundle-output", "-c", os.path.join(B.CSRC, src), "-o", co],
+                              stderr=subprocess.DEVNULL)
         txt = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], text=True)
         cur = None
         for ln in txt.split("\n"):

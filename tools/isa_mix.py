@@ -119,7 +119,7 @@ def main():
         sys.path.insert(0, ROOT)
         from gym_lowcostrobot_amd import build as B
 
-        src, part = ("lcr_kernels2.hip", ["-DLCR_PART=10"]) if "step2" in a.kernel else ("lcr_kernels.hip", ["-DLCR_PART=0"])
+        src, part = ("lcr_kernels2.hip", ["-DLCR_PART=14"] + B.NO_POST_RA) if "step2" in a.kernel else ("lcr_kernels.hip", ["-DLCR_PART=0"])   # (as build.py builds the unit)
         path = os.path.join(tempfile.gettempdir(), src.replace(".hip", ".s"))
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + part + ["-S", "--cuda-device-only", "-o", path, os.path.join(B.CSRC, src)],
                               stderr=subprocess.DEVNULL)
