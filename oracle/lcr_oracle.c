@@ -1210,6 +1210,149 @@ static int newton_primal(int nv, int nr, const real *M, const real *J, const rea
     return it;
 }
 
+/* ---- the PRODUCT's faithful solver (orc_params.solver = 2, round 5): nonlinear conjugate gradients on the PRIMAL problem ---------------------------------
+ * MuJoCo's "CG" solver (MJ-DOC Computation / Solver algorithms: Polak-Ribiere-Plus directions, preconditioned, exact line search by one-dimensional Newton
+ * steps on phi'(al)) -- the matrix-free sibling of its default Newton solver; both minimise the same strictly convex F (see newton_primal above), so both land on
+ * the SAME optimum, which is what parity needs.  Written in `real` arithmetic (the fp32 twin of this oracle exercises the float behaviour of the kernels'
+ * iteration).  precond: 0 = M (MuJoCo's choice), 1 = the body-diagonal blocks of the Hessian M + J'WJ (arm 6x6, each cube 6x6), refreshed every iteration.
+ * Fixed iteration count `iters`, fixed `ls_iters` line-search refinements (wave-uniform on the GPU); warm start from the carried forces: x0 = a0 + M^-1 J' f. */
+static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, const int *blkdim, const double *const *rowmu, real *f, real *W /* nr x 6 or NULL */) {
+    for (int i = 0; i < nr; i++) {
+        if (kind[i] == 2) continue;
+        const int dm = kind[i] == 0 ? 1 : blkdim[i];
+        if (W) for (int r = 0; r < dm; r++) for (int c = 0; c < 6; c++) W[(size_t)(i + r) * 6 + c] = 0;
+        if (kind[i] == 0) {
+            f[i] = z[i] < 0 ? -z[i] / Rr[i] : 0;
+            if (W && z[i] < 0) W[(size_t)i * 6] = (real)1 / Rr[i];
+            continue;
+        }
+        const double *mu = rowmu[i];
+        const real Rn = Rr[i], Rt = Rr[i + 1] * (real)(mu[0] * mu[0]);
+        real w[6], N = 0, y[6];
+        w[0] = z[i];
+        for (int r = 1; r < dm; r++) { w[r] = (real)mu[r - 1] * z[i + r]; N += w[r] * w[r]; }
+        N = (real)sqrt((double)N);
+        if (w[0] >= N) { for (int r = 0; r < dm; r++) y[r] = 0; }
+        else if (N * Rn <= -w[0] * Rt) {
+            y[0] = -w[0] / Rn;
+            for (int r = 1; r < dm; r++) y[r] = -w[r] / Rt;
+            if (W) { W[(size_t)i * 6] = (real)1 / Rn; for (int r = 1; r < dm; r++) W[(size_t)(i + r) * 6 + r] = (real)(mu[r - 1] * mu[r - 1]) / Rt; }
+        } else {
+            const real D = Rn + Rt;
+            y[0] = (N - w[0]) / D;
+            for (int r = 1; r < dm; r++) y[r] = -y[0] * w[r] / N;
+            if (W) {
+                real u[6];
+                for (int r = 1; r < dm; r++) u[r] = w[r] / N;
+                W[(size_t)i * 6] = (real)1 / D;
+                for (int r = 1; r < dm; r++) {
+                    W[(size_t)i * 6 + r] = -u[r] / D * (real)mu[r - 1];
+                    W[(size_t)(i + r) * 6] = -u[r] / D * (real)mu[r - 1];
+                    for (int c = 1; c < dm; c++)
+                        W[(size_t)(i + r) * 6 + c] = (u[r] * u[c] / D + (y[0] / N) * ((r == c ? (real)1 : (real)0) - u[r] * u[c])) * (real)(mu[r - 1] * mu[c - 1]);
+                }
+            }
+        }
+        f[i] = y[0];
+        for (int r = 1; r < dm; r++) f[i + r] = y[r] * (real)mu[r - 1];
+    }
+}
+static int cg_primal(int nv, int nr, const real *M, const real *Lm /* chol of M */, const real *J, const real *aref, const real *Rr, const real *a0, const int *kind,
+                     const int *blkdim, const double *const *rowmu, real *f /* in: warm-start forces, out: forces */, int iters, int ls_iters, int precond, double tol) {
+    real x[ORC_NV_MAX], g[ORC_NV_MAX], Mg[ORC_NV_MAX], g_old[ORC_NV_MAX], Mg_old[ORC_NV_MAX], s[ORC_NV_MAX], tmp[ORC_NV_MAX];
+    real *z = (real *)malloc(sizeof(real) * (size_t)nr * 16), *Js = z + nr, *zt = Js + nr, *ft = zt + nr, *W = ft + nr;
+    /* warm start x0 = a0 + M^-1 J' f */
+    for (int d = 0; d < nv; d++) { real acc = 0; for (int i = 0; i < nr; i++) acc += J[(size_t)i * nv + d] * f[i]; tmp[d] = acc; }
+    chol_solve(Lm, nv, tmp);
+    for (int d = 0; d < nv; d++) x[d] = a0[d] + tmp[d];
+    for (int d = 0; d < nv; d++) { s[d] = 0; g_old[d] = 0; Mg_old[d] = 0; }
+    int it, used = 0;
+    for (it = 0; it <= iters; it++) {
+        for (int i = 0; i < nr; i++) { real acc = -aref[i]; for (int d = 0; d < nv; d++) acc += J[(size_t)i * nv + d] * x[d]; z[i] = acc; }
+        prim_forces(nr, z, Rr, kind, blkdim, rowmu, f, W);
+        if (it == iters) break;
+        real gn = 0, sc = 0;
+        for (int i = 0; i < nv; i++) {
+            real acc = 0;
+            for (int j = 0; j < nv; j++) acc += M[i * nv + j] * (x[j] - a0[j]);
+            for (int r = 0; r < nr; r++) acc -= J[(size_t)r * nv + i] * f[r];
+            g[i] = acc;
+        }
+        /* preconditioner */
+        for (int i = 0; i < nv; i++) Mg[i] = g[i];
+        if (precond == 0) chol_solve(Lm, nv, Mg);
+        else {
+            for (int b = 0; b < nv / 6; b++) {
+                real Hb[36];
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Hb[a * 6 + c] = M[(6 * b + a) * nv + 6 * b + c];
+                for (int i = 0; i < nr; i++) {
+                    if (kind[i] == 2) continue;
+                    const int dm = kind[i] == 0 ? 1 : blkdim[i];
+                    for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) {
+                        const real wv = W[(size_t)(i + r) * 6 + c];
+                        if (wv == 0) continue;
+                        for (int a = 0; a < 6; a++) for (int c2 = 0; c2 < 6; c2++) Hb[a * 6 + c2] += J[(size_t)(i + r) * nv + 6 * b + a] * wv * J[(size_t)(i + c) * nv + 6 * b + c2];
+                    }
+                }
+                chol(Hb, 6);
+                chol_solve(Hb, 6, Mg + 6 * b);
+            }
+        }
+        for (int i = 0; i < nv; i++) { gn += g[i] * Mg[i]; sc += M[i * nv + i]; }
+        (void)sc;
+        if (tol > 0 && (double)gn <= tol * tol) break;   /* |g| in the preconditioner's norm */
+        used = it + 1;
+        real beta = 0;
+        if (it > 0) {
+            real num = 0, den = 0;
+            for (int i = 0; i < nv; i++) { num += g[i] * (Mg[i] - Mg_old[i]); den += g_old[i] * Mg_old[i]; }
+            beta = den > 0 ? num / den : 0;
+            if (beta < 0) beta = 0;
+        }
+        for (int i = 0; i < nv; i++) { s[i] = -Mg[i] + beta * s[i]; g_old[i] = g[i]; Mg_old[i] = Mg[i]; }
+        /* line search: phi'(al) = q0 + al q1 - sum f(z + al Js) . Js ,  phi'' = q1 + Js' W Js */
+        real q1 = 0, d0 = 0;
+        for (int i = 0; i < nv; i++) { real acc = 0; for (int j = 0; j < nv; j++) acc += M[i * nv + j] * s[j]; q1 += s[i] * acc; d0 += g[i] * s[i]; }
+        for (int i = 0; i < nr; i++) { real acc = 0; for (int d = 0; d < nv; d++) acc += J[(size_t)i * nv + d] * s[d]; Js[i] = acc; }
+        real fJ0 = 0;
+        for (int i = 0; i < nr; i++) fJ0 += f[i] * Js[i];
+        const real q0 = d0 + fJ0;                     /* quadratic part of phi'(0) */
+        real al = 0, lo = 0, hi = -1, dphi = d0, hphi;
+        {
+            real acc = q1;
+            /* Js' W Js : W rows are stored per row with block-local column index */
+            for (int i = 0; i < nr; i++) {
+                if (kind[i] == 2) continue;
+                const int dm = kind[i] == 0 ? 1 : blkdim[i];
+                for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) acc += Js[i + r] * W[(size_t)(i + r) * 6 + c] * Js[i + c];
+            }
+            hphi = acc;
+        }
+        if (!(dphi < 0)) { continue; }
+        al = -dphi / hphi;
+        for (int ls = 0; ls < ls_iters; ls++) {
+            for (int i = 0; i < nr; i++) zt[i] = z[i] + al * Js[i];
+            prim_forces(nr, zt, Rr, kind, blkdim, rowmu, ft, W);
+            real fJ = 0, acc = q1;
+            for (int i = 0; i < nr; i++) fJ += ft[i] * Js[i];
+            for (int i = 0; i < nr; i++) {
+                if (kind[i] == 2) continue;
+                const int dm = kind[i] == 0 ? 1 : blkdim[i];
+                for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) acc += Js[i + r] * W[(size_t)(i + r) * 6 + c] * Js[i + c];
+            }
+            dphi = q0 + al * q1 - fJ; hphi = acc;
+            if (dphi < 0) lo = al; else hi = al;
+            real an = al - dphi / hphi;
+            if (hi >= 0) { if (!(an > lo && an < hi)) an = (real)0.5 * (lo + hi); }
+            else if (!(an > lo)) an = 2 * al;
+            al = an;
+        }
+        for (int i = 0; i < nv; i++) x[i] += al * s[i];
+    }
+    free(z);
+    return used;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* one physics substep == mujoco.mj_step (reach_cube_env.py:276-277) -- MJ-DOC restatement          */
 /* ------------------------------------------------------------------------------------------------ */
@@ -1413,7 +1556,17 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         int max_it = adaptive ? (P->pgs_cap > 0 ? P->pgs_cap : ORC_PGS_CAP) : P->pgs_iters;
         if (P->solver == 1) {   /* the exact optimum of the convex problem (primal Newton, as MuJoCo's default solver) instead of PGS sweeps */
             const int nit = newton_primal(nv, nr, M, J, aref, Rr, a0, kind, blkdim, rowmu, f, 100);
-            if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
+            if (getenv("ORC_SWEEP_SUM")) lag->max_sweeps += (uint32_t)nit;
+            else if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
+            max_it = 0;
+        }
+        if (P->solver == 2) {   /* the product's faithful solver: primal conjugate gradients (see cg_primal) */
+            static int cg_ls = -1, cg_pre = -1;
+            if (cg_ls < 0) { cg_ls = getenv("ORC_CG_LS") ? atoi(getenv("ORC_CG_LS")) : 3; cg_pre = getenv("ORC_CG_PRE") ? atoi(getenv("ORC_CG_PRE")) : 0; }
+            const int nit = cg_primal(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, P->pgs_iters > 0 ? P->pgs_iters : (P->pgs_cap > 0 ? P->pgs_cap : 50), cg_ls, cg_pre,
+                                      P->pgs_iters > 0 ? 0.0 : P->pgs_tol);
+            if (getenv("ORC_SWEEP_SUM")) lag->max_sweeps += (uint32_t)nit;
+            else if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
             max_it = 0;
         }
         double lastchange = 0;
@@ -1464,6 +1617,38 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                 }
             }
             sweeps++;
+            {   /* (study, ORC_MOMENTUM=1) Nesterov extrapolation of the sweep's net change, projected back onto the cones; restart when successive changes oppose */
+                static int mom = -1;
+                static __thread real dprev[MAX_ROWS];
+                static __thread double tk;
+                if (mom < 0) mom = getenv("ORC_MOMENTUM") ? atoi(getenv("ORC_MOMENTUM")) : 0;
+                if (mom) {
+                    if (it == 0) { tk = 1.0; for (int i = 0; i < nr; i++) dprev[i] = 0; }
+                    double dd = 0;
+                    for (int i = 0; i < nr; i++) dd += (double)(f[i] - f_start[i]) * (double)dprev[i];
+                    if (dd < 0) tk = 1.0;
+                    const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk)), beta = (tk - 1.0) / tn;
+                    tk = tn;
+                    for (int i = 0; i < nr; i++) { dprev[i] = f[i] - f_start[i]; }
+                    if (it + 1 < max_it) {
+                        for (int i = 0; i < nr; i++) f[i] += (real)beta * dprev[i];
+                        for (int i = 0; i < nr; i++) {
+                            if (kind[i] == 0) { if (f[i] < 0) f[i] = 0; }
+                            else if (kind[i] == 1) {
+                                const int dm = blkdim[i]; const double *mu = rowmu[i];
+                                double N = 0; for (int r = 1; r < dm; r++) N += (double)f[i + r] * (double)f[i + r] / (mu[r - 1] * mu[r - 1]);
+                                N = sqrt(N);
+                                double y0 = (double)f[i];
+                                if (N <= y0) continue;
+                                if (N <= -y0) { for (int r = 0; r < dm; r++) f[i + r] = 0; continue; }
+                                const double a = 0.5 * (y0 + N);
+                                f[i] = (real)a;
+                                for (int r = 1; r < dm; r++) f[i + r] = (real)((double)f[i + r] * a / N);
+                            }
+                        }
+                    }
+                }
+            }
             for (int i = 0; i < nr; i++) {
                 if (fabs((double)f[i]) > fmaxabs) fmaxabs = fabs((double)f[i]);
                 if (fabs((double)(f[i] - f_start[i])) > lastchange) lastchange = fabs((double)(f[i] - f_start[i]));
@@ -1477,7 +1662,12 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             if (k > lag->kkt) lag->kkt = k;
         }
         free(MiJt); free(A);
-        if ((uint32_t)sweeps > lag->max_sweeps) lag->max_sweeps = (uint32_t)sweeps;
+        {   /* study aid (tools/solver_modes_study.py): ORC_SWEEP_SUM=1 makes max_sweeps the SUM over the substeps of a control step */
+            static int sum_mode = -1;
+            if (sum_mode < 0) sum_mode = getenv("ORC_SWEEP_SUM") != NULL;
+            if (sum_mode) lag->max_sweeps += (uint32_t)sweeps;
+            else if ((uint32_t)sweeps > lag->max_sweeps) lag->max_sweeps = (uint32_t)sweeps;
+        }
         if (diag) { g_diag_res = lastchange; }
     }
     /* slots that are not active in this substep restart from zero */
