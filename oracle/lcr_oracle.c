@@ -1210,12 +1210,19 @@ static int newton_primal(int nv, int nr, const real *M, const real *J, const rea
     return it;
 }
 
-/* ---- the PRODUCT's faithful solver (orc_params.solver = 2, round 5): nonlinear conjugate gradients on the PRIMAL problem ---------------------------------
- * MuJoCo's "CG" solver (MJ-DOC Computation / Solver algorithms: Polak-Ribiere-Plus directions, preconditioned, exact line search by one-dimensional Newton
- * steps on phi'(al)) -- the matrix-free sibling of its default Newton solver; both minimise the same strictly convex F (see newton_primal above), so both land on
- * the SAME optimum, which is what parity needs.  Written in `real` arithmetic (the fp32 twin of this oracle exercises the float behaviour of the kernels'
- * iteration).  precond: 0 = M (MuJoCo's choice), 1 = the body-diagonal blocks of the Hessian M + J'WJ (arm 6x6, each cube 6x6), refreshed every iteration.
- * Fixed iteration count `iters`, fixed `ls_iters` line-search refinements (wave-uniform on the GPU); warm start from the carried forces: x0 = a0 + M^-1 J' f. */
+/* ---- the PRODUCT's faithful solver (orc_params.solver = 2, round 5; = the NEWTON kernels): MuJoCo's default algorithm with a fixed budget ---------------
+ * Newton's method on the primal problem (see newton_primal above for F and the zones), all nv accelerations at once, in `real` arithmetic (the fp32 twin of this
+ * oracle exercises the float behaviour of the kernels' iteration):
+ *   start     x0 = a0 + M^-1 J' f_carried   (the constraint forces carried from the previous substep / control step; MuJoCo: qacc_warmstart)
+ *   iteration g = M (x - a0) - J' f(x),  H = M + J' W(x) J  (W: block-diagonal Jacobian of -f w.r.t. the row residuals, zero / diagonal / rank-structured in
+ *             the top / bottom / middle zone of a contact's cone),  dx = -H^-1 g  (Cholesky);  stop when the Newton decrement -g'dx <= newton_tol^2 (1 + |x0|_M^2)
+ *   line search on phi(al) = F(x + al dx), convex and C^1: derivative-only -- phi'(al) = grad F(x + al dx) . dx costs one gradient pass --, first al = 1 (exact while
+ *             no contact changes zone), bracket by doubling, then the Illinois variant of regula falsi; at most ls_iters evaluations, stop when
+ *             |phi'(al)| <= ls_tol |phi'(0)|.  (Measured, profiles/r05_solver_decision.txt: the search must be accurate, and the derivative-only iteration beats
+ *             1-D Newton steps on phi' at equal evaluations.)
+ *   at most newton_iters iterations (default 10).  On the GPU both loops are left wave-uniformly (when every lane of the wave has met the criterion), so a lane may
+ *   iterate further than here -- at the optimum that changes nothing beyond rounding.
+ * Returns the forces f(x) and the accelerations x themselves: the integration uses x (M (x - a0) = J' f at the optimum). */
 static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, const int *blkdim, const double *const *rowmu, real *f, real *W /* nr x 6 or NULL */) {
     for (int i = 0; i < nr; i++) {
         if (kind[i] == 2) continue;
@@ -1257,100 +1264,69 @@ static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, 
         for (int r = 1; r < dm; r++) f[i + r] = y[r] * (real)mu[r - 1];
     }
 }
-static int cg_primal(int nv, int nr, const real *M, const real *Lm /* chol of M */, const real *J, const real *aref, const real *Rr, const real *a0, const int *kind,
-                     const int *blkdim, const double *const *rowmu, real *f /* in: warm-start forces, out: forces */, int iters, int ls_iters, int precond, double tol) {
-    real x[ORC_NV_MAX], g[ORC_NV_MAX], Mg[ORC_NV_MAX], g_old[ORC_NV_MAX], Mg_old[ORC_NV_MAX], s[ORC_NV_MAX], tmp[ORC_NV_MAX];
-    real *z = (real *)malloc(sizeof(real) * (size_t)nr * 16), *Js = z + nr, *zt = Js + nr, *ft = zt + nr, *W = ft + nr;
-    /* warm start x0 = a0 + M^-1 J' f */
+static int newton_product(int nv, int nr, const real *M, const real *Lm, const real *J, const real *aref, const real *Rr, const real *a0, const int *kind,
+                          const int *blkdim, const double *const *rowmu, real *f, real *x_out, int iters, int ls_iters, double tol, double ls_tol) {
+    real x[ORC_NV_MAX], xa[ORC_NV_MAX], g[ORC_NV_MAX], H[ORC_NV_MAX * ORC_NV_MAX], dx[ORC_NV_MAX], tmp[ORC_NV_MAX];
+    real *z = (real *)malloc(sizeof(real) * (size_t)(nr + 1) * 8), *W = z + nr + 1;
     for (int d = 0; d < nv; d++) { real acc = 0; for (int i = 0; i < nr; i++) acc += J[(size_t)i * nv + d] * f[i]; tmp[d] = acc; }
     chol_solve(Lm, nv, tmp);
-    for (int d = 0; d < nv; d++) x[d] = a0[d] + tmp[d];
-    for (int d = 0; d < nv; d++) { s[d] = 0; g_old[d] = 0; Mg_old[d] = 0; }
-    int it, used = 0;
-    for (it = 0; it <= iters; it++) {
-        for (int i = 0; i < nr; i++) { real acc = -aref[i]; for (int d = 0; d < nv; d++) acc += J[(size_t)i * nv + d] * x[d]; z[i] = acc; }
-        prim_forces(nr, z, Rr, kind, blkdim, rowmu, f, W);
-        if (it == iters) break;
-        real gn = 0, sc = 0;
-        for (int i = 0; i < nv; i++) {
-            real acc = 0;
-            for (int j = 0; j < nv; j++) acc += M[i * nv + j] * (x[j] - a0[j]);
-            for (int r = 0; r < nr; r++) acc -= J[(size_t)r * nv + i] * f[r];
-            g[i] = acc;
-        }
-        /* preconditioner */
-        for (int i = 0; i < nv; i++) Mg[i] = g[i];
-        if (precond == 0) chol_solve(Lm, nv, Mg);
-        else {
-            for (int b = 0; b < nv / 6; b++) {
-                real Hb[36];
-                for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Hb[a * 6 + c] = M[(6 * b + a) * nv + 6 * b + c];
-                for (int i = 0; i < nr; i++) {
-                    if (kind[i] == 2) continue;
-                    const int dm = kind[i] == 0 ? 1 : blkdim[i];
-                    for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) {
-                        const real wv = W[(size_t)(i + r) * 6 + c];
-                        if (wv == 0) continue;
-                        for (int a = 0; a < 6; a++) for (int c2 = 0; c2 < 6; c2++) Hb[a * 6 + c2] += J[(size_t)(i + r) * nv + 6 * b + a] * wv * J[(size_t)(i + c) * nv + 6 * b + c2];
-                    }
-                }
-                chol(Hb, 6);
-                chol_solve(Hb, 6, Mg + 6 * b);
+    real scale = 1;
+    for (int d = 0; d < nv; d++) { x[d] = a0[d] + tmp[d]; real acc = 0; for (int j = 0; j < nv; j++) acc += M[d * nv + j] * a0[j]; scale += a0[d] * acc; }
+    /* gradient of F at xx (and, with Wm, the blocks of W) */
+#define NP_GRAD(xx, Wm)                                                                                                                        \
+    do {                                                                                                                                       \
+        for (int i = 0; i < nr; i++) { real acc = -aref[i]; for (int d = 0; d < nv; d++) acc += J[(size_t)i * nv + d] * (xx)[d]; z[i] = acc; } \
+        prim_forces(nr, z, Rr, kind, blkdim, rowmu, f, (Wm));                                                                                  \
+        for (int i = 0; i < nv; i++) {                                                                                                         \
+            real acc = 0;                                                                                                                      \
+            for (int j = 0; j < nv; j++) acc += M[i * nv + j] * ((xx)[j] - a0[j]);                                                             \
+            for (int r = 0; r < nr; r++) acc -= J[(size_t)r * nv + i] * f[r];                                                                  \
+            g[i] = acc;                                                                                                                        \
+        }                                                                                                                                      \
+    } while (0)
+    int it;
+    for (it = 0; it < iters; it++) {
+        NP_GRAD(x, W);
+        for (int a = 0; a < nv; a++) for (int c = 0; c < nv; c++) H[a * nv + c] = M[a * nv + c];
+        for (int i = 0; i < nr; i++) {
+            if (kind[i] == 2) continue;
+            const int dm = kind[i] == 0 ? 1 : blkdim[i];
+            for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) {
+                const real wv = W[(size_t)(i + r) * 6 + c];
+                if (wv == 0) continue;
+                for (int a = 0; a < nv; a++) { const real ja = J[(size_t)(i + r) * nv + a] * wv; if (ja == 0) continue;
+                    for (int c2 = 0; c2 < nv; c2++) H[a * nv + c2] += ja * J[(size_t)(i + c) * nv + c2]; }
             }
         }
-        for (int i = 0; i < nv; i++) { gn += g[i] * Mg[i]; sc += M[i * nv + i]; }
-        (void)sc;
-        if (tol > 0 && (double)gn <= tol * tol) break;   /* |g| in the preconditioner's norm */
-        used = it + 1;
-        real beta = 0;
-        if (it > 0) {
-            real num = 0, den = 0;
-            for (int i = 0; i < nv; i++) { num += g[i] * (Mg[i] - Mg_old[i]); den += g_old[i] * Mg_old[i]; }
-            beta = den > 0 ? num / den : 0;
-            if (beta < 0) beta = 0;
-        }
-        for (int i = 0; i < nv; i++) { s[i] = -Mg[i] + beta * s[i]; g_old[i] = g[i]; Mg_old[i] = Mg[i]; }
-        /* line search: phi'(al) = q0 + al q1 - sum f(z + al Js) . Js ,  phi'' = q1 + Js' W Js */
-        real q1 = 0, d0 = 0;
-        for (int i = 0; i < nv; i++) { real acc = 0; for (int j = 0; j < nv; j++) acc += M[i * nv + j] * s[j]; q1 += s[i] * acc; d0 += g[i] * s[i]; }
-        for (int i = 0; i < nr; i++) { real acc = 0; for (int d = 0; d < nv; d++) acc += J[(size_t)i * nv + d] * s[d]; Js[i] = acc; }
-        real fJ0 = 0;
-        for (int i = 0; i < nr; i++) fJ0 += f[i] * Js[i];
-        const real q0 = d0 + fJ0;                     /* quadratic part of phi'(0) */
-        real al = 0, lo = 0, hi = -1, dphi = d0, hphi;
-        {
-            real acc = q1;
-            /* Js' W Js : W rows are stored per row with block-local column index */
-            for (int i = 0; i < nr; i++) {
-                if (kind[i] == 2) continue;
-                const int dm = kind[i] == 0 ? 1 : blkdim[i];
-                for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) acc += Js[i + r] * W[(size_t)(i + r) * 6 + c] * Js[i + c];
-            }
-            hphi = acc;
-        }
-        if (!(dphi < 0)) { continue; }
-        al = -dphi / hphi;
+        for (int a = 0; a < nv; a++) dx[a] = -g[a];
+        if (chol(H, nv)) break;
+        chol_solve(H, nv, dx);
+        real d0 = 0;
+        for (int a = 0; a < nv; a++) d0 += g[a] * dx[a];
+        if (!((double)-d0 > tol * tol * (double)scale)) break;    /* Newton decrement: converged (or no descent) */
+        /* line search: phi'(al) = grad F(x + al dx) . dx */
+        real al = 1, lo_a = 0, hi_a = -1, dlo = d0, dhi = 0;
         for (int ls = 0; ls < ls_iters; ls++) {
-            for (int i = 0; i < nr; i++) zt[i] = z[i] + al * Js[i];
-            prim_forces(nr, zt, Rr, kind, blkdim, rowmu, ft, W);
-            real fJ = 0, acc = q1;
-            for (int i = 0; i < nr; i++) fJ += ft[i] * Js[i];
-            for (int i = 0; i < nr; i++) {
-                if (kind[i] == 2) continue;
-                const int dm = kind[i] == 0 ? 1 : blkdim[i];
-                for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) acc += Js[i + r] * W[(size_t)(i + r) * 6 + c] * Js[i + c];
-            }
-            dphi = q0 + al * q1 - fJ; hphi = acc;
-            if (dphi < 0) lo = al; else hi = al;
-            real an = al - dphi / hphi;
-            if (hi >= 0) { if (!(an > lo && an < hi)) an = (real)0.5 * (lo + hi); }
-            else if (!(an > lo)) an = 2 * al;
+            for (int d = 0; d < nv; d++) xa[d] = x[d] + al * dx[d];
+            NP_GRAD(xa, NULL);
+            real dphi = 0;
+            for (int a = 0; a < nv; a++) dphi += g[a] * dx[a];
+            const int done = fabs((double)dphi) <= ls_tol * fabs((double)d0);
+            if (dphi < 0) { if (hi_a >= 0 && lo_a > 0) dhi *= (real)0.5; lo_a = al; dlo = dphi; }
+            else { if (hi_a >= 0) dlo *= (real)0.5; hi_a = al; dhi = dphi; }
+            if (done) break;
+            real an;
+            if (hi_a < 0) an = 2 * al;
+            else { an = lo_a - dlo * (hi_a - lo_a) / (dhi - dlo); if (!(an > lo_a && an < hi_a)) an = (real)0.5 * (lo_a + hi_a); }
             al = an;
         }
-        for (int i = 0; i < nv; i++) x[i] += al * s[i];
+        for (int d = 0; d < nv; d++) x[d] += al * dx[d];
     }
+    NP_GRAD(x, NULL);
+#undef NP_GRAD
+    for (int d = 0; d < nv; d++) x_out[d] = x[d];
     free(z);
-    return used;
+    return it;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1530,6 +1506,8 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
     /* -- dual problem: A = J M^-1 J^T, b = J a0 - aref ; PGS, warm start, fixed or adaptive sweep count (D1, D2) */
     real f[MAX_ROWS];
     real qfc[ORC_NV_MAX];
+    real xsol[ORC_NV_MAX];   /* solver = 3: the primal iterate (accelerations) */
+    int use_x = 0;
     memset(qfc, 0, sizeof qfc);
     if (nr > 0) {
         real *MiJt = (real *)malloc(sizeof(real) * (size_t)nr * nv);
@@ -1560,11 +1538,10 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             else if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
             max_it = 0;
         }
-        if (P->solver == 2) {   /* the product's faithful solver: primal conjugate gradients (see cg_primal) */
-            static int cg_ls = -1, cg_pre = -1;
-            if (cg_ls < 0) { cg_ls = getenv("ORC_CG_LS") ? atoi(getenv("ORC_CG_LS")) : 3; cg_pre = getenv("ORC_CG_PRE") ? atoi(getenv("ORC_CG_PRE")) : 0; }
-            const int nit = cg_primal(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, P->pgs_iters > 0 ? P->pgs_iters : (P->pgs_cap > 0 ? P->pgs_cap : 50), cg_ls, cg_pre,
-                                      P->pgs_iters > 0 ? 0.0 : P->pgs_tol);
+        if (P->solver == 2) {   /* the product's faithful solver: Newton on the primal with a fixed budget (see newton_product) */
+            const int nit = newton_product(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, xsol, P->newton_iters > 0 ? P->newton_iters : 10,
+                                           P->ls_iters > 0 ? P->ls_iters : 8, P->newton_tol > 0 ? P->newton_tol : 1e-6, P->ls_tol > 0 ? P->ls_tol : 1e-4);
+            use_x = 1;
             if (getenv("ORC_SWEEP_SUM")) lag->max_sweeps += (uint32_t)nit;
             else if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
             max_it = 0;
@@ -1617,38 +1594,6 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
                 }
             }
             sweeps++;
-            {   /* (study, ORC_MOMENTUM=1) Nesterov extrapolation of the sweep's net change, projected back onto the cones; restart when successive changes oppose */
-                static int mom = -1;
-                static __thread real dprev[MAX_ROWS];
-                static __thread double tk;
-                if (mom < 0) mom = getenv("ORC_MOMENTUM") ? atoi(getenv("ORC_MOMENTUM")) : 0;
-                if (mom) {
-                    if (it == 0) { tk = 1.0; for (int i = 0; i < nr; i++) dprev[i] = 0; }
-                    double dd = 0;
-                    for (int i = 0; i < nr; i++) dd += (double)(f[i] - f_start[i]) * (double)dprev[i];
-                    if (dd < 0) tk = 1.0;
-                    const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk)), beta = (tk - 1.0) / tn;
-                    tk = tn;
-                    for (int i = 0; i < nr; i++) { dprev[i] = f[i] - f_start[i]; }
-                    if (it + 1 < max_it) {
-                        for (int i = 0; i < nr; i++) f[i] += (real)beta * dprev[i];
-                        for (int i = 0; i < nr; i++) {
-                            if (kind[i] == 0) { if (f[i] < 0) f[i] = 0; }
-                            else if (kind[i] == 1) {
-                                const int dm = blkdim[i]; const double *mu = rowmu[i];
-                                double N = 0; for (int r = 1; r < dm; r++) N += (double)f[i + r] * (double)f[i + r] / (mu[r - 1] * mu[r - 1]);
-                                N = sqrt(N);
-                                double y0 = (double)f[i];
-                                if (N <= y0) continue;
-                                if (N <= -y0) { for (int r = 0; r < dm; r++) f[i + r] = 0; continue; }
-                                const double a = 0.5 * (y0 + N);
-                                f[i] = (real)a;
-                                for (int r = 1; r < dm; r++) f[i + r] = (real)((double)f[i + r] * a / N);
-                            }
-                        }
-                    }
-                }
-            }
             for (int i = 0; i < nr; i++) {
                 if (fabs((double)f[i]) > fmaxabs) fmaxabs = fabs((double)f[i]);
                 if (fabs((double)(f[i] - f_start[i])) > lastchange) lastchange = fabs((double)(f[i] - f_start[i]));
@@ -1657,6 +1602,9 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         }
         for (int i = 0; i < nr; i++)
             for (int d = 0; d < nv; d++) qfc[d] += J[(size_t)i * nv + d] * f[i];
+        if (use_x) {   /* integrate with the primal iterate itself: qfrc_constraint := M (x - a0) (= J'f at the optimum) */
+            for (int d = 0; d < nv; d++) { real acc = 0; for (int j = 0; j < nv; j++) acc += M[d * nv + j] * (xsol[j] - a0[j]); qfc[d] = acc; }
+        }
         if (lag->want_kkt) {
             const double k = kkt_residual(A, nr, bvec, Rr, f, kind, blkdim, rowmu);
             if (k > lag->kkt) lag->kkt = k;
@@ -1735,6 +1683,15 @@ void orc_default_params(orc_params *p, int task) {
     p->solver = 0;    /* PGS (what the kernels run) */
     p->jacobi = task == ORC_TASK_PUSH_LOOP ? 0 : 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
+    p->newton_iters = 10; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-4;   /* (read by solver = 2 only) */
+}
+void orc_preset_params(orc_params *p, int task, int preset) {
+    orc_default_params(p, task);
+    if (preset == ORC_PRESET_FAITHFUL) {
+        p->solver = 2;                       /* Newton on the primal: MuJoCo's default solver (follower.xml:3 names none) */
+        p->condim6 = 2;                      /* follower.xml:15 condim="6" on every finger contact */
+        p->cc_points = 8;                    /* as many points as MuJoCo's box-box collider may return (stack_two_cubes.xml:25-35) */
+    }
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
 int orc_nv(int task) { return task == ORC_TASK_STACK ? 18 : 12; }

@@ -41,6 +41,10 @@ class OrcParams(ctypes.Structure):
         ("pgs_cap", ctypes.c_int32),    # most sweeps of the converged mode (0 = 50)
         ("solver", ctypes.c_int32),     # 0: PGS (= the kernels); 1: primal Newton to machine precision (exact optimum of MuJoCo's convex problem)
         ("jacobi", ctypes.c_int32),     # 1 (default; push_loop: 0): two row groups (arm-only | cube rows) sweep concurrently (= the kernels' two waves); 0: one Gauss-Seidel pass
+        ("newton_iters", ctypes.c_int32),  # solver = 2 (preset "faithful"): most Newton iterations per substep
+        ("ls_iters", ctypes.c_int32),      # ... most evaluations of phi' per line search
+        ("newton_tol", ctypes.c_double),
+        ("ls_tol", ctypes.c_double),
     ]
 
 

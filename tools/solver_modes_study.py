@@ -53,8 +53,8 @@ if __name__ == "__main__":
     ap.add_argument("--exact_walk", type=int, default=0)
     ap.add_argument("--tasks", default="reach,push,lift,pick_place,stack,push_loop")
     a = ap.parse_args()
-    cands = {f"pg{k}": dict(cone=3, pgs_iters=k) for k in (4, 8, 16, 32)}
-    cands.update({f"pg5-{k}": dict(cone=5, pgs_iters=k) for k in (4, 8, 16, 32)})
+    cands = {"pg4": dict(cone=3, pgs_iters=4), "newton": dict(solver=2)}
+    cands.update({f"newton{k}/{l}": dict(solver=2, newton_iters=k, ls_iters=l) for k, l in ((4, 8), (6, 8), (8, 4), (8, 6), (8, 8), (10, 8), (12, 8), (12, 12))})
     for tm in a.tasks.split(","):
         mode = "ee" if tm == "pick_place" else "joint"
         base = dict(condim6=2, cc_points=8) if a.faithful else {}
