@@ -11,13 +11,15 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LCR_LIB_PATH") or os.path.join(_HERE, "liblcr_hip.so")  # override: A/B builds of the same ABI
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NWARM = 124   # LCR_NWARM: floats per env of carried constraint forces (layout: include/lcr.h)
 TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_loop": 5}
 ACTION_MODES = {"joint": 0, "ee": 1}
 OBS_MODES = {"image": 0, "state": 1, "both": 2}
 REWARD_TYPES = {"sparse": 0, "dense": 1}
 STEP_KERNELS = {"auto": 0, "single": 1, "coop": 2}   # lcr_config.step_kernel
+SOLVERS = {"pgs": 0, "newton": 1}                     # lcr_config.solver
+PRESETS = {"faithful": 0, "fast": 1}                  # lcr_config_preset
 PROFILE_MODES = {None: None, "wave_cycles": 2, "phase_cycles": 3}   # lcr_config.diagnostics values 2, 3 (per-wave cycle read-back; see include/lcr.h)
 COMPAT_ZERO_QVEL_ON_RESET = 1
 COMPAT_COLD_SOLVE_EACH_STEP = 2   # contact solver starts every control step from zero forces (default: forces carried across steps)
@@ -27,7 +29,7 @@ LCR_OK, LCR_ERR_INVALID, LCR_ERR_NO_DEVICE, LCR_ERR_HIP, LCR_ERR_OOM, LCR_ERR_UN
 
 # every symbol include/lcr.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
-    "lcr_abi_version", "lcr_last_error", "lcr_config_default", "lcr_action_dim", "lcr_nq", "lcr_nv",
+    "lcr_abi_version", "lcr_last_error", "lcr_config_default", "lcr_config_preset", "lcr_action_dim", "lcr_nq", "lcr_nv",
     "lcr_create", "lcr_destroy", "lcr_set_stream", "lcr_sync", "lcr_reset", "lcr_step", "lcr_step_host",
     "lcr_get_obs", "lcr_get_outputs", "lcr_fetch_host", "lcr_get_state", "lcr_set_state", "lcr_malloc", "lcr_free",
     "lcr_memcpy_h2d", "lcr_memcpy_d2h", "lcr_timer_begin", "lcr_timer_end", "lcr_fill_random_actions",
@@ -65,6 +67,12 @@ class LcrConfig(ctypes.Structure):
         ("step_kernel", ctypes.c_int32),
         ("cc_points", ctypes.c_int32),
         ("global_envs", ctypes.c_int64),   # ABI v4: envs of the whole job (0 = n_envs); the step_kernel = 0 dispatch looks at it, never at the shard size
+        ("solver", ctypes.c_int32),        # ABI v5: SOLVERS
+        ("newton_iters", ctypes.c_int32),
+        ("ls_iters", ctypes.c_int32),
+        ("finger_floor_condim", ctypes.c_int32),
+        ("newton_tol", ctypes.c_double),
+        ("ls_tol", ctypes.c_double),
     ]
 
 
@@ -159,6 +167,7 @@ def load():
     L.lcr_abi_version.restype = ctypes.c_int
     L.lcr_last_error.restype = ctypes.c_char_p
     L.lcr_config_default.argtypes = [ctypes.POINTER(LcrConfig), ctypes.c_int]
+    L.lcr_config_preset.argtypes = [ctypes.POINTER(LcrConfig), ctypes.c_int, ctypes.c_int]
     L.lcr_action_dim.argtypes = [ctypes.POINTER(LcrConfig)]
     L.lcr_nq.argtypes = [ctypes.c_int]
     L.lcr_nv.argtypes = [ctypes.c_int]

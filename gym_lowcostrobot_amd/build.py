@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcr_hip.so")
 SOURCES = ["lcr_capi.hip", "lcr_kernels.hip", "lcr_kernels2.hip", "lcr_render.hip"]   # (bench.kernel_sha16 and the tools hash / compile these)
-HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", "lcr_step_common.h", os.path.join("..", "..", "include", "lcr.h")]
+HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", "lcr_step_common.h", "lcr_newton.h", os.path.join("..", "..", "include", "lcr.h")]
 # -ffast-math: the kernels carry no NaN/inf/signed-zero semantics (the -0.0 sparse reward is built from its bit pattern,
 # the fp64 reset sampling uses explicitly rounded __dmul_rn/__dadd_rn); -fno-slp-vectorize: packed-f32 formation by the
 # SLP vectoriser costs more moves than it saves here (measured on MI355X: 0.340 ms -> 0.286 ms per 65 536-env step).
@@ -35,6 +35,7 @@ ITER_ILP = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
          ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels_loop.hip", "lcr_kernels_loop.o", []),
          ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
+         ("lcr_kernels.hip", "lcr_kernels_newton.o", ["-DLCR_PART=4"]),   # the Newton kernels of the faithful preset (one cube)
          # the two-cooperating-waves family (lcr_kernels2.hip): 10 / 14 one cube built for one / two waves per SIMD, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point
          # manifold.  Instruction-scheduling flags per unit, each measured on the MI355X against the default (tools/quick_times.py; results are bit-identical, the flags only
          # reorder instructions): no post-RA scheduler for the 256-register build (Reach 65 536 envs 0.2578 -> 0.2554 ms, Push 0.3128 -> 0.3064, PickPlace-ee 0.3106 -> 0.3068);

@@ -134,6 +134,28 @@ int lcr_config_default(lcr_config *cfg, int task) {
     cfg->step_kernel = 0;
     cfg->cc_points = 0;
     cfg->global_envs = 0;   // this handle is the whole job
+    cfg->solver = LCR_SOLVER_PGS;
+    cfg->newton_iters = 10;
+    cfg->ls_iters = 8;
+    cfg->finger_floor_condim = 0;
+    cfg->newton_tol = 1e-6;
+    cfg->ls_tol = 1e-4;
+    return LCR_OK;
+}
+
+int lcr_config_preset(lcr_config *cfg, int task, int preset) {
+    if (preset != LCR_PRESET_FAITHFUL && preset != LCR_PRESET_FAST) return fail(LCR_ERR_INVALID, "unknown preset %d", preset);
+    const int rc = lcr_config_default(cfg, task);
+    if (rc != LCR_OK) return rc;
+    if (preset == LCR_PRESET_FAITHFUL) {
+        cfg->solver = LCR_SOLVER_NEWTON;
+        cfg->finger_cube_condim = 6;
+        cfg->finger_floor_condim = 6;
+        cfg->cc_points = task == LCR_TASK_STACK ? 8 : 0;
+    } else {
+        cfg->solver = LCR_SOLVER_PGS;
+        cfg->finger_floor_condim = 4;
+    }
     return LCR_OK;
 }
 
@@ -175,6 +197,16 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->step_kernel == 2 && cfg->pgs_iters < 0) return fail(LCR_ERR_UNSUPPORTED, "the converged solver mode (pgs_iters < 0) is implemented by the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
     if (cfg->step_kernel == 2 && cfg->task == LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_UNSUPPORTED, "PushCubeLoop has the one-wave step kernel only (lcr_kernels_loop.hip); step_kernel = 2 pins the two-wave family");
     if (cfg->step_kernel == 2 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "diagnostics = 2 (per-wave cycles) reads back the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
+    if (cfg->solver != LCR_SOLVER_PGS && cfg->solver != LCR_SOLVER_NEWTON) return fail(LCR_ERR_INVALID, "solver must be LCR_SOLVER_PGS (0) or LCR_SOLVER_NEWTON (1)");
+    if (cfg->finger_floor_condim != 0 && cfg->finger_floor_condim != 4 && cfg->finger_floor_condim != 6) return fail(LCR_ERR_INVALID, "finger_floor_condim must be 4 or 6");
+    if (cfg->solver == LCR_SOLVER_NEWTON) {
+        if (cfg->newton_iters <= 0 || cfg->ls_iters <= 0 || !(cfg->newton_tol > 0) || !(cfg->ls_tol > 0)) return fail(LCR_ERR_INVALID, "newton_iters, ls_iters, newton_tol and ls_tol must be positive");
+        if (cfg->finger_cube_condim == 4 || cfg->finger_floor_condim == 4) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels carry six-row finger contacts (finger_cube_condim = finger_floor_condim = 6)");
+        if (cfg->task == LCR_TASK_STACK || cfg->task == LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels serve the one-cube tasks without rails so far");
+        if (cfg->step_kernel == 2) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels are one-wave kernels (step_kernel = 2 pins the two-wave family)");
+        if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters < 0 (converged sweeps) belongs to LCR_SOLVER_PGS");
+        if (cfg->diagnostics == 2 || cfg->diagnostics == 3) return fail(LCR_ERR_UNSUPPORTED, "the per-wave cycle read-back is implemented by the sweep kernels");
+    } else if (cfg->finger_floor_condim == 6) return fail(LCR_ERR_UNSUPPORTED, "six-row finger<->floor contacts are implemented by the Newton kernels (solver = LCR_SOLVER_NEWTON)");
     if (cfg->global_envs < 0) return fail(LCR_ERR_INVALID, "global_envs must be >= 0 (0 = n_envs)");
     if (cfg->global_envs > 0 && (cfg->env_id_offset < 0 || cfg->env_id_offset + (int64_t)cfg->n_envs > cfg->global_envs))
         return fail(LCR_ERR_INVALID, "shard [env_id_offset, env_id_offset + n_envs) = [%lld, %lld) does not lie inside the job of global_envs = %lld",
@@ -330,6 +362,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             }
             if (D.cc8) D.coop = 1;   // (74-80 KiB of LDS per workgroup: its only build is the one-wave-per-SIMD one)
             if (loop) D.coop = 0;    // PushCubeLoop: one kernel
+            D.newton = cfg->solver == LCR_SOLVER_NEWTON ? 1 : 0;
+            D.newton_iters = cfg->newton_iters; D.ls_iters = cfg->ls_iters;
+            D.newton_tol = (float)cfg->newton_tol; D.ls_tol = (float)cfg->ls_tol;
+            if (D.newton) { D.coop = 0; D.roll = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots
         }
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

@@ -67,6 +67,10 @@ struct LcrDev {
     // squared friction coefficients (round 4: the contact blocks take a projected-gradient step in the variables f_j / mu_j, lcr_step_common.h soc_step)
     float mu_c2, mu_ct2;             // cube geom: tangential, torsional
     float mu_fc2, mu_fct2, mu_fcr2;  // finger<->cube pair (max rule): tangential, torsional, rolling
+    // the faithful preset (round 5): Newton on the primal (lcr_newton.h), six-row finger contacts against cube AND floor
+    int newton;                      // 1: lcr_config.solver = LCR_SOLVER_NEWTON
+    int newton_iters, ls_iters;      // most Newton iterations per substep / most evaluations of phi' per line search
+    float newton_tol, ls_tol;
 };
 
 // pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height
@@ -80,6 +84,8 @@ struct LcrCam {
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
 // PushCubeLoop (lcr_kernels_loop.hip: one wave per 64 envs, row-wise solver)
 int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
+// the Newton kernels of the faithful preset (lcr_kernels.hip, unit LCR_PART = 4)
+int lcr_launch_step_newton(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
 // two-cooperating-waves family (lcr_kernels2.hip); occ = waves per SIMD the variant is compiled for
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);

@@ -21,6 +21,7 @@
 //                             stack_two_cubes_env.py:326-363; TimeLimit(50) from __init__.py:9-43
 //   reset                     envs/reach_cube_env.py:297-311, push:308-328, pick_place:316-336, stack:307-324
 #include "lcr_step_common.h"
+#include "lcr_newton.h"
 
 // translation-unit selection, see the launchers at the end of the file
 #ifndef LCR_PART
@@ -33,8 +34,13 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool ADAPT, bool ROLL, bool BIG>
+// NEWTON (the faithful preset): every finger contact has MuJoCo's six rows -- against the floor too (follower.xml:15 condim="6") -- and the constraint problem is solved
+// by Newton's method on the primal (lcr_newton.h) instead of sweeps on the dual
+template <bool ROLL, bool NEWTON> constexpr int arm_rows_of(int s) { return (NEWTON && s < 4) ? 6 : as_rows<ROLL>(s); }
+template <bool ROLL, int NC, bool BIG, bool NEWTON> constexpr int arm_row0_of(int s) { return NEWTON ? (s < 4 ? 6 * s : 24) : as_row0<ROLL, NC, BIG>(s); }
+template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
+    static_assert(!NEWTON || (ROLL && NC == 1 && !ADAPT), "the Newton kernels carry six-row finger slots; one cube so far");
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
@@ -135,6 +141,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
     for (int j = 0; j < 6; j++) y[j] = tau[j];
     fsub(CL, y);
+    float y0s[6];   // (NEWTON) the unconstrained arm acceleration in y coordinates: a0 of the primal problem
+#pragma unroll
+    for (int j = 0; j < 6; j++) y0s[j] = y[j];
     // cube accelerations, world frame (isotropic inertia: no gyroscopic term)
     f3 ca[NC], cal[NC];
     f3 cww[NC];  // cube angular velocity in world frame
@@ -546,7 +555,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 if (s == 4 && j >= 3 && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int r = 0; r < as_rows<ROLL>(s); r++) {
+            for (int r = 0; r < arm_rows_of<ROLL, NEWTON>(s); r++) {
                 f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));   // row 3: rotation about n (torsion)
                 if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }     // rows 4, 5: rotation about t1, t2 (rolling)
                 float g[6];
@@ -581,10 +590,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float2v gp = {g[2 * k], g[2 * k + 1]};
                     if (NC == 2 && !BIG && s == 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2]) = gp;
                     else if (NC == 2 && !BIG && r >= 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2]) = gp;
-                    else *reinterpret_cast<float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
+                    else *reinterpret_cast<float2v *>(&lds[(arm_row0_of<ROLL, NC, BIG, NEWTON>(s) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
                 }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
-                if (ROLL && r > 3) Rr = Rf * P.rr_fc;
+                if (ROLL && r > 3) Rr = Rf * (s < 2 ? P.rr_fc : RR_FF);   // (rolling rows of a finger on the floor: NEWTON only)
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
                 const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
@@ -646,8 +655,317 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     // ---- projected Gauss-Seidel on the dual, matrix-free, warm-started.  Fixed sweep count (pgs_iters > 0), or ADAPT
     //      (pgs_iters < 0): sweep until the largest force change of a sweep is <= pgs_tol (1 + largest |force|) in EVERY lane
     //      of the wave, at most 50 sweeps ----
-    const int max_it = ADAPT ? 50 : P.pgs_iters;
+    const int max_it = NEWTON ? 0 : (ADAPT ? 50 : P.pgs_iters);
     int sweeps_done = 0;
+    if constexpr (NEWTON) {
+        // ---- Newton on the primal (lcr_newton.h; oracle: newton_product).  x = (y, cube linear acceleration, cube angular acceleration): the set-up above has
+        //      already put the carried forces' accelerations into y / ca / cal -- x0 = a0 + M^-1 J'f, MuJoCo's qacc_warmstart.
+        //      The row residuals zs = J x - aref live in registers and follow x (zs += al jd, jd = J dx): a line-search evaluation touches no LDS row. ----
+        constexpr int NX = 12, NH = NX * (NX + 1) / 2;
+        constexpr int Z_LIM = 0, Z_ARM = 6, Z_FLOOR = 34, NZ = 50;   // rows: joint limits 0-5, arm slots 6 + 6 s (slot 4: 30-33), floor slots 34 + 4 s
+        const float cm = P.cube_mass, ci = rcp(iinv);
+        const bool wave_cube4 = __any(AS[4].act && link_on_cube) != 0;
+        bool floor_any = false;
+#pragma unroll
+        for (int s = 0; s < 4; s++) floor_any = floor_any || FS[0][s].act;
+        floor_any = __any(floor_any) != 0;
+        float x[NX];
+#pragma unroll
+        for (int j = 0; j < 6; j++) x[j] = y[j];
+        x[6] = ca[0].x; x[7] = ca[0].y; x[8] = ca[0].z; x[9] = cal[0].x; x[10] = cal[0].y; x[11] = cal[0].z;
+        float scale = fmaf(cm * GRAV, GRAV, 1.f);
+#pragma unroll
+        for (int j = 0; j < 6; j++) scale = fmaf(y0s[j], y0s[j], scale);
+        // joint-limit rows: regulariser and reference acceleration once per substep
+        float lim_aref[6], lim_iR[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { lim_aref[j] = 0.f; lim_iR[j] = 0.f; }
+        if (wave_lim) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                if (!((lim_wave >> j) & 1u)) continue;
+                const bool lower = S.q[j] < JLO[j];
+                const float pos = lower ? S.q[j] - JLO[j] : JHI[j] - S.q[j];
+                const float imp = impedance(pos, D0_DEF, DW_DEF, 1.0f / W_DEF);
+                lim_iR[j] = lim_act[j] ? rcp(fmaxf((1.f - imp) * rcp(imp) * INVW_DOF[j], 1e-15f)) : 0.f;
+                lim_aref[j] = -B_DEF * (lower ? 1.f : -1.f) * S.qd[j] - K_DEF * imp * pos;
+            }
+        }
+        float zs[NZ], jd[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; i++) { zs[i] = 0.f; jd[i] = 0.f; }
+        // squared friction coefficients and the friction regulariser of a contact (finger geoms: 1.5 / 0.005 / 1e-4; a finger on a cube: max rule; a link proxy: floor 1
+        // and no torsion row -- condim 3 --, on a cube the cube's coefficients)
+        auto arm_m2 = [&](auto s_tag, float (&m2)[6]) {
+            constexpr int s = decltype(s_tag)::value;
+            const bool oncube = s < 2 || (s == 4 && link_on_cube);
+            m2[0] = 1.f;
+            m2[1] = m2[2] = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
+            m2[3] = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : (oncube ? P.mu_ct2 : 0.f));
+            m2[4] = m2[5] = s < 2 ? P.mu_fcr2 : (s < 4 ? MU_ROLL * MU_ROLL : 0.f);
+        };
+        // the dense row r of arm slot s in x space: g row from LDS, the cube's share in closed form
+        auto arm_row = [&](auto s_tag, int r, bool cube_part, float (&row)[NX]) {
+            constexpr int s = decltype(s_tag)::value;
+            const ArmSlot<NRW> &T = AS[s];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float2v gp = *reinterpret_cast<const float2v *>(&lds[(arm_row0_of<ROLL, NC, BIG, NEWTON>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
+                row[2 * k] = gp.x; row[2 * k + 1] = gp.y;
+            }
+            f3 lin = mk(0.f, 0.f, 0.f), ang = mk(0.f, 0.f, 0.f);
+            if (cube_part) {   // the cube's contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
+                const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : (r == 3 ? T.n : (r == 4 ? T.t1 : T.t2))));
+                const float on = (s < 2 || link_on_cube) ? -1.f : 0.f;
+                if (r < 3) { lin = on * d; ang = on * cross(T.rc, d); }
+                else ang = on * d;
+            }
+            row[6] = lin.x; row[7] = lin.y; row[8] = lin.z; row[9] = ang.x; row[10] = ang.y; row[11] = ang.z;
+        };
+        // out[row] = J_row . v (- aref with SUB): the residuals at the start (v = x) and the directional derivatives of a Newton step (v = dx)
+        auto dots = [&](auto sub_tag, const float (&v)[NX], float (&out)[NZ]) {
+            constexpr bool SUB = decltype(sub_tag)::value;
+            if (wave_lim) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    if (!((lim_wave >> j) & 1u)) continue;
+                    float g6[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) g6[k] = k == j ? (S.q[j] < JLO[j] ? 1.f : -1.f) : 0.f;
+                    fsub(CL, g6);
+                    float a = SUB ? -lim_aref[j] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) a = fmaf(g6[k], v[k], a);
+                    out[Z_LIM + j] = a;
+                }
+            }
+            auto arm = [&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                if (!slot_any[s]) return;
+                constexpr int NR = s < 4 ? 6 : 4;
+                const bool cube_part = s < 2 || (s == 4 && wave_cube4);
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    float row[NX];
+                    arm_row(s_tag, r, cube_part, row);
+                    float a = SUB ? -AS[s].aref[r] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NX; i++) { if (i < 6 || cube_part) a = fmaf(row[i], v[i], a); }
+                    out[Z_ARM + 6 * s + r] = a;
+                }
+            };
+            arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+            arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+            if (floor_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {   // rows [d ; r x d] with d = (z, y, -x), torsion row [0 ; z]
+                    const FloorSlot &T = FS[0][s];
+                    const f3 r = T.r;
+                    out[Z_FLOOR + 4 * s + 0] = v[8] + r.y * v[9] - r.x * v[10] - (SUB ? T.aref[0] : 0.f);
+                    out[Z_FLOOR + 4 * s + 1] = v[7] - r.z * v[9] + r.x * v[11] - (SUB ? T.aref[1] : 0.f);
+                    out[Z_FLOOR + 4 * s + 2] = -v[6] - r.z * v[10] + r.y * v[11] - (SUB ? T.aref[2] : 0.f);
+                    out[Z_FLOOR + 4 * s + 3] = v[11] - (SUB ? T.aref[3] : 0.f);
+                }
+            }
+        };
+        // sum over the constraints of f(zs + al jd) . jd: the constraint part of phi'(al) -- registers only
+        auto ls_eval = [&](float al) -> float {
+            float acc = 0.f;
+            if (wave_lim) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    if (!((lim_wave >> j) & 1u)) continue;
+                    const float z = fmaf(al, jd[Z_LIM + j], zs[Z_LIM + j]);
+                    acc = fmaf(z < 0.f ? -z * lim_iR[j] : 0.f, jd[Z_LIM + j], acc);
+                }
+            }
+            auto arm = [&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                if (!slot_any[s]) return;
+                constexpr int NR = s < 4 ? 6 : 4;
+                float m2a[6], m2[NR], z[NR];
+                arm_m2(s_tag, m2a);
+#pragma unroll
+                for (int r = 0; r < NR; r++) { m2[r] = m2a[r]; z[r] = fmaf(al, jd[Z_ARM + 6 * s + r], zs[Z_ARM + 6 * s + r]); }
+                BlkEval<NR> B;
+                blk_eval<NR>(z, AS[s].Rn, AS[s].Rn * P.inv_impratio * m2[1], m2, AS[s].act, B);
+#pragma unroll
+                for (int r = 0; r < NR; r++) acc = fmaf(B.f[r], jd[Z_ARM + 6 * s + r], acc);
+            };
+            arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+            arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+            if (floor_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const FloorSlot &T = FS[0][s];
+                    const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
+                    float z[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) z[q] = fmaf(al, jd[Z_FLOOR + 4 * s + q], zs[Z_FLOOR + 4 * s + q]);
+                    BlkEval<4> B;
+                    blk_eval<4>(z, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, m2, T.act, B);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc = fmaf(B.f[q], jd[Z_FLOOR + 4 * s + q], acc);
+                }
+            }
+            return acc;
+        };
+        // gradient and Hessian of F at x (residuals zs) -- or, with OUT, the forces at x into the slot records
+        auto assemble = [&](auto out_tag, float (&g)[NX], float (&Hm)[NH]) {
+            constexpr bool OUT = decltype(out_tag)::value;
+            if (!OUT) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) g[i] = x[i] - y0s[i];
+                g[6] = cm * x[6]; g[7] = cm * x[7]; g[8] = cm * (x[8] + GRAV); g[9] = ci * x[9]; g[10] = ci * x[10]; g[11] = ci * x[11];
+#pragma unroll
+                for (int i = 0; i < NH; i++) Hm[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NX; i++) Hm[tri(i, i)] = i < 6 ? 1.f : (i < 9 ? cm : ci);
+            }
+            if (wave_lim) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    if (!((lim_wave >> j) & 1u)) continue;
+                    const float z = zs[Z_LIM + j];
+                    const float wl = z < 0.f ? lim_iR[j] : 0.f, f = -z * wl;
+                    if (OUT) { flim[j] = f; continue; }
+                    float gl[NX];
+#pragma unroll
+                    for (int k = 0; k < NX; k++) gl[k] = 0.f;
+                    float g6[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) g6[k] = k == j ? (S.q[j] < JLO[j] ? 1.f : -1.f) : 0.f;
+                    fsub(CL, g6);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { gl[k] = g6[k]; g[k] = fmaf(-f, g6[k], g[k]); }
+                    h_rank1<0, 6, NX>(Hm, gl, wl);
+                }
+            }
+            auto arm = [&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                if (!slot_any[s]) return;
+                constexpr int NR = s < 4 ? 6 : 4;
+                ArmSlot<NRW> &T = AS[s];
+                const bool cube_part = s < 2 || (s == 4 && wave_cube4);
+                float m2a[6], m2[NR], z[NR];
+                arm_m2(s_tag, m2a);
+#pragma unroll
+                for (int r = 0; r < NR; r++) { m2[r] = m2a[r]; z[r] = zs[Z_ARM + 6 * s + r]; }
+                BlkEval<NR> B;
+                blk_eval<NR>(z, T.Rn, T.Rn * P.inv_impratio * m2[1], m2, T.act, B);
+                if (OUT) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) T.f[r] = B.f[r];
+                    return;
+                }
+                float row[NR][NX];
+#pragma unroll
+                for (int r = 0; r < NR; r++) arm_row(s_tag, r, cube_part, row[r]);
+#pragma unroll
+                for (int i = 0; i < NX; i++) {
+                    if (i >= 6 && !cube_part) continue;
+                    float a = g[i];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) a = fmaf(-B.f[r], row[r][i], a);
+                    g[i] = a;
+                }
+                if (cube_part) h_block<0, NX, NX, NR>(Hm, row, B, m2);
+                else h_block<0, 6, NX, NR>(Hm, row, B, m2);
+            };
+            arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+            arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+            if (floor_any || OUT) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    FloorSlot &T = FS[0][s];
+                    const f3 r = T.r;
+                    const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
+                    float z[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) z[q] = zs[Z_FLOOR + 4 * s + q];
+                    BlkEval<4> B;
+                    blk_eval<4>(z, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, m2, T.act && floor_any, B);
+                    if (OUT) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) T.f[q] = B.f[q];
+                        continue;
+                    }
+                    float row[4][NX];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int i = 0; i < NX; i++) row[q][i] = 0.f;
+                    row[0][8] = 1.f; row[0][9] = r.y; row[0][10] = -r.x;
+                    row[1][7] = 1.f; row[1][9] = -r.z; row[1][11] = r.x;
+                    row[2][6] = -1.f; row[2][10] = -r.z; row[2][11] = r.y;
+                    row[3][11] = 1.f;
+#pragma unroll
+                    for (int i = 6; i < NX; i++) {
+                        float a = g[i];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) a = fmaf(-B.f[q], row[q][i], a);
+                        g[i] = a;
+                    }
+                    h_block<6, NX, NX, 4>(Hm, row, B, m2);
+                }
+            }
+        };
+        dots(std::true_type{}, x, zs);
+        const float tol2 = P.newton_tol * P.newton_tol * scale;
+        int it = 0;
+        for (; it < P.newton_iters; it++) {
+            float dx[NX], d0 = 0.f;
+            {
+                float Hm[NH], g[NX], hid[NX];
+                assemble(std::false_type{}, g, Hm);
+                chol_packed<NX>(Hm, hid);
+#pragma unroll
+                for (int i = 0; i < NX; i++) dx[i] = -g[i];
+                solve_packed<NX>(Hm, hid, dx);
+#pragma unroll
+                for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
+            }
+            const bool live = -d0 > tol2;   // Newton decrement above the tolerance: this lane still moves
+            if (!__any(live)) break;
+            dots(std::false_type{}, dx, jd);
+            // line search on phi'(al) = q0 + al q1 - sum f(zs + al jd) . jd: first the full step (exact while no contact changes zone), bracket by doubling, then the
+            // Illinois variant of regula falsi
+            float q1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NX; i++) q1 = fmaf((i < 6 ? 1.f : (i < 9 ? cm : ci)) * dx[i], dx[i], q1);
+            const float q0 = d0 + ls_eval(0.f);
+            float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f;
+            bool done = !live;
+            for (int ls = 0; ls < P.ls_iters; ls++) {
+                const float dphi = fmaf(al, q1, q0) - ls_eval(al);
+                if (!done) {
+                    const bool fin = fabsf(dphi) <= P.ls_tol * fabsf(d0);
+                    if (dphi < 0.f) { if (hi_a >= 0.f && lo_a > 0.f) dhi *= 0.5f; lo_a = al; dlo = dphi; }
+                    else { if (hi_a >= 0.f) dlo *= 0.5f; hi_a = al; dhi = dphi; }
+                    float an;
+                    if (hi_a < 0.f) an = 2.f * al;
+                    else { an = lo_a - dlo * (hi_a - lo_a) * rcp(dhi - dlo); if (!(an > lo_a && an < hi_a)) an = 0.5f * (lo_a + hi_a); }
+                    al = fin ? al : an;
+                    done = fin;
+                }
+                if (__all(done)) break;
+            }
+            const float step = live ? al : 0.f;
+#pragma unroll
+            for (int i = 0; i < NX; i++) x[i] = fmaf(step, dx[i], x[i]);
+#pragma unroll
+            for (int i = 0; i < NZ; i++) zs[i] = fmaf(step, jd[i], zs[i]);
+        }
+        sweeps_done = it;
+        {   // the forces at the solution: carried to the next substep / control step
+            float Hd[NH], gd[NX];
+            assemble(std::true_type{}, gd, Hd);
+        }
+        // the integration below uses the accelerations themselves (M (x - a0) = J'f at the optimum)
+#pragma unroll
+        for (int j = 0; j < 6; j++) y[j] = x[j];
+        ca[0] = mk(x[6], x[7], x[8]); cal[0] = mk(x[9], x[10], x[11]);
+    }
     for (int it = 0; it < max_it; it++) {
         float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep
         auto track = [&](float d0, float d1, float d2, float d3, float f0, float f1, float f2, float f3_) {
@@ -980,9 +1298,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG>
+template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[LdsSize<NC, false, ROLL, BIG>::value];
+    __shared__ float lds[NEWTON ? 28 * LDS_ROW : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave)
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -1100,7 +1418,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         }
     }
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, ADAPT, ROLL, BIG>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
@@ -1329,6 +1647,17 @@ int lcr_launch_step_stack_big(const LcrDev &P, const float *action_dev, int ee_m
 }
 #endif
 
+#if LCR_HAS_PART(4)
+// the faithful preset (lcr_config.solver = LCR_SOLVER_NEWTON): six-row finger contacts everywhere, Newton on the primal
+int lcr_launch_step_newton(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
+    const int blocks = (P.n + 63) / 64;
+    const hipStream_t st = (hipStream_t)stream;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<1, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    return check_launch();
+}
+#endif
+
 #if LCR_HAS_PART(0)
 template <bool ADAPT, bool ROLL>
 static void launch_one_cube_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
@@ -1339,6 +1668,7 @@ static void launch_one_cube_t(const LcrDev &P, const float *action_dev, int ee_m
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
     const hipStream_t st = (hipStream_t)stream;
     if (P.walls) return lcr_launch_step_loop(P, action_dev, ee_mode, stream);   // PushCubeLoop: its own unit and solver (lcr_kernels_loop.hip)
+    if (P.newton && P.task != 4) return lcr_launch_step_newton(P, action_dev, ee_mode, stream);
     if (P.coop && P.pgs_iters >= 0 && P.diag != 2) {   // two cooperating waves per 64 envs (no converged mode, no per-wave cycle read-back)
         if (P.task == 4) return P.cc8 ? lcr_launch_step2_stack_cc8(P, action_dev, ee_mode, P.coop, stream) : lcr_launch_step2_stack(P, action_dev, ee_mode, P.coop, stream);
         return lcr_launch_step2_one_cube(P, action_dev, ee_mode, P.coop, stream);

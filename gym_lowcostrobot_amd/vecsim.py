@@ -64,7 +64,7 @@ class VecSim:
         n_substeps=20,
         max_episode_steps=50,
         impratio=100.0,
-        pgs_iters=4,
+        pgs_iters=None,
         compat=0,
         auto_reset=True,
         base_seed=0,
@@ -76,6 +76,13 @@ class VecSim:
         cc_points=None,
         global_envs=None,
         profile=None,
+        preset=None,
+        solver=None,
+        newton_iters=None,
+        ls_iters=None,
+        newton_tol=None,
+        ls_tol=None,
+        finger_floor_condim=None,
     ):
         self.L = _capi.load()
         if action_mode not in ACTION_MODES:
@@ -86,7 +93,13 @@ class VecSim:
             raise ValueError(f"invalid reward_type {reward_type!r}")
         self.task_name = task if isinstance(task, str) else {v: k for k, v in TASKS.items()}[task]
         cfg = LcrConfig()
-        check(self.L.lcr_config_default(ctypes.byref(cfg), TASKS[self.task_name]))
+        # preset: "faithful" (the reference's contact model solved by Newton's method) | "fast" (rounds 1-4: four sweeps, fewer rows); None = the library's default
+        if preset is None:
+            check(self.L.lcr_config_default(ctypes.byref(cfg), TASKS[self.task_name]))
+        else:
+            if preset not in _capi.PRESETS:
+                raise ValueError(f"invalid preset {preset!r} (faithful | fast)")
+            check(self.L.lcr_config_preset(ctypes.byref(cfg), TASKS[self.task_name], _capi.PRESETS[preset]))
         cfg.n_envs = int(n_envs)
         cfg.device = int(device)
         cfg.env_id_offset = int(env_id_offset)
@@ -102,7 +115,18 @@ class VecSim:
         cfg.impratio = impratio
         cfg.n_substeps = int(n_substeps)
         cfg.max_episode_steps = int(max_episode_steps)
-        cfg.pgs_iters = int(pgs_iters)
+        if pgs_iters is not None:
+            cfg.pgs_iters = int(pgs_iters)
+        if solver is not None:
+            if solver not in _capi.SOLVERS:
+                raise ValueError(f"invalid solver {solver!r} (pgs | newton)")
+            cfg.solver = _capi.SOLVERS[solver]
+        for name, val in (("newton_iters", newton_iters), ("ls_iters", ls_iters), ("finger_floor_condim", finger_floor_condim)):
+            if val is not None:
+                setattr(cfg, name, int(val))
+        for name, val in (("newton_tol", newton_tol), ("ls_tol", ls_tol)):
+            if val is not None:
+                setattr(cfg, name, float(val))
         cfg.compat = int(compat)
         cfg.auto_reset = int(bool(auto_reset))
         cfg.base_seed = int(base_seed)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LCR_ABI_VERSION 4
+#define LCR_ABI_VERSION 5
 
 typedef enum lcr_status {
     LCR_OK = 0,
@@ -117,7 +117,25 @@ typedef struct lcr_config {
                                   the job).  Must be >= env_id_offset + n_envs.  Only the step_kernel = 0 dispatch reads it (see there): the reference
                                   has one independent MjData per env (reach_cube_env.py:89-90), so how a batch is cut into shards must not show in
                                   the results */
+    /* ABI v5 (round 5): the solver of the constraint problem and the rows of a finger<->floor contact.  See lcr_config_preset. */
+    int32_t solver;            /* lcr_solver.  LCR_SOLVER_NEWTON: Newton's method on the primal problem, all accelerations at once, warm-started from the carried
+                                  constraint forces -- MuJoCo's default solver (follower.xml:3 names none); reaches the optimum of MuJoCo's convex constraint problem to
+                                  float rounding (tools/kkt_distance.py).  LCR_SOLVER_PGS: pgs_iters warm-started sweeps of a block projected-gradient step on the dual
+                                  problem (rounds 1-4; p90 2e-4 / p99 1e-2 rad per control step away from that optimum at four sweeps). */
+    int32_t newton_iters;      /* LCR_SOLVER_NEWTON: most iterations per substep (10); a wave leaves the loop when every one of its envs has converged */
+    int32_t ls_iters;          /* ... most evaluations of phi' per line search (8) */
+    int32_t finger_floor_condim; /* rows of a finger<->floor contact: 6 = MuJoCo's (follower.xml:15 condim="6": + two rolling rows, coefficient 1e-4 m), 4 = without
+                                  them.  0 = the preset's default.  6 is implemented by the Newton kernels (LCR_SOLVER_PGS with 6: LCR_ERR_UNSUPPORTED) */
+    double newton_tol;         /* LCR_SOLVER_NEWTON: an env has converged when its Newton decrement -g'dx <= newton_tol^2 (1 + |a0|_M^2)   (1e-6) */
+    double ls_tol;             /* ... its line search stops when |phi'(al)| <= ls_tol |phi'(0)|   (1e-4) */
 } lcr_config;
+
+typedef enum lcr_solver { LCR_SOLVER_PGS = 0, LCR_SOLVER_NEWTON = 1 } lcr_solver;
+/* LCR_PRESET_FAITHFUL (what lcr_config_default fills in): the reference's contact model as its MJCF states it -- six-row finger contacts against cube AND floor
+ * (follower.xml:15), up to eight box-box points (stack_two_cubes.xml:25-35), elliptic cones -- solved by Newton's method (follower.xml:3).
+ * LCR_PRESET_FAST: the rounds 1-4 configuration -- four block projected-gradient sweeps, rolling rows only where they change a step by more than the fp32
+ * parity tolerance, four box-box points -- about 4 x the throughput at p90 2e-4 / p99 1e-2 rad per control step from the optimum. */
+typedef enum lcr_preset { LCR_PRESET_FAITHFUL = 0, LCR_PRESET_FAST = 1 } lcr_preset;
 
 typedef struct lcr_sim lcr_sim;
 
@@ -178,6 +196,8 @@ const char *lcr_last_error(void);
 
 /* Fill `cfg` with the reference constructor defaults for `task`. */
 int lcr_config_default(lcr_config *cfg, int task);
+/* The reference constructor defaults for `task` with the solver / contact-row settings of `preset` (lcr_preset). */
+int lcr_config_preset(lcr_config *cfg, int task, int preset);
 /* Number of action components k for a config: {joint:5, ee:3} + (0 if block_gripper else 1)  (reach_cube_env.py:95-96) */
 int lcr_action_dim(const lcr_config *cfg);
 int lcr_nq(int task); /* 13, stack 20 */

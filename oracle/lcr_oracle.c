@@ -1264,6 +1264,11 @@ static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, 
         for (int r = 1; r < dm; r++) f[i + r] = y[r] * (real)mu[r - 1];
     }
 }
+/* study aid (tools/newton_cost_study.py): per (env, substep) Newton iterations and line-search evaluations of newton_product, [n][substeps][2] int32 */
+static int32_t *g_newton_trace = NULL;
+static int g_newton_trace_sub = 0;
+void orc_set_newton_trace(int32_t *buf, int substeps) { g_newton_trace = buf; g_newton_trace_sub = substeps; }
+static __thread int32_t *t_trace_slot = NULL;
 static int newton_product(int nv, int nr, const real *M, const real *Lm, const real *J, const real *aref, const real *Rr, const real *a0, const int *kind,
                           const int *blkdim, const double *const *rowmu, real *f, real *x_out, int iters, int ls_iters, double tol, double ls_tol) {
     real x[ORC_NV_MAX], xa[ORC_NV_MAX], g[ORC_NV_MAX], H[ORC_NV_MAX * ORC_NV_MAX], dx[ORC_NV_MAX], tmp[ORC_NV_MAX];
@@ -1314,6 +1319,7 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
             const int done = fabs((double)dphi) <= ls_tol * fabs((double)d0);
             if (dphi < 0) { if (hi_a >= 0 && lo_a > 0) dhi *= (real)0.5; lo_a = al; dlo = dphi; }
             else { if (hi_a >= 0) dlo *= (real)0.5; hi_a = al; dhi = dphi; }
+            if (t_trace_slot) t_trace_slot[1]++;
             if (done) break;
             real an;
             if (hi_a < 0) an = 2 * al;
@@ -1321,6 +1327,7 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
             al = an;
         }
         for (int d = 0; d < nv; d++) x[d] += al * dx[d];
+        if (t_trace_slot) t_trace_slot[0]++;
     }
     NP_GRAD(x, NULL);
 #undef NP_GRAD
@@ -1955,7 +1962,11 @@ static void step_one(const orc_params *P, const task_model *T, orc_io *io, size_
      * after reset), as MuJoCo carries mjData.qacc_warmstart across mj_step calls and the reference never resets it between env.step calls.
      * ORC_COMPAT_COLD_SOLVE_EACH_STEP (or io->warm == NULL): every control step starts from zero forces instead. */
     if (io->warm && !(P->compat & ORC_COMPAT_COLD_SOLVE_EACH_STEP)) warmp = (warm_t *)((char *)io->warm + e * sizeof(warm_t));
-    for (int s = 0; s < P->n_substeps; s++) substep(P, T, qpos, qvel, ctrl, &lag, warmp, e == 0 && s == P->n_substeps - 1, s);
+    for (int s = 0; s < P->n_substeps; s++) {
+        t_trace_slot = (g_newton_trace && s < g_newton_trace_sub) ? g_newton_trace + ((size_t)e * g_newton_trace_sub + s) * 2 : NULL;
+        substep(P, T, qpos, qvel, ctrl, &lag, warmp, e == 0 && s == P->n_substeps - 1, s);
+    }
+    t_trace_slot = NULL;
     for (int i = 0; i < nq; i++) qpos64[i] = (double)qpos[i];
     for (int i = 0; i < nv; i++) qvel64[i] = (double)qvel[i];
     for (int i = 0; i < 3; i++) ee_lag[i] = (double)lag.ee[i];

@@ -112,12 +112,15 @@ def _p(a):
 class Oracle:
     """n independent envs stepped on the CPU, AoS arrays (env-major)."""
 
-    def __init__(self, task, n, f32=False, kkt=False, **kw):
+    def __init__(self, task, n, f32=False, kkt=False, preset=None, **kw):
         self.L = lib(f32)
         self.task = TASKS[task] if isinstance(task, str) else int(task)
         self.n = n
         self.params = OrcParams()
-        self.L.orc_default_params(ctypes.byref(self.params), self.task)
+        if preset is None:
+            self.L.orc_default_params(ctypes.byref(self.params), self.task)
+        else:   # "faithful": six-row finger contacts everywhere, eight-point box-box, Newton on the primal; "fast": rounds 1-4
+            self.L.orc_preset_params(ctypes.byref(self.params), self.task, {"faithful": 0, "fast": 1}[preset])
         for k, v in kw.items():
             if not hasattr(self.params, k):
                 raise AttributeError(k)

@@ -93,7 +93,14 @@ def make_pair(task, n, **kw):
             okw[k] = int(v) if isinstance(v, bool) else v
     if kw.get("finger_cube_condim") is not None:
         okw["condim6"] = 1 if kw["finger_cube_condim"] == 6 else 0   # rolling rows on the finger<->cube contacts (default: by task, both sides)
-    o = orc.Oracle(task, n, **okw)
+    if kw.get("finger_floor_condim") == 6:
+        okw["condim6"] = 2                                             # ... and on the finger<->floor contacts (the Newton kernels)
+    if kw.get("solver") is not None:
+        okw["solver"] = {"pgs": 0, "newton": 2}[kw["solver"]]
+    for k in ("newton_iters", "ls_iters", "newton_tol", "ls_tol"):
+        if k in kw:
+            okw[k] = kw[k]
+    o = orc.Oracle(task, n, preset=kw.get("preset"), **okw)
     kw.setdefault("diagnostics", True)
     sim = VecSim(task, n, observation_mode="state", **kw)
     assert sim.action_dim == o.action_dim

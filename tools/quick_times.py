@@ -15,13 +15,14 @@ ap.add_argument("names", nargs="*", default=list(W))
 ap.add_argument("--n", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--arm-collision", type=int, default=1)
-ap.add_argument("--pgs-iters", type=int, default=4)
+ap.add_argument("--pgs-iters", type=int, default=None)
+ap.add_argument("--preset", default=None)
 ap.add_argument("--finger-cube-condim", type=int, default=None)
 ap.add_argument("--cc-points", type=int, default=None)
 a = ap.parse_args()
 for name in a.names:
     task, mode = W[name]
-    sim = VecSim(task, a.n, action_mode=mode, arm_collision=a.arm_collision, pgs_iters=a.pgs_iters, finger_cube_condim=a.finger_cube_condim, cc_points=a.cc_points)
+    sim = VecSim(task, a.n, action_mode=mode, arm_collision=a.arm_collision, pgs_iters=a.pgs_iters, finger_cube_condim=a.finger_cube_condim, cc_points=a.cc_points, preset=a.preset)
     bufs = [sim.alloc_actions() for _ in range(32)]
     for i, b in enumerate(bufs):
         sim.fill_random_actions(b, 0, i)
@@ -35,5 +36,5 @@ for name in a.names:
         ms.append(sim.timer_end() / a.steps)
     st = sim.get_state()
     ok = bool(np.isfinite(st["qpos"]).all())
-    print(f"{name:14s} n={a.n} arm_collision={a.arm_collision} pgs={a.pgs_iters} condim={a.finger_cube_condim} cc_points={a.cc_points}: {np.median(ms):.4f} ms/step  ({a.n / np.median(ms) * 1e3:.3e} env-steps/s)  finite={ok}", flush=True)
+    print(f"{name:14s} n={a.n} arm_collision={a.arm_collision} preset={a.preset} pgs={a.pgs_iters} condim={a.finger_cube_condim} cc_points={a.cc_points}: {np.median(ms):.4f} ms/step  ({a.n / np.median(ms) * 1e3:.3e} env-steps/s)  finite={ok}", flush=True)
     sim.close()
