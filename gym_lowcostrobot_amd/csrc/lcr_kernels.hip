@@ -658,313 +658,22 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     const int max_it = NEWTON ? 0 : (ADAPT ? 50 : P.pgs_iters);
     int sweeps_done = 0;
     if constexpr (NEWTON) {
-        // ---- Newton on the primal (lcr_newton.h; oracle: newton_product).  x = (y, cube linear acceleration, cube angular acceleration): the set-up above has
-        //      already put the carried forces' accelerations into y / ca / cal -- x0 = a0 + M^-1 J'f, MuJoCo's qacc_warmstart.
-        //      The row residuals zs = J x - aref live in registers and follow x (zs += al jd, jd = J dx): a line-search evaluation touches no LDS row. ----
-        constexpr int NX = 12, NH = NX * (NX + 1) / 2;
-        constexpr int Z_LIM = 0, Z_ARM = 6, Z_FLOOR = 34, NZ = 50;   // rows: joint limits 0-5, arm slots 6 + 6 s (slot 4: 30-33), floor slots 34 + 4 s
-        const float cm = P.cube_mass, ci = rcp(iinv);
-        const bool wave_cube4 = __any(AS[4].act && link_on_cube) != 0;
-        bool floor_any = false;
-#pragma unroll
-        for (int s = 0; s < 4; s++) floor_any = floor_any || FS[0][s].act;
-        floor_any = __any(floor_any) != 0;
-        float x[NX];
-#pragma unroll
-        for (int j = 0; j < 6; j++) x[j] = y[j];
-        x[6] = ca[0].x; x[7] = ca[0].y; x[8] = ca[0].z; x[9] = cal[0].x; x[10] = cal[0].y; x[11] = cal[0].z;
-        float scale = fmaf(cm * GRAV, GRAV, 1.f);
-#pragma unroll
-        for (int j = 0; j < 6; j++) scale = fmaf(y0s[j], y0s[j], scale);
-        // joint-limit rows: regulariser and reference acceleration once per substep
-        float lim_aref[6], lim_iR[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) { lim_aref[j] = 0.f; lim_iR[j] = 0.f; }
-        if (wave_lim) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                if (!((lim_wave >> j) & 1u)) continue;
-                const bool lower = S.q[j] < JLO[j];
-                const float pos = lower ? S.q[j] - JLO[j] : JHI[j] - S.q[j];
-                const float imp = impedance(pos, D0_DEF, DW_DEF, 1.0f / W_DEF);
-                lim_iR[j] = lim_act[j] ? rcp(fmaxf((1.f - imp) * rcp(imp) * INVW_DOF[j], 1e-15f)) : 0.f;
-                lim_aref[j] = -B_DEF * (lower ? 1.f : -1.f) * S.qd[j] - K_DEF * imp * pos;
-            }
+        // ---- Newton on the primal (lcr_newton.h; oracle: newton_product).  The set-up above has already put the carried forces' accelerations into y / ca / cal:
+        //      x0 = a0 + M^-1 J'f, MuJoCo's qacc_warmstart.  The bodies are solved per connected component of the wave's coupling graph: while no lane has a finger
+        //      or a gripper-body proxy on the cube, arm and cube are independent 6-dimensional problems ----
+        const int row0[NAS] = {arm_row0_of<ROLL, NC, BIG, NEWTON>(0), arm_row0_of<ROLL, NC, BIG, NEWTON>(1), arm_row0_of<ROLL, NC, BIG, NEWTON>(2),
+                               arm_row0_of<ROLL, NC, BIG, NEWTON>(3), arm_row0_of<ROLL, NC, BIG, NEWTON>(4)};
+        FloorSlot no_walls[4];
+        const float no_wsg[2] = {1.f, 1.f};
+        NewtonCtx<NC, NRW, false, 4> C{P, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, no_walls, no_wsg, false,
+                                       ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
+        const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
+        if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, 4, 3>(C, y, ca, cal);
+        else {
+            const int ia = newton_solve<NC, NRW, false, 4, 1>(C, y, ca, cal);
+            const int ic = newton_solve<NC, NRW, false, 4, 2>(C, y, ca, cal);
+            sweeps_done = max(ia, ic);
         }
-        float zs[NZ], jd[NZ];
-#pragma unroll
-        for (int i = 0; i < NZ; i++) { zs[i] = 0.f; jd[i] = 0.f; }
-        // squared friction coefficients and the friction regulariser of a contact (finger geoms: 1.5 / 0.005 / 1e-4; a finger on a cube: max rule; a link proxy: floor 1
-        // and no torsion row -- condim 3 --, on a cube the cube's coefficients)
-        auto arm_m2 = [&](auto s_tag, float (&m2)[6]) {
-            constexpr int s = decltype(s_tag)::value;
-            const bool oncube = s < 2 || (s == 4 && link_on_cube);
-            m2[0] = 1.f;
-            m2[1] = m2[2] = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
-            m2[3] = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : (oncube ? P.mu_ct2 : 0.f));
-            m2[4] = m2[5] = s < 2 ? P.mu_fcr2 : (s < 4 ? MU_ROLL * MU_ROLL : 0.f);
-        };
-        // the dense row r of arm slot s in x space: g row from LDS, the cube's share in closed form
-        auto arm_row = [&](auto s_tag, int r, bool cube_part, float (&row)[NX]) {
-            constexpr int s = decltype(s_tag)::value;
-            const ArmSlot<NRW> &T = AS[s];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float2v gp = *reinterpret_cast<const float2v *>(&lds[(arm_row0_of<ROLL, NC, BIG, NEWTON>(s) + r) * LDS_ROW + k * 128 + lane * 2]);
-                row[2 * k] = gp.x; row[2 * k + 1] = gp.y;
-            }
-            f3 lin = mk(0.f, 0.f, 0.f), ang = mk(0.f, 0.f, 0.f);
-            if (cube_part) {   // the cube's contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
-                const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : (r == 3 ? T.n : (r == 4 ? T.t1 : T.t2))));
-                const float on = (s < 2 || link_on_cube) ? -1.f : 0.f;
-                if (r < 3) { lin = on * d; ang = on * cross(T.rc, d); }
-                else ang = on * d;
-            }
-            row[6] = lin.x; row[7] = lin.y; row[8] = lin.z; row[9] = ang.x; row[10] = ang.y; row[11] = ang.z;
-        };
-        // out[row] = J_row . v (- aref with SUB): the residuals at the start (v = x) and the directional derivatives of a Newton step (v = dx)
-        auto dots = [&](auto sub_tag, const float (&v)[NX], float (&out)[NZ]) {
-            constexpr bool SUB = decltype(sub_tag)::value;
-            if (wave_lim) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    if (!((lim_wave >> j) & 1u)) continue;
-                    float g6[6];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) g6[k] = k == j ? (S.q[j] < JLO[j] ? 1.f : -1.f) : 0.f;
-                    fsub(CL, g6);
-                    float a = SUB ? -lim_aref[j] : 0.f;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) a = fmaf(g6[k], v[k], a);
-                    out[Z_LIM + j] = a;
-                }
-            }
-            auto arm = [&](auto s_tag) {
-                constexpr int s = decltype(s_tag)::value;
-                if (!slot_any[s]) return;
-                constexpr int NR = s < 4 ? 6 : 4;
-                const bool cube_part = s < 2 || (s == 4 && wave_cube4);
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    float row[NX];
-                    arm_row(s_tag, r, cube_part, row);
-                    float a = SUB ? -AS[s].aref[r] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < NX; i++) { if (i < 6 || cube_part) a = fmaf(row[i], v[i], a); }
-                    out[Z_ARM + 6 * s + r] = a;
-                }
-            };
-            arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
-            arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
-            if (floor_any) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) {   // rows [d ; r x d] with d = (z, y, -x), torsion row [0 ; z]
-                    const FloorSlot &T = FS[0][s];
-                    const f3 r = T.r;
-                    out[Z_FLOOR + 4 * s + 0] = v[8] + r.y * v[9] - r.x * v[10] - (SUB ? T.aref[0] : 0.f);
-                    out[Z_FLOOR + 4 * s + 1] = v[7] - r.z * v[9] + r.x * v[11] - (SUB ? T.aref[1] : 0.f);
-                    out[Z_FLOOR + 4 * s + 2] = -v[6] - r.z * v[10] + r.y * v[11] - (SUB ? T.aref[2] : 0.f);
-                    out[Z_FLOOR + 4 * s + 3] = v[11] - (SUB ? T.aref[3] : 0.f);
-                }
-            }
-        };
-        // sum over the constraints of f(zs + al jd) . jd: the constraint part of phi'(al) -- registers only
-        auto ls_eval = [&](float al) -> float {
-            float acc = 0.f;
-            if (wave_lim) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    if (!((lim_wave >> j) & 1u)) continue;
-                    const float z = fmaf(al, jd[Z_LIM + j], zs[Z_LIM + j]);
-                    acc = fmaf(z < 0.f ? -z * lim_iR[j] : 0.f, jd[Z_LIM + j], acc);
-                }
-            }
-            auto arm = [&](auto s_tag) {
-                constexpr int s = decltype(s_tag)::value;
-                if (!slot_any[s]) return;
-                constexpr int NR = s < 4 ? 6 : 4;
-                float m2a[6], m2[NR], z[NR];
-                arm_m2(s_tag, m2a);
-#pragma unroll
-                for (int r = 0; r < NR; r++) { m2[r] = m2a[r]; z[r] = fmaf(al, jd[Z_ARM + 6 * s + r], zs[Z_ARM + 6 * s + r]); }
-                BlkEval<NR> B;
-                blk_eval<NR>(z, AS[s].Rn, AS[s].Rn * P.inv_impratio * m2[1], m2, AS[s].act, B);
-#pragma unroll
-                for (int r = 0; r < NR; r++) acc = fmaf(B.f[r], jd[Z_ARM + 6 * s + r], acc);
-            };
-            arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
-            arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
-            if (floor_any) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const FloorSlot &T = FS[0][s];
-                    const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
-                    float z[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) z[q] = fmaf(al, jd[Z_FLOOR + 4 * s + q], zs[Z_FLOOR + 4 * s + q]);
-                    BlkEval<4> B;
-                    blk_eval<4>(z, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, m2, T.act, B);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) acc = fmaf(B.f[q], jd[Z_FLOOR + 4 * s + q], acc);
-                }
-            }
-            return acc;
-        };
-        // gradient and Hessian of F at x (residuals zs) -- or, with OUT, the forces at x into the slot records
-        auto assemble = [&](auto out_tag, float (&g)[NX], float (&Hm)[NH]) {
-            constexpr bool OUT = decltype(out_tag)::value;
-            if (!OUT) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) g[i] = x[i] - y0s[i];
-                g[6] = cm * x[6]; g[7] = cm * x[7]; g[8] = cm * (x[8] + GRAV); g[9] = ci * x[9]; g[10] = ci * x[10]; g[11] = ci * x[11];
-#pragma unroll
-                for (int i = 0; i < NH; i++) Hm[i] = 0.f;
-#pragma unroll
-                for (int i = 0; i < NX; i++) Hm[tri(i, i)] = i < 6 ? 1.f : (i < 9 ? cm : ci);
-            }
-            if (wave_lim) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    if (!((lim_wave >> j) & 1u)) continue;
-                    const float z = zs[Z_LIM + j];
-                    const float wl = z < 0.f ? lim_iR[j] : 0.f, f = -z * wl;
-                    if (OUT) { flim[j] = f; continue; }
-                    float gl[NX];
-#pragma unroll
-                    for (int k = 0; k < NX; k++) gl[k] = 0.f;
-                    float g6[6];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) g6[k] = k == j ? (S.q[j] < JLO[j] ? 1.f : -1.f) : 0.f;
-                    fsub(CL, g6);
-#pragma unroll
-                    for (int k = 0; k < 6; k++) { gl[k] = g6[k]; g[k] = fmaf(-f, g6[k], g[k]); }
-                    h_rank1<0, 6, NX>(Hm, gl, wl);
-                }
-            }
-            auto arm = [&](auto s_tag) {
-                constexpr int s = decltype(s_tag)::value;
-                if (!slot_any[s]) return;
-                constexpr int NR = s < 4 ? 6 : 4;
-                ArmSlot<NRW> &T = AS[s];
-                const bool cube_part = s < 2 || (s == 4 && wave_cube4);
-                float m2a[6], m2[NR], z[NR];
-                arm_m2(s_tag, m2a);
-#pragma unroll
-                for (int r = 0; r < NR; r++) { m2[r] = m2a[r]; z[r] = zs[Z_ARM + 6 * s + r]; }
-                BlkEval<NR> B;
-                blk_eval<NR>(z, T.Rn, T.Rn * P.inv_impratio * m2[1], m2, T.act, B);
-                if (OUT) {
-#pragma unroll
-                    for (int r = 0; r < NR; r++) T.f[r] = B.f[r];
-                    return;
-                }
-                float row[NR][NX];
-#pragma unroll
-                for (int r = 0; r < NR; r++) arm_row(s_tag, r, cube_part, row[r]);
-#pragma unroll
-                for (int i = 0; i < NX; i++) {
-                    if (i >= 6 && !cube_part) continue;
-                    float a = g[i];
-#pragma unroll
-                    for (int r = 0; r < NR; r++) a = fmaf(-B.f[r], row[r][i], a);
-                    g[i] = a;
-                }
-                if (cube_part) h_block<0, NX, NX, NR>(Hm, row, B, m2);
-                else h_block<0, 6, NX, NR>(Hm, row, B, m2);
-            };
-            arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
-            arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
-            if (floor_any || OUT) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    FloorSlot &T = FS[0][s];
-                    const f3 r = T.r;
-                    const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
-                    float z[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) z[q] = zs[Z_FLOOR + 4 * s + q];
-                    BlkEval<4> B;
-                    blk_eval<4>(z, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, m2, T.act && floor_any, B);
-                    if (OUT) {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) T.f[q] = B.f[q];
-                        continue;
-                    }
-                    float row[4][NX];
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-#pragma unroll
-                        for (int i = 0; i < NX; i++) row[q][i] = 0.f;
-                    row[0][8] = 1.f; row[0][9] = r.y; row[0][10] = -r.x;
-                    row[1][7] = 1.f; row[1][9] = -r.z; row[1][11] = r.x;
-                    row[2][6] = -1.f; row[2][10] = -r.z; row[2][11] = r.y;
-                    row[3][11] = 1.f;
-#pragma unroll
-                    for (int i = 6; i < NX; i++) {
-                        float a = g[i];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) a = fmaf(-B.f[q], row[q][i], a);
-                        g[i] = a;
-                    }
-                    h_block<6, NX, NX, 4>(Hm, row, B, m2);
-                }
-            }
-        };
-        dots(std::true_type{}, x, zs);
-        const float tol2 = P.newton_tol * P.newton_tol * scale;
-        int it = 0;
-        for (; it < P.newton_iters; it++) {
-            float dx[NX], d0 = 0.f;
-            {
-                float Hm[NH], g[NX], hid[NX];
-                assemble(std::false_type{}, g, Hm);
-                chol_packed<NX>(Hm, hid);
-#pragma unroll
-                for (int i = 0; i < NX; i++) dx[i] = -g[i];
-                solve_packed<NX>(Hm, hid, dx);
-#pragma unroll
-                for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
-            }
-            const bool live = -d0 > tol2;   // Newton decrement above the tolerance: this lane still moves
-            if (!__any(live)) break;
-            dots(std::false_type{}, dx, jd);
-            // line search on phi'(al) = q0 + al q1 - sum f(zs + al jd) . jd: first the full step (exact while no contact changes zone), bracket by doubling, then the
-            // Illinois variant of regula falsi
-            float q1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < NX; i++) q1 = fmaf((i < 6 ? 1.f : (i < 9 ? cm : ci)) * dx[i], dx[i], q1);
-            const float q0 = d0 + ls_eval(0.f);
-            float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f;
-            bool done = !live;
-            for (int ls = 0; ls < P.ls_iters; ls++) {
-                const float dphi = fmaf(al, q1, q0) - ls_eval(al);
-                if (!done) {
-                    const bool fin = fabsf(dphi) <= P.ls_tol * fabsf(d0);
-                    if (dphi < 0.f) { if (hi_a >= 0.f && lo_a > 0.f) dhi *= 0.5f; lo_a = al; dlo = dphi; }
-                    else { if (hi_a >= 0.f) dlo *= 0.5f; hi_a = al; dhi = dphi; }
-                    float an;
-                    if (hi_a < 0.f) an = 2.f * al;
-                    else { an = lo_a - dlo * (hi_a - lo_a) * rcp(dhi - dlo); if (!(an > lo_a && an < hi_a)) an = 0.5f * (lo_a + hi_a); }
-                    al = fin ? al : an;
-                    done = fin;
-                }
-                if (__all(done)) break;
-            }
-            const float step = live ? al : 0.f;
-#pragma unroll
-            for (int i = 0; i < NX; i++) x[i] = fmaf(step, dx[i], x[i]);
-#pragma unroll
-            for (int i = 0; i < NZ; i++) zs[i] = fmaf(step, jd[i], zs[i]);
-        }
-        sweeps_done = it;
-        {   // the forces at the solution: carried to the next substep / control step
-            float Hd[NH], gd[NX];
-            assemble(std::true_type{}, gd, Hd);
-        }
-        // the integration below uses the accelerations themselves (M (x - a0) = J'f at the optimum)
-#pragma unroll
-        for (int j = 0; j < 6; j++) y[j] = x[j];
-        ca[0] = mk(x[6], x[7], x[8]); cal[0] = mk(x[9], x[10], x[11]);
     }
     for (int it = 0; it < max_it; it++) {
         float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep

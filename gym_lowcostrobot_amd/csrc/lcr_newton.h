@@ -124,4 +124,503 @@ DEV void solve_packed(const float (&H)[NX * (NX + 1) / 2], const float (&id)[NX]
 constexpr float MU_ROLL = 1e-4f;
 constexpr float RR_FF = (MU_FINGER * MU_FINGER) / (MU_ROLL * MU_ROLL);   // regulariser scale of the rolling rows: mu_tan^2 / mu_roll^2
 
+// ================================================================================================
+// The solve.  Everything a substep's set-up leaves behind is reached through NewtonCtx (references into the caller's registers / LDS).
+// ================================================================================================
+// Bodies: bit 0 the arm (y coordinates, 6), bit 1 cube 0, bit 2 cube 1 (linear + angular acceleration, 6 each).  newton_solve<.., MASK> minimises F over the
+// bodies in MASK with every constraint that acts on them; the caller cuts the bodies of a wave into the connected components of its WAVE-UNIFORM coupling graph
+// (an edge where some lane has a contact between two bodies) and solves them one after the other: independent problems, each as small as it can be -- most of
+// the time the arm and the cube(s) do not touch, and a wave pays as many iterations as its slowest lane needs for THAT body.
+template <int NC, int NRW, bool WALLS, int NCC>
+struct NewtonCtx {
+    const LcrDev &P;
+    const float *lds;   // g rows of the arm-coupled slots: row (row0[s] + r), float2 pairs [k][lane]
+    int lane;
+    const int (&row0)[NAS];
+    ArmSlot<NRW> (&AS)[NAS];
+    const bool (&slot_any)[NAS];
+    bool link_on_cube;
+    const int (&slot_cube)[3];
+    FloorSlot (&FS)[NC][4];
+    FloorSlot (&WS)[4];          // PushCubeLoop rails (lcr_kernels_loop.hip), pair coordinates
+    const float (&wsg)[2];
+    bool wall_any;
+    float *ccl;                  // StackTwoCubes: cube<->cube records in LDS, field k of slot s at ccl[(s * CC_REC + k) * 64]
+    const bool (&cc_act)[NCC];
+    bool cc_any;
+    f3 ccn, cct1, cct2;
+    const f3 (&cp)[NC];
+    const bool (&lim_act)[6];
+    unsigned lim_wave;
+    const float (&q)[6];
+    const float (&qd)[6];
+    const Chol6 &CL;
+    float (&flim)[6];
+    const float (&y0s)[6];
+};
+
+template <int MASK> constexpr int nw_off(int body) {   // first compact index of a body of MASK
+    int o = 0;
+    for (int b = 0; b < body; b++) o += ((MASK >> b) & 1) ? 6 : 0;
+    return o;
+}
+template <int MASK> constexpr int nw_dim() { return 6 * ((MASK & 1) + ((MASK >> 1) & 1) + ((MASK >> 2) & 1)); }
+
+template <int NC, int NRW, bool WALLS, int NCC, int MASK>
+DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC]) {
+    constexpr bool HAS_A = (MASK & 1) != 0;
+    constexpr bool HAS_C[2] = {(MASK & 2) != 0, NC == 2 && (MASK & 4) != 0};
+    constexpr int NX = nw_dim<MASK>(), NH = NX * (NX + 1) / 2;
+    constexpr int OA = nw_off<MASK>(0), OC[2] = {nw_off<MASK>(1), nw_off<MASK>(2)};
+    constexpr bool ARM_CUBE = HAS_A && (HAS_C[0] || HAS_C[1]);   // arm slots may carry a cube share
+    constexpr bool HAS_CC = NC == 2 && HAS_C[0] && HAS_C[1];
+    // residual rows: joint limits, arm slots (6 rows each, slot 4: 4), floor slots per cube, rails, cube<->cube
+    constexpr int Z_LIM = 0, Z_ARM = 6, Z_FLOOR = 34, Z_WALL = Z_FLOOR + 16 * NC, Z_CC = Z_WALL + (WALLS ? 16 : 0), NZ = Z_CC + (NC == 2 ? 4 * NCC : 0);
+    const LcrDev &P = C.P;
+    const float cm = P.cube_mass, ci = rcp(P.cube_iinv);
+    auto mdiag = [&](int i) -> float { return (HAS_A && i < 6) ? 1.f : (((i - (HAS_A ? 6 : 0)) % 6) < 3 ? cm : ci); };
+    const bool wave_lim = HAS_A && C.lim_wave != 0u;
+    const bool wave_cube4 = ARM_CUBE && __any(C.AS[4].act && C.link_on_cube) != 0;
+    bool fl_any[2] = {false, false};
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (!HAS_C[c]) continue;
+        bool a = false;
+#pragma unroll
+        for (int s = 0; s < 4; s++) a = a || C.FS[c][s].act;
+        fl_any[c] = __any(a) != 0;
+    }
+    float x[NX], x0[NX];
+    if (HAS_A) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { x[OA + j] = y[j]; x0[OA + j] = C.y0s[j]; }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (!HAS_C[c]) continue;
+        x[OC[c] + 0] = ca[c].x; x[OC[c] + 1] = ca[c].y; x[OC[c] + 2] = ca[c].z; x[OC[c] + 3] = cal[c].x; x[OC[c] + 4] = cal[c].y; x[OC[c] + 5] = cal[c].z;
+        x0[OC[c] + 0] = 0.f; x0[OC[c] + 1] = 0.f; x0[OC[c] + 2] = -GRAV; x0[OC[c] + 3] = 0.f; x0[OC[c] + 4] = 0.f; x0[OC[c] + 5] = 0.f;
+    }
+    float scale = 1.f;
+#pragma unroll
+    for (int i = 0; i < NX; i++) scale = fmaf(mdiag(i) * x0[i], x0[i], scale);
+    // joint-limit rows: regulariser and reference acceleration once per solve
+    float lim_aref[6], lim_iR[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { lim_aref[j] = 0.f; lim_iR[j] = 0.f; }
+    if (wave_lim) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            if (!((C.lim_wave >> j) & 1u)) continue;
+            const bool lower = C.q[j] < JLO[j];
+            const float pos = lower ? C.q[j] - JLO[j] : JHI[j] - C.q[j];
+            const float imp = impedance(pos, D0_DEF, DW_DEF, 1.0f / W_DEF);
+            lim_iR[j] = C.lim_act[j] ? rcp(fmaxf((1.f - imp) * rcp(imp) * INVW_DOF[j], 1e-15f)) : 0.f;
+            lim_aref[j] = -B_DEF * (lower ? 1.f : -1.f) * C.qd[j] - K_DEF * imp * pos;
+        }
+    }
+    auto lim_row = [&](int j, float (&g6)[6]) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) g6[k] = k == j ? (C.q[j] < JLO[j] ? 1.f : -1.f) : 0.f;
+        fsub(C.CL, g6);
+    };
+    // squared friction coefficients of an arm slot's rows (finger geoms: 1.5 / 0.005 / 1e-4; a finger on a cube: max rule; a link proxy: floor 1 and no torsion
+    // row -- condim 3 --, on a cube the cube's coefficients)
+    auto arm_m2 = [&](auto s_tag, float (&m2)[6]) {
+        constexpr int s = decltype(s_tag)::value;
+        const bool oncube = s < 2 || (s == 4 && C.link_on_cube);
+        m2[0] = 1.f;
+        m2[1] = m2[2] = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
+        m2[3] = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : (oncube ? P.mu_ct2 : 0.f));
+        m2[4] = m2[5] = s < 2 ? P.mu_fcr2 : (s < 4 ? MU_ROLL * MU_ROLL : 0.f);
+    };
+    // which arm slots exist in this problem, and whether their rows carry a cube share here
+    auto arm_here = [&](int s) -> bool { return HAS_A && C.slot_any[s]; };
+    auto arm_cube_part = [&](int s) -> bool { return ARM_CUBE && (s < 2 || (s == 4 && wave_cube4)); };
+    // the dense row r of arm slot s in the compact coordinates: g row from LDS, the cube's share in closed form
+    auto arm_row = [&](auto s_tag, int r, bool cube_part, float (&row)[NX]) {
+        constexpr int s = decltype(s_tag)::value;
+        const ArmSlot<NRW> &T = C.AS[s];
+#pragma unroll
+        for (int i = 0; i < NX; i++) row[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float2v gp = *reinterpret_cast<const float2v *>(&C.lds[(C.row0[s] + r) * LDS_ROW + k * 128 + C.lane * 2]);
+            row[OA + 2 * k] = gp.x; row[OA + 2 * k + 1] = gp.y;
+        }
+        if (ARM_CUBE && cube_part) {   // the cube's contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
+            const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : (r == 3 ? T.n : (r == 4 ? T.t1 : T.t2))));
+            const float on = (s < 2 || C.link_on_cube) ? -1.f : 0.f;
+            const f3 lin = r < 3 ? on * d : mk(0.f, 0.f, 0.f), ang = r < 3 ? on * cross(T.rc, d) : on * d;
+            const int which = NC == 2 ? C.slot_cube[s == 4 ? 2 : (s & 1)] : 0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (!HAS_C[c]) continue;
+                const float m = (NC == 1 || which == c) ? 1.f : 0.f;
+                row[OC[c] + 0] = m * lin.x; row[OC[c] + 1] = m * lin.y; row[OC[c] + 2] = m * lin.z;
+                row[OC[c] + 3] = m * ang.x; row[OC[c] + 4] = m * ang.y; row[OC[c] + 5] = m * ang.z;
+            }
+        }
+    };
+    // a contact between a cube and the world: frame (n, t1, t2), lever r from the cube centre; rows [d ; r x d], torsion [0 ; n]
+    struct CubeFrame { f3 n, t1, t2, r; };
+    auto floor_frame = [&](int c, int s) -> CubeFrame { return CubeFrame{mk(0.f, 0.f, 1.f), mk(0.f, 1.f, 0.f), mk(-1.f, 0.f, 0.f), C.FS[c][s].r}; };
+    auto wall_frame = [&](int s) -> CubeFrame {   // rails: pair coordinates (a, b, c) = (x, y, z) for the x pair, (y, z, x) for the y pair; n = sg a, t1 = b, t2 = sg c
+        const float sg = C.wsg[s >> 1];
+        const f3 r = C.WS[s].r;
+        if ((s >> 1) == 0) return CubeFrame{mk(sg, 0.f, 0.f), mk(0.f, 1.f, 0.f), mk(0.f, 0.f, sg), r};
+        return CubeFrame{mk(0.f, sg, 0.f), mk(0.f, 0.f, 1.f), mk(sg, 0.f, 0.f), mk(r.z, r.x, r.y)};
+    };
+    auto cube_rows = [&](const CubeFrame &Fm, int c, float sgn, float (&row)[4][NX], bool clear) {
+        if (clear) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < NX; i++) row[q][i] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f3 d = q == 0 ? Fm.n : (q == 1 ? Fm.t1 : (q == 2 ? Fm.t2 : Fm.n));
+            const f3 lin = q < 3 ? sgn * d : mk(0.f, 0.f, 0.f), ang = q < 3 ? sgn * cross(Fm.r, d) : sgn * d;
+            const int o = c == 0 ? OC[0] : OC[1];
+            row[q][o + 0] = lin.x; row[q][o + 1] = lin.y; row[q][o + 2] = lin.z; row[q][o + 3] = ang.x; row[q][o + 4] = ang.y; row[q][o + 5] = ang.z;
+        }
+    };
+    auto cc_pos = [&](int s) -> f3 { return mk(C.ccl[(size_t)(s * CC_REC + 0) * 64], C.ccl[(size_t)(s * CC_REC + 1) * 64], C.ccl[(size_t)(s * CC_REC + 2) * 64]); };
+    auto cc_rows = [&](int s, float (&row)[4][NX]) {
+        const f3 pos = cc_pos(s);
+        cube_rows(CubeFrame{C.ccn, C.cct1, C.cct2, pos - C.cp[NC - 1]}, NC - 1, 1.f, row, true);
+        cube_rows(CubeFrame{C.ccn, C.cct1, C.cct2, pos - C.cp[0]}, 0, -1.f, row, false);
+    };
+
+    float zs[NZ], jd[NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; i++) { zs[i] = 0.f; jd[i] = 0.f; }
+    // out[row] = J_row . v (- aref with SUB): the residuals at the start (v = x) and the directional derivatives of a Newton step (v = dx)
+    auto dots = [&](auto sub_tag, const float (&v)[NX], float (&out)[NZ]) {
+        constexpr bool SUB = decltype(sub_tag)::value;
+        if (wave_lim) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                if (!((C.lim_wave >> j) & 1u)) continue;
+                float g6[6];
+                lim_row(j, g6);
+                float a = SUB ? -lim_aref[j] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; k++) a = fmaf(g6[k], v[OA + k], a);
+                out[Z_LIM + j] = a;
+            }
+        }
+        auto arm = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if (!arm_here(s)) return;
+            constexpr int NR = s < 4 ? 6 : 4;
+            const bool cube_part = arm_cube_part(s);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float row[NX];
+                arm_row(s_tag, r, cube_part, row);
+                float a = SUB ? -C.AS[s].aref[r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < NX; i++) { if ((HAS_A && i >= OA && i < OA + 6) || cube_part) a = fmaf(row[i], v[i], a); }
+                out[Z_ARM + 6 * s + r] = a;
+            }
+        };
+        arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+        arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+        auto cube_con = [&](const CubeFrame &Fm, int c, const float (&aref)[4], int zoff) {
+            float row[4][NX];
+            cube_rows(Fm, c, 1.f, row, true);
+            const int o = c == 0 ? OC[0] : OC[1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float a = SUB ? -aref[q] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; i++) a = fmaf(row[q][o + i], v[o + i], a);
+                out[zoff + q] = a;
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (!HAS_C[c] || !fl_any[c]) continue;
+#pragma unroll
+            for (int s = 0; s < 4; s++) cube_con(floor_frame(c, s), c, C.FS[c][s].aref, Z_FLOOR + 16 * c + 4 * s);
+        }
+        if constexpr (WALLS) {
+            if (HAS_C[0] && C.wall_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) cube_con(wall_frame(s), 0, C.WS[s].aref, Z_WALL + 4 * s);
+            }
+        }
+        if constexpr (HAS_CC) {
+            if (C.cc_any) {
+#pragma unroll
+                for (int s = 0; s < NCC; s++) {
+                    float row[4][NX];
+                    cc_rows(s, row);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float a = SUB ? -C.ccl[(size_t)(s * CC_REC + 7 + q) * 64] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < NX; i++) { if (i >= OC[0]) a = fmaf(row[q][i], v[i], a); }
+                        out[Z_CC + 4 * s + q] = a;
+                    }
+                }
+            }
+        }
+    };
+    // sum over the constraints of f(zs + al jd) . jd: the constraint part of phi'(al) -- registers only (cube<->cube: their regulariser from LDS)
+    auto ls_eval = [&](float al) -> float {
+        float acc = 0.f;
+        if (wave_lim) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                if (!((C.lim_wave >> j) & 1u)) continue;
+                const float z = fmaf(al, jd[Z_LIM + j], zs[Z_LIM + j]);
+                acc = fmaf(z < 0.f ? -z * lim_iR[j] : 0.f, jd[Z_LIM + j], acc);
+            }
+        }
+        auto arm = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if (!arm_here(s)) return;
+            constexpr int NR = s < 4 ? 6 : 4;
+            float m2a[6], m2[NR], z[NR];
+            arm_m2(s_tag, m2a);
+#pragma unroll
+            for (int r = 0; r < NR; r++) { m2[r] = m2a[r]; z[r] = fmaf(al, jd[Z_ARM + 6 * s + r], zs[Z_ARM + 6 * s + r]); }
+            BlkEval<NR> B;
+            blk_eval<NR>(z, C.AS[s].Rn, C.AS[s].Rn * P.inv_impratio * m2[1], m2, C.AS[s].act, B);
+#pragma unroll
+            for (int r = 0; r < NR; r++) acc = fmaf(B.f[r], jd[Z_ARM + 6 * s + r], acc);
+        };
+        arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+        arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+        auto cube_con = [&](float Rn, bool act, int zoff) {
+            const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
+            float z[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) z[q] = fmaf(al, jd[zoff + q], zs[zoff + q]);
+            BlkEval<4> B;
+            blk_eval<4>(z, Rn, Rn * P.inv_impratio * P.mu_c2, m2, act, B);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = fmaf(B.f[q], jd[zoff + q], acc);
+        };
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (!HAS_C[c] || !fl_any[c]) continue;
+#pragma unroll
+            for (int s = 0; s < 4; s++) cube_con(C.FS[c][s].Rn, C.FS[c][s].act, Z_FLOOR + 16 * c + 4 * s);
+        }
+        if constexpr (WALLS) {
+            if (HAS_C[0] && C.wall_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) cube_con(C.WS[s].Rn, C.WS[s].act, Z_WALL + 4 * s);
+            }
+        }
+        if constexpr (HAS_CC) {
+            if (C.cc_any) {
+#pragma unroll
+                for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC + 15) * 64], C.cc_act[s], Z_CC + 4 * s);
+            }
+        }
+        return acc;
+    };
+    // gradient and Hessian of F at x (residuals zs) -- or, with OUT, the forces at x into the slot records
+    auto assemble = [&](auto out_tag, float (&g)[NX], float (&Hm)[NH]) {
+        constexpr bool OUT = decltype(out_tag)::value;
+        if (!OUT) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) g[i] = mdiag(i) * (x[i] - x0[i]);
+#pragma unroll
+            for (int i = 0; i < NH; i++) Hm[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NX; i++) Hm[tri(i, i)] = mdiag(i);
+        }
+        if (wave_lim) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                if (!((C.lim_wave >> j) & 1u)) continue;
+                const float z = zs[Z_LIM + j];
+                const float wl = z < 0.f ? lim_iR[j] : 0.f, f = -z * wl;
+                if (OUT) { C.flim[j] = f; continue; }
+                float gl[NX], g6[6];
+#pragma unroll
+                for (int k = 0; k < NX; k++) gl[k] = 0.f;
+                lim_row(j, g6);
+#pragma unroll
+                for (int k = 0; k < 6; k++) { gl[OA + k] = g6[k]; g[OA + k] = fmaf(-f, g6[k], g[OA + k]); }
+                h_rank1<OA, OA + 6, NX>(Hm, gl, wl);
+            }
+        }
+        auto arm = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if (!arm_here(s)) return;
+            constexpr int NR = s < 4 ? 6 : 4;
+            ArmSlot<NRW> &T = C.AS[s];
+            const bool cube_part = arm_cube_part(s);
+            float m2a[6], m2[NR], z[NR];
+            arm_m2(s_tag, m2a);
+#pragma unroll
+            for (int r = 0; r < NR; r++) { m2[r] = m2a[r]; z[r] = zs[Z_ARM + 6 * s + r]; }
+            BlkEval<NR> B;
+            blk_eval<NR>(z, T.Rn, T.Rn * P.inv_impratio * m2[1], m2, T.act, B);
+            if (OUT) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) T.f[r] = B.f[r];
+                return;
+            }
+            float row[NR][NX];
+#pragma unroll
+            for (int r = 0; r < NR; r++) arm_row(s_tag, r, cube_part, row[r]);
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                if (!((HAS_A && i >= OA && i < OA + 6) || cube_part)) continue;
+                float a = g[i];
+#pragma unroll
+                for (int r = 0; r < NR; r++) a = fmaf(-B.f[r], row[r][i], a);
+                g[i] = a;
+            }
+            if (ARM_CUBE && cube_part) h_block<0, NX, NX, NR>(Hm, row, B, m2);
+            else h_block<OA, OA + 6, NX, NR>(Hm, row, B, m2);
+        };
+        arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+        arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+        auto cube_con = [&](auto c_tag, const CubeFrame &Fm, FloorSlot &T, bool act, int zoff) {
+            constexpr int c = decltype(c_tag)::value;
+            const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
+            float z[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) z[q] = zs[zoff + q];
+            BlkEval<4> B;
+            blk_eval<4>(z, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, m2, act, B);
+            if (OUT) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) T.f[q] = B.f[q];
+                return;
+            }
+            float row[4][NX];
+            cube_rows(Fm, c, 1.f, row, true);
+            constexpr int o = OC[c];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                float a = g[o + i];
+#pragma unroll
+                for (int q = 0; q < 4; q++) a = fmaf(-B.f[q], row[q][o + i], a);
+                g[o + i] = a;
+            }
+            h_block<o, o + 6, NX, 4>(Hm, row, B, m2);
+        };
+        if constexpr (HAS_C[0]) {
+            if (fl_any[0] || OUT) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) cube_con(std::integral_constant<int, 0>{}, floor_frame(0, s), C.FS[0][s], C.FS[0][s].act && fl_any[0], Z_FLOOR + 4 * s);
+            }
+            if constexpr (WALLS) {
+                if (C.wall_any || OUT) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) cube_con(std::integral_constant<int, 0>{}, wall_frame(s), C.WS[s], C.WS[s].act && C.wall_any, Z_WALL + 4 * s);
+                }
+            }
+        }
+        if constexpr (HAS_C[1]) {
+            if (fl_any[1] || OUT) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) cube_con(std::integral_constant<int, 1>{}, floor_frame(1, s), C.FS[NC - 1][s], C.FS[NC - 1][s].act && fl_any[1], Z_FLOOR + 16 + 4 * s);
+            }
+        }
+        if constexpr (HAS_CC) {
+            if (C.cc_any) {
+#pragma unroll
+                for (int s = 0; s < NCC; s++) {
+                    const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
+                    const float Rn = C.ccl[(size_t)(s * CC_REC + 15) * 64];
+                    float z[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) z[q] = zs[Z_CC + 4 * s + q];
+                    BlkEval<4> B;
+                    blk_eval<4>(z, Rn, Rn * P.inv_impratio * P.mu_c2, m2, C.cc_act[s], B);
+                    if (OUT) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC + 3 + q) * 64] = B.f[q];
+                        continue;
+                    }
+                    float row[4][NX];
+                    cc_rows(s, row);
+#pragma unroll
+                    for (int i = OC[0]; i < NX; i++) {
+                        float a = g[i];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) a = fmaf(-B.f[q], row[q][i], a);
+                        g[i] = a;
+                    }
+                    h_block<OC[0], NX, NX, 4>(Hm, row, B, m2);
+                }
+            }
+        }
+    };
+
+    dots(std::true_type{}, x, zs);
+    const float tol2 = P.newton_tol * P.newton_tol * scale;
+    int lane_its = 0;   // iterations in which THIS env still moved (what the oracle counts per env)
+    for (int it = 0; it < P.newton_iters; it++) {
+        float dx[NX], d0 = 0.f;
+        {
+            float Hm[NH], g[NX], hid[NX];
+            assemble(std::false_type{}, g, Hm);
+            chol_packed<NX>(Hm, hid);
+#pragma unroll
+            for (int i = 0; i < NX; i++) dx[i] = -g[i];
+            solve_packed<NX>(Hm, hid, dx);
+#pragma unroll
+            for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
+        }
+        const bool live = -d0 > tol2;   // Newton decrement above the tolerance: this lane still moves
+        if (!__any(live)) break;
+        lane_its += live ? 1 : 0;
+        dots(std::false_type{}, dx, jd);
+        // line search on phi'(al) = q0 + al q1 - sum f(zs + al jd) . jd: first the full step (exact while no contact changes zone), bracket by doubling, then the
+        // Illinois variant of regula falsi
+        float q1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) q1 = fmaf(mdiag(i) * dx[i], dx[i], q1);
+        const float q0 = d0 + ls_eval(0.f);
+        float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f;
+        bool done = !live;
+        for (int ls = 0; ls < P.ls_iters; ls++) {
+            const float dphi = fmaf(al, q1, q0) - ls_eval(al);
+            if (!done) {
+                const bool fin = fabsf(dphi) <= P.ls_tol * fabsf(d0);
+                if (dphi < 0.f) { if (hi_a >= 0.f && lo_a > 0.f) dhi *= 0.5f; lo_a = al; dlo = dphi; }
+                else { if (hi_a >= 0.f) dlo *= 0.5f; hi_a = al; dhi = dphi; }
+                float an;
+                if (hi_a < 0.f) an = 2.f * al;
+                else { an = lo_a - dlo * (hi_a - lo_a) * rcp(dhi - dlo); if (!(an > lo_a && an < hi_a)) an = 0.5f * (lo_a + hi_a); }
+                al = fin ? al : an;
+                done = fin;
+            }
+            if (__all(done)) break;
+        }
+        const float step = live ? al : 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) x[i] = fmaf(step, dx[i], x[i]);
+#pragma unroll
+        for (int i = 0; i < NZ; i++) zs[i] = fmaf(step, jd[i], zs[i]);
+    }
+    {   // the forces at the solution: carried to the next substep / control step
+        float Hd[NH], gd[NX];
+        assemble(std::true_type{}, gd, Hd);
+    }
+    // the integration uses the accelerations themselves (M (x - a0) = J'f at the optimum)
+    if (HAS_A) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) y[j] = x[OA + j];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (!HAS_C[c]) continue;
+        ca[c] = mk(x[OC[c] + 0], x[OC[c] + 1], x[OC[c] + 2]); cal[c] = mk(x[OC[c] + 3], x[OC[c] + 4], x[OC[c] + 5]);
+    }
+    return lane_its;
+}
+
 }  // namespace

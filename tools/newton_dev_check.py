@@ -28,6 +28,13 @@ def check(task, mode, n, steps, preset="faithful"):
         DQ.append(dq)
         IT.append(sim.max_sweeps.numpy() if sim.max_sweeps is not None else np.zeros(n))
         OIT.append(o.max_sweeps.copy())
+        if t == steps - 1 and os.environ.get("DEV_DUMP"):
+            k = IT[-1].astype(int); oo = OIT[-1].astype(int)
+            bad = np.where(k >= 8)[0][:12]
+            am = sim.active_mask.numpy()
+            for e in bad:
+                print("   env", e, "kernel its", k[e], "oracle its", oo[e], "mask %x" % am[e], "oracle mask %x" % o.active_mask[e], "dq %.1e" % dq[e])
+            print("   hist kernel", np.bincount(k, minlength=11), "oracle", np.bincount(oo, minlength=11))
     dq = np.concatenate(DQ)
     print(f"{task:10s} {mode:5s} {preset}: |dq| p50 {np.median(dq):.1e} p90 {np.percentile(dq, 90):.1e} p99 {np.percentile(dq, 99):.1e} max {np.nanmax(dq):.1e}"
           f"  within 2e-5: {100 * (dq <= 2e-5).mean():.2f} %  finite: {np.isfinite(dq).all()}   newton its (max per substep) kernel mean {np.mean(IT):.2f} max {np.max(IT)}"
