@@ -36,6 +36,7 @@ UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", 
          ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels_loop.hip", "lcr_kernels_loop.o", []),
          ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
          ("lcr_kernels.hip", "lcr_kernels_newton.o", ["-DLCR_PART=4"]),   # the Newton kernels of the faithful preset (one cube)
+         ("lcr_kernels.hip", "lcr_kernels_newton_stack.o", ["-DLCR_PART=5"]),   # ... StackTwoCubes (eight cube<->cube slots)
          # the two-cooperating-waves family (lcr_kernels2.hip): 10 / 14 one cube built for one / two waves per SIMD, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point
          # manifold.  Instruction-scheduling flags per unit, each measured on the MI355X against the default (tools/quick_times.py; results are bit-identical, the flags only
          # reorder instructions): no post-RA scheduler for the 256-register build (Reach 65 536 envs 0.2578 -> 0.2554 ms, Push 0.3128 -> 0.3064, PickPlace-ee 0.3106 -> 0.3068);

@@ -192,8 +192,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->step_kernel < 0 || cfg->step_kernel > 2) return fail(LCR_ERR_INVALID, "step_kernel must be 0 (by task and job size), 1 (one wave per 64 envs) or 2 (two cooperating waves)");
     if (cfg->diagnostics < 0 || cfg->diagnostics > 3) return fail(LCR_ERR_INVALID, "diagnostics must be 0, 1 (decision signature), 2 or 3 (per-wave cycle read-back, profiling)");
     // combinations no kernel implements are refused, not silently degraded
-    if (cfg->cc_points == 8 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 runs on the two-wave kernels, diagnostics = 2 (per-wave cycles) on the one-wave kernels");
-    if (cfg->cc_points == 8 && cfg->step_kernel == 1) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 is implemented by the two-wave kernels only (step_kernel = 1 pins the one-wave family)");
+    if (cfg->cc_points == 8 && cfg->solver == LCR_SOLVER_PGS && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 runs on the two-wave kernels, diagnostics = 2 (per-wave cycles) on the one-wave kernels");
+    if (cfg->cc_points == 8 && cfg->solver == LCR_SOLVER_PGS && cfg->step_kernel == 1) return fail(LCR_ERR_UNSUPPORTED, "cc_points = 8 is implemented by the two-wave kernels only (step_kernel = 1 pins the one-wave family)");
     if (cfg->step_kernel == 2 && cfg->pgs_iters < 0) return fail(LCR_ERR_UNSUPPORTED, "the converged solver mode (pgs_iters < 0) is implemented by the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
     if (cfg->step_kernel == 2 && cfg->task == LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_UNSUPPORTED, "PushCubeLoop has the one-wave step kernel only (lcr_kernels_loop.hip); step_kernel = 2 pins the two-wave family");
     if (cfg->step_kernel == 2 && cfg->diagnostics == 2) return fail(LCR_ERR_UNSUPPORTED, "diagnostics = 2 (per-wave cycles) reads back the one-wave kernels only (step_kernel = 2 pins the two-wave family)");
@@ -202,7 +202,6 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->solver == LCR_SOLVER_NEWTON) {
         if (cfg->newton_iters <= 0 || cfg->ls_iters <= 0 || !(cfg->newton_tol > 0) || !(cfg->ls_tol > 0)) return fail(LCR_ERR_INVALID, "newton_iters, ls_iters, newton_tol and ls_tol must be positive");
         if (cfg->finger_cube_condim == 4 || cfg->finger_floor_condim == 4) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels carry six-row finger contacts (finger_cube_condim = finger_floor_condim = 6)");
-        if (cfg->task == LCR_TASK_STACK || cfg->task == LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels serve the one-cube tasks without rails so far");
         if (cfg->step_kernel == 2) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels are one-wave kernels (step_kernel = 2 pins the two-wave family)");
         if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters < 0 (converged sweeps) belongs to LCR_SOLVER_PGS");
         if (cfg->diagnostics == 2 || cfg->diagnostics == 3) return fail(LCR_ERR_UNSUPPORTED, "the per-wave cycle read-back is implemented by the sweep kernels");
@@ -365,7 +364,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             D.newton = cfg->solver == LCR_SOLVER_NEWTON ? 1 : 0;
             D.newton_iters = cfg->newton_iters; D.ls_iters = cfg->ls_iters;
             D.newton_tol = (float)cfg->newton_tol; D.ls_tol = (float)cfg->ls_tol;
-            if (D.newton) { D.coop = 0; D.roll = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots
+            if (D.newton) { D.coop = 0; D.roll = 1; D.big_lds = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots, every g row in LDS (cc8: slots 4-7 of their eight cube<->cube records)
         }
     }
     D.arm_collision = cfg->arm_collision ? 1 : 0;

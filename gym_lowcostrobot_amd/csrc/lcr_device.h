@@ -86,6 +86,7 @@ int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void 
 int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
 // the Newton kernels of the faithful preset (lcr_kernels.hip, unit LCR_PART = 4)
 int lcr_launch_step_newton(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
+int lcr_launch_step_newton_stack(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);   // (unit LCR_PART = 5)
 // two-cooperating-waves family (lcr_kernels2.hip); occ = waves per SIMD the variant is compiled for
 int lcr_launch_step2_one_cube(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);
 int lcr_launch_step2_stack(const LcrDev &P, const float *action_dev, int ee_mode, int occ, void *stream);

@@ -36,11 +36,11 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // NEWTON (the faithful preset): every finger contact has MuJoCo's six rows -- against the floor too (follower.xml:15 condim="6") -- and the constraint problem is solved
 // by Newton's method on the primal (lcr_newton.h) instead of sweeps on the dual
-template <bool ROLL, bool NEWTON> constexpr int arm_rows_of(int s) { return (NEWTON && s < 4) ? 6 : as_rows<ROLL>(s); }
-template <bool ROLL, int NC, bool BIG, bool NEWTON> constexpr int arm_row0_of(int s) { return NEWTON ? (s < 4 ? 6 * s : 24) : as_row0<ROLL, NC, BIG>(s); }
 template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
-    static_assert(!NEWTON || (ROLL && NC == 1 && !ADAPT), "the Newton kernels carry six-row finger slots; one cube so far");
+    static_assert(!NEWTON || (ROLL && !ADAPT && (NC == 1 || BIG)), "the Newton kernels carry six-row finger slots and keep every g row in LDS");
+    constexpr int NCC = NEWTON ? 8 : 4;   // cube<->cube manifold points (Stack): the Newton kernels carry eight slots, 4-7 in use with lcr_config.cc_points = 8
+    constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();   // first LDS row of the cube<->cube records
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
@@ -250,10 +250,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 
     // ---- collision: cube <-> cube (Stack).  Face-axis SAT (6 axes), then vertices of each box below the other's
     //      reference face and inside its footprint; first 4 found (box1's vertices first).  Records live in LDS. ----
-    bool cc_act[4] = {false, false, false, false};
+    bool cc_act[NCC];
+#pragma unroll
+    for (int s = 0; s < NCC; s++) cc_act[s] = false;
     bool cc_any = false;
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
-    float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
+    float *ccl = lds + CCB * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
     const size_t CS = 64;
     if constexpr (NC == 2) {
         const f3 dc = S.cp[1] - S.cp[0];
@@ -272,10 +274,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
         const bool touching = best < 0.f;
         int cnt = 0;
-        f3 cpos[4];
-        float cdist[4] = {0.f, 0.f, 0.f, 0.f};
+        f3 cpos[NCC];
+        float cdist[NCC];
 #pragma unroll
-        for (int s = 0; s < 4; s++) cpos[s] = mk(0.f, 0.f, 0.f);
+        for (int s = 0; s < NCC; s++) { cpos[s] = mk(0.f, 0.f, 0.f); cdist[s] = 0.f; }
         if (__any(touching)) {  // wave-uniform: the manifold construction is skipped unless some env has overlapping cubes
             // reference box A (owner of the best axis), incident box B; per-lane selection by compare/select
             const bool Ais0 = bax < 3;
@@ -307,13 +309,16 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 f3 d = V[i] - cA;
                 Vu[i] = dot(d, u); Vv[i] = dot(d, v); Vd[i] = dot(d, m) - CH;
             }
-            float skey[4] = {0.f, 0.f, 0.f, 0.f};
-            int sidx[4] = {-1, -1, -1, -1};
-            auto consider = [&](bool ok, int cand, f3 P, float dist, float cu, float cv) {
-                const float key[4] = {cu + cv, -cu + cv, -cu - cv, cu - cv};
+            float skey[NCC];
+            int sidx[NCC];
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    bool t = ok && (sidx[s] < 0 || key[s] > skey[s]);
+            for (int s = 0; s < NCC; s++) { skey[s] = 0.f; sidx[s] = -1; }
+            const bool eight = NCC == 8 && P.cc8;   // (the axis extremes join the diagonal ones: lcr_config.cc_points = 8)
+            auto consider = [&](bool ok, int cand, f3 P, float dist, float cu, float cv) {
+                const float key[8] = {cu + cv, -cu + cv, -cu - cv, cu - cv, cu, cv, -cu, -cv};   // diagonals of the reference face, then its axes
+#pragma unroll
+                for (int s = 0; s < NCC; s++) {
+                    bool t = ok && (s < 4 || eight) && (sidx[s] < 0 || key[s] > skey[s]);
                     skey[s] = t ? key[s] : skey[s];
                     sidx[s] = t ? cand : sidx[s];
                     cdist[s] = t ? dist : cdist[s];
@@ -356,20 +361,20 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < NCC; s++) {
                 bool dup = false;
 #pragma unroll
                 for (int s2 = 0; s2 < s; s2++) dup = dup || (sidx[s2] == sidx[s]);
                 cc_act[s] = sidx[s] >= 0 && !dup;
                 cnt += cc_act[s] ? 1 : 0;
-                if (P.diag) diag_choice(DG, cc_act[s], 8 + s, sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0.f ? 1 : 0));
+                if (P.diag) diag_choice(DG, cc_act[s], s < 4 ? 8 + s : 24 + (s - 4), sidx[s] + 32 * (bax + 6 * kb) + 1024 * (bsgn < 0.f ? 1 : 0));
             }
         }
         cc_any = __any(cnt > 0) != 0;
         if (cc_any) {
             make_frame(ccn, cct1, cct2);
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < NCC; s++) {
                 const f3 r0 = cpos[s] - S.cp[0], r1 = cpos[s] - S.cp[1];
                 float imp = impedance(cdist[s], D0_DEF, DW_DEF, 1.0f / W_DEF);
                 float Rn = fmaxf((1.f - imp) * rcp(imp) * (2.f * minv), 1e-15f);
@@ -665,14 +670,34 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                                arm_row0_of<ROLL, NC, BIG, NEWTON>(3), arm_row0_of<ROLL, NC, BIG, NEWTON>(4)};
         FloorSlot no_walls[4];
         const float no_wsg[2] = {1.f, 1.f};
-        NewtonCtx<NC, NRW, false, 4> C{P, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, no_walls, no_wsg, false,
-                                       ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
-        const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
-        if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, 4, 3>(C, y, ca, cal);
-        else {
-            const int ia = newton_solve<NC, NRW, false, 4, 1>(C, y, ca, cal);
-            const int ic = newton_solve<NC, NRW, false, 4, 2>(C, y, ca, cal);
-            sweeps_done = max(ia, ic);
+        NewtonCtx<NC, NRW, false, NCC> C{P, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, no_walls, no_wsg, false,
+                                         ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
+        if constexpr (NC == 1) {
+            const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
+            if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal);
+            else {
+                const int ia = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal);
+                const int ic = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
+                sweeps_done = max(ia, ic);
+            }
+        } else {
+            // edges of the wave's coupling graph: arm <-> cube c where some lane has a finger sphere or a gripper-body proxy on that cube, cube 0 <-> cube 1 where some
+            // lane's cubes touch
+            bool on0 = false, on1 = false;
+#pragma unroll
+            for (int s = 0; s < 2; s++) { on0 = on0 || (AS[s].act && slot_cube[s] == 0); on1 = on1 || (AS[s].act && slot_cube[s] == 1); }
+            on0 = on0 || (AS[4].act && link_on_cube && slot_cube[2] == 0); on1 = on1 || (AS[4].act && link_on_cube && slot_cube[2] == 1);
+            const bool eA0 = __any(on0) != 0, eA1 = __any(on1) != 0, e01 = cc_any;
+            int i1 = 0, i2 = 0, i3 = 0;
+            if ((eA0 && eA1) || (e01 && (eA0 || eA1))) i1 = newton_solve<NC, NRW, false, NCC, 7>(C, y, ca, cal);
+            else if (eA0) { i1 = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal); }
+            else if (eA1) { i1 = newton_solve<NC, NRW, false, NCC, 5>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal); }
+            else if (e01) { i1 = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 6>(C, y, ca, cal); }
+            else {
+                i1 = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
+                i3 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal);
+            }
+            sweeps_done = max(i1, max(i2, i3));
         }
     }
     for (int it = 0; it < max_it; it++) {
@@ -934,7 +959,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
         for (int k = 0; k < NRW; k++) W.arm[s][k] = AS[s].f[k];
 #pragma unroll
-    for (int s = 0; s < 4; s++) W.cc_prev[s] = cc_act[s];
+    for (int s = 0; s < NCC; s++) W.cc_prev[s] = cc_act[s];
     if (P.diag) {   // wave-uniform
         unsigned m = 0u;
 #pragma unroll
@@ -942,8 +967,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
             for (int s = 0; s < 4; s++) m |= FS[c][s].act ? (1u << (4 * c + s)) : 0u;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            if (NC == 2) m |= cc_act[s] ? (1u << (8 + s)) : 0u;
+        for (int s = 0; s < NCC; s++) {
+            if (NC == 2) m |= cc_act[s] ? (1u << (s < 4 ? 8 + s : 24 + (s - 4))) : 0u;
         }
         m |= AS[0].act ? (1u << 12) : 0u; m |= AS[1].act ? (1u << 13) : 0u;
         m |= AS[2].act ? (1u << 14) : 0u; m |= AS[3].act ? (1u << 15) : 0u;
@@ -1009,7 +1034,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[NEWTON ? 28 * LDS_ROW : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave)
+    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CC_REC * 64 : 0) : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records = 74 KiB)
+    constexpr int NCC = NEWTON ? 8 : 4;
+    constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -1116,14 +1143,14 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
     for (int j = 0; j < 6; j++) W.lim[j] = wld(WARM_LIM + j);
 #pragma unroll
-    for (int s = 0; s < 4; s++) W.cc_prev[s] = false;
+    for (int s = 0; s < 8; s++) W.cc_prev[s] = false;
     if constexpr (NC == 2) {   // cube<->cube forces live in their LDS records between substeps
-        float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;
+        float *ccl = lds + CCB * LDS_ROW + lane;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            W.cc_prev[s] = wld(WARM_CCPREV + s) != 0.f;
+        for (int s = 0; s < NCC; s++) {
+            W.cc_prev[s] = wld(s < 4 ? WARM_CCPREV + s : WARM_CCPREV2 + (s - 4)) != 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(WARM_CC + 4 * s + r);
+            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r);
         }
     }
     Diag DG = {0u, 0u, 0u, 0u};
@@ -1225,12 +1252,12 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 #pragma unroll
         for (int j = 0; j < 6; j++) wst(WARM_LIM + j, W.lim[j]);
         if constexpr (NC == 2) {
-            const float *ccl = lds + cc_base_rows<NC, BIG, ROLL>() * LDS_ROW + lane;
+            const float *ccl = lds + CCB * LDS_ROW + lane;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                wst(WARM_CCPREV + s, W.cc_prev[s] ? 1.f : 0.f);
+            for (int s = 0; s < NCC; s++) {
+                wst(s < 4 ? WARM_CCPREV + s : WARM_CCPREV2 + (s - 4), W.cc_prev[s] ? 1.f : 0.f);
 #pragma unroll
-                for (int r = 0; r < 4; r++) wst(WARM_CC + 4 * s + r, W.cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
+                for (int r = 0; r < 4; r++) wst(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r, W.cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
             }
         }
     }
@@ -1367,6 +1394,16 @@ int lcr_launch_step_newton(const LcrDev &P, const float *action_dev, int ee_mode
 }
 #endif
 
+#if LCR_HAS_PART(5)
+int lcr_launch_step_newton_stack(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
+    const int blocks = (P.n + 63) / 64;
+    const hipStream_t st = (hipStream_t)stream;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<2, false, false, true, true, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<2, true, false, true, true, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    return check_launch();
+}
+#endif
+
 #if LCR_HAS_PART(0)
 template <bool ADAPT, bool ROLL>
 static void launch_one_cube_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
@@ -1377,7 +1414,7 @@ static void launch_one_cube_t(const LcrDev &P, const float *action_dev, int ee_m
 int lcr_launch_step(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
     const hipStream_t st = (hipStream_t)stream;
     if (P.walls) return lcr_launch_step_loop(P, action_dev, ee_mode, stream);   // PushCubeLoop: its own unit and solver (lcr_kernels_loop.hip)
-    if (P.newton && P.task != 4) return lcr_launch_step_newton(P, action_dev, ee_mode, stream);
+    if (P.newton) return P.task == 4 ? lcr_launch_step_newton_stack(P, action_dev, ee_mode, stream) : lcr_launch_step_newton(P, action_dev, ee_mode, stream);
     if (P.coop && P.pgs_iters >= 0 && P.diag != 2) {   // two cooperating waves per 64 envs (no converged mode, no per-wave cycle read-back)
         if (P.task == 4) return P.cc8 ? lcr_launch_step2_stack_cc8(P, action_dev, ee_mode, P.coop, stream) : lcr_launch_step2_stack(P, action_dev, ee_mode, P.coop, stream);
         return lcr_launch_step2_one_cube(P, action_dev, ee_mode, P.coop, stream);

@@ -20,14 +20,17 @@
 //   step / reward / goals     envs/push_cube_loop_env.py:319-383; TimeLimit(50) from __init__.py:37-42
 //   reset                     envs/push_cube_loop_env.py:299-317
 #include "lcr_step_common.h"
+#include "lcr_newton.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool WALLS, bool ADAPT, bool ROLL, bool BIG>
+// NEWTON (the faithful preset): six-row finger contacts against cube AND floor, the constraint problem solved by Newton's method on the primal (lcr_newton.h)
+template <int NC, bool WALLS, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
+    static_assert(!NEWTON || (ROLL && NC == 1 && !ADAPT), "the Newton kernels carry six-row finger slots");
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
@@ -128,6 +131,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
     for (int j = 0; j < 6; j++) y[j] = tau[j];
     fsub(CL, y);
+    float y0s[6];   // (NEWTON) the unconstrained arm acceleration in y coordinates: a0 of the primal problem
+#pragma unroll
+    for (int j = 0; j < 6; j++) y0s[j] = y[j];
     // cube accelerations, world frame (isotropic inertia: no gyroscopic term)
     f3 ca[NC], cal[NC];
     f3 cww[NC];  // cube angular velocity in world frame
@@ -625,7 +631,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 if (s == 4 && j >= 3 && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int r = 0; r < as_rows<ROLL>(s); r++) {
+            for (int r = 0; r < arm_rows_of<ROLL, NEWTON>(s); r++) {
                 f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));   // row 3: rotation about n (torsion)
                 if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }     // rows 4, 5: rotation about t1, t2 (rolling)
                 float g[6];
@@ -660,10 +666,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     const float2v gp = {g[2 * k], g[2 * k + 1]};
                     if (NC == 2 && !BIG && s == 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2]) = gp;
                     else if (NC == 2 && !BIG && r >= 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2]) = gp;
-                    else *reinterpret_cast<float2v *>(&lds[(as_row0<ROLL, NC, BIG>(s) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
+                    else *reinterpret_cast<float2v *>(&lds[(arm_row0_of<ROLL, NC, BIG, NEWTON>(s) + r) * LDS_ROW + k * 128 + lane * 2]) = gp;
                 }
                 float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
-                if (ROLL && r > 3) Rr = Rf * P.rr_fc;
+                if (ROLL && r > 3) Rr = Rf * (s < 2 ? P.rr_fc : RR_FF);   // (rolling rows of a finger on the floor: NEWTON only)
                 T.aref[r] = -Bc * vel - (r == 0 ? Kc * imp * dist : 0.f);
                 // warm start: previous substep's force of this slot (zero if it was inactive), applied to the accelerations
                 const bool row_on = T.act && (s != 4 || r < 3 || oncube);   // a link proxy on the floor has no torsion row (condim 3)
@@ -714,8 +720,22 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     // ---- projected Gauss-Seidel on the dual, matrix-free, warm-started.  Fixed sweep count (pgs_iters > 0), or ADAPT
     //      (pgs_iters < 0): sweep until the largest force change of a sweep is <= pgs_tol (1 + largest |force|) in EVERY lane
     //      of the wave, at most 50 sweeps ----
-    const int max_it = ADAPT ? 50 : P.pgs_iters;
+    const int max_it = NEWTON ? 0 : (ADAPT ? 50 : P.pgs_iters);
     int sweeps_done = 0;
+    if constexpr (NEWTON) {
+        // ---- Newton on the primal (lcr_newton.h; oracle: newton_product); the cube's problem carries the rails' rows ----
+        const int row0[NAS] = {arm_row0_of<ROLL, NC, BIG, NEWTON>(0), arm_row0_of<ROLL, NC, BIG, NEWTON>(1), arm_row0_of<ROLL, NC, BIG, NEWTON>(2),
+                               arm_row0_of<ROLL, NC, BIG, NEWTON>(3), arm_row0_of<ROLL, NC, BIG, NEWTON>(4)};
+        NewtonCtx<NC, NRW, WALLS, 4> C{P, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, WS, wsg, wall_any,
+                                       ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
+        const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
+        if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, WALLS, 4, 3>(C, y, ca, cal);
+        else {
+            const int ia = newton_solve<NC, NRW, WALLS, 4, 1>(C, y, ca, cal);
+            const int ic = newton_solve<NC, NRW, WALLS, 4, 2>(C, y, ca, cal);
+            sweeps_done = max(ia, ic);
+        }
+    }
     for (int it = 0; it < max_it; it++) {
         float chg = 0.f, fmx = 0.f;   // ADAPT: largest |force change| and |force| of this sweep
         auto track = [&](float d0, float d1, float d2, float d3, float f0, float f1, float f2, float f3_) {
@@ -1126,9 +1146,9 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL, bool BIG>
+template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[LdsSize<NC, WALLS, ROLL, BIG>::value];
+    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW : LdsSize<NC, WALLS, ROLL, BIG>::value];
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -1251,7 +1271,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         }
     }
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
@@ -1391,7 +1411,11 @@ static void launch_loop_t(const LcrDev &P, const float *action_dev, int ee_mode,
 }
 int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
     const hipStream_t st = (hipStream_t)stream;
-    if (P.pgs_iters < 0) {   // converged mode
+    if (P.newton) {   // the faithful preset: Newton on the primal, six-row finger contacts everywhere
+        const int blocks = (P.n + 63) / 64;
+        if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+        else hipLaunchKernelGGL((lcr_step_kernel<1, true, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    } else if (P.pgs_iters < 0) {   // converged mode
         if (P.roll) launch_loop_t<true, true>(P, action_dev, ee_mode, st);
         else launch_loop_t<true, false>(P, action_dev, ee_mode, st);
     } else {

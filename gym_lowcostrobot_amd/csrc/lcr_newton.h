@@ -124,6 +124,11 @@ DEV void solve_packed(const float (&H)[NX * (NX + 1) / 2], const float (&id)[NX]
 constexpr float MU_ROLL = 1e-4f;
 constexpr float RR_FF = (MU_FINGER * MU_FINGER) / (MU_ROLL * MU_ROLL);   // regulariser scale of the rolling rows: mu_tan^2 / mu_roll^2
 
+// rows and LDS placement of the arm-coupled slots in the Newton kernels: the finger slots 0-3 have six rows, the proxy slot four -- 28 g rows (42 KiB per wave)
+template <bool ROLL, bool NEWTON> constexpr int arm_rows_of(int s) { return (NEWTON && s < 4) ? 6 : as_rows<ROLL>(s); }
+template <bool ROLL, int NC, bool BIG, bool NEWTON> constexpr int arm_row0_of(int s) { return NEWTON ? (s < 4 ? 6 * s : 24) : as_row0<ROLL, NC, BIG>(s); }
+constexpr int NEWTON_G_ROWS = 28;
+
 // ================================================================================================
 // The solve.  Everything a substep's set-up leaves behind is reached through NewtonCtx (references into the caller's registers / LDS).
 // ================================================================================================

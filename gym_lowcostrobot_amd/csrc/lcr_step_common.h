@@ -309,7 +309,7 @@ struct Warm {
     float arm[NAS][NRW];
     float lim[6];
     float wall[4][4];
-    bool cc_prev[4];
+    bool cc_prev[8];   // (slots 4-7: the eight-point manifold of the Newton kernels)
 };
 
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
