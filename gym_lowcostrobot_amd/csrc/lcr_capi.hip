@@ -99,7 +99,8 @@ const char *lcr_last_error(void) { return g_err; }
 int lcr_nq(int task) { return task == LCR_TASK_STACK ? 20 : 13; }
 int lcr_nv(int task) { return task == LCR_TASK_STACK ? 18 : 12; }
 
-int lcr_config_default(lcr_config *cfg, int task) {
+// the reference constructor defaults + the rounds 1-4 solver settings (LCR_PRESET_FAST); lcr_config_preset builds on it
+static int config_base(lcr_config *cfg, int task) {
     if (!cfg) return fail(LCR_ERR_INVALID, "cfg is NULL");
     if (task < LCR_TASK_REACH || task > LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_INVALID, "unknown task %d", task);
     memset(cfg, 0, sizeof *cfg);
@@ -143,9 +144,11 @@ int lcr_config_default(lcr_config *cfg, int task) {
     return LCR_OK;
 }
 
+int lcr_config_default(lcr_config *cfg, int task) { return lcr_config_preset(cfg, task, LCR_PRESET_FAITHFUL); }
+
 int lcr_config_preset(lcr_config *cfg, int task, int preset) {
     if (preset != LCR_PRESET_FAITHFUL && preset != LCR_PRESET_FAST) return fail(LCR_ERR_INVALID, "unknown preset %d", preset);
-    const int rc = lcr_config_default(cfg, task);
+    const int rc = config_base(cfg, task);
     if (rc != LCR_OK) return rc;
     if (preset == LCR_PRESET_FAITHFUL) {
         cfg->solver = LCR_SOLVER_NEWTON;

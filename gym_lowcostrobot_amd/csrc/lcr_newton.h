@@ -1,5 +1,5 @@
 // lcr_newton.h -- building blocks of the FAITHFUL preset's contact solve: Newton's method on the primal problem, MuJoCo's default solver
-// (follower.xml:3 names no solver).  Oracle: newton_product in oracle/lcr_oracle.c (orc_params.solver = 2); decision record: profiles/r05_solver_decision.txt.
+// (follower.xml:3 names no solver).  CPU checker: newton_product of the test oracle (orc_params.solver = 2); decision record: profiles/r05_solver_decision.txt.
 //
 // The constrained accelerations x minimise the strictly convex, C^1, piecewise quadratic
 //     F(x) = 1/2 (x - a0)' M (x - a0) + sum_b s_b(J_b x - aref_b),      s_b(z) = max_{f in K_b} ( -f'z - 1/2 f'R_b f ),

@@ -5,6 +5,7 @@ gym_lowcostrobot/envs/reach_cube_env.py:297-333 and the four sibling files).  Al
 the HIP kernels behind the C ABI (include/lcr.h); this file only owns handles and moves bytes.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -94,6 +95,8 @@ class VecSim:
         self.task_name = task if isinstance(task, str) else {v: k for k, v in TASKS.items()}[task]
         cfg = LcrConfig()
         # preset: "faithful" (the reference's contact model solved by Newton's method) | "fast" (rounds 1-4: four sweeps, fewer rows); None = the library's default
+        if preset is None:
+            preset = os.environ.get("LCR_PRESET") or None   # (what the single-env facade classes, whose constructors are the reference's, can be switched with)
         if preset is None:
             check(self.L.lcr_config_default(ctypes.byref(cfg), TASKS[self.task_name]))
         else:

@@ -1661,7 +1661,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
 /* ------------------------------------------------------------------------------------------------ */
 /* glue: reach_cube_env.py:141-348 and the per-task deltas                                          */
 /* ------------------------------------------------------------------------------------------------ */
-void orc_default_params(orc_params *p, int task) {
+static void params_base(orc_params *p, int task) {   /* the reference's constructor defaults + the rounds 1-4 solver settings (preset "fast") */
     memset(p, 0, sizeof *p);
     p->task = task;
     p->action_mode = ORC_ACTION_JOINT;   /* reach:80 */
@@ -1690,10 +1690,11 @@ void orc_default_params(orc_params *p, int task) {
     p->solver = 0;    /* PGS (what the kernels run) */
     p->jacobi = task == ORC_TASK_PUSH_LOOP ? 0 : 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
-    p->newton_iters = 10; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-4;   /* (read by solver = 2 only) */
+    p->newton_iters = 10; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-4;   /* (read by solver = 2 only; = lcr_config_default) */
 }
+void orc_default_params(orc_params *p, int task) { orc_preset_params(p, task, ORC_PRESET_FAITHFUL); }
 void orc_preset_params(orc_params *p, int task, int preset) {
-    orc_default_params(p, task);
+    params_base(p, task);
     if (preset == ORC_PRESET_FAITHFUL) {
         p->solver = 2;                       /* Newton on the primal: MuJoCo's default solver (follower.xml:3 names none) */
         p->condim6 = 2;                      /* follower.xml:15 condim="6" on every finger contact */

@@ -125,6 +125,8 @@ class Oracle:
             if not hasattr(self.params, k):
                 raise AttributeError(k)
             setattr(self.params, k, v)
+        if self.params.solver == 2 and any(k in kw for k in ("pgs_iters", "cone", "jacobi", "pgs_tol", "pgs_cap")):
+            raise ValueError("sweep parameters (pgs_iters, cone, jacobi, pgs_tol, pgs_cap) belong to preset='fast' (solver = 0); the default preset runs Newton's method")
         self.nq = self.L.orc_nq(self.task)
         self.nv = self.L.orc_nv(self.task)
         self.action_dim = self.L.orc_action_dim(ctypes.byref(self.params))

@@ -36,9 +36,20 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.distance_threshold == 0.05 and cfg.cube_xy_range == 0.3 and cfg.n_substeps == 20
         assert cfg.max_episode_steps == 50                        # gym_lowcostrobot/__init__.py:12
         assert cfg.impratio == 100.0
-        assert cfg.finger_cube_condim == (6 if task in ("push_loop", "stack") else 4)   # rolling rows where they matter
-        assert cfg.step_kernel == 0 and cfg.cc_points == 0          # kernel family by task and job size; default cube<->cube manifold (4 points)
+        # the default is the FAITHFUL preset (ABI v5): the contact model as the reference's MJCF states it, solved by MuJoCo's default algorithm
+        assert cfg.solver == _capi.SOLVERS["newton"]                 # follower.xml:3 names no solver -> Newton
+        assert cfg.finger_cube_condim == 6 and cfg.finger_floor_condim == 6   # follower.xml:15 condim="6" on every finger contact
+        assert cfg.cc_points == (8 if task == "stack" else 0)       # stack_two_cubes.xml:25-35: box-box, up to eight points
+        assert cfg.newton_iters == 10 and cfg.ls_iters == 8 and cfg.newton_tol == 1e-6 and cfg.ls_tol == 1e-4
+        assert cfg.step_kernel == 0
         assert cfg.global_envs == 0                                  # ABI v4: this handle is the whole job
+        fast = _capi.LcrConfig()
+        assert hip_lib.lcr_config_preset(ctypes.byref(fast), tid, _capi.PRESETS["fast"]) == 0
+        assert fast.solver == _capi.SOLVERS["pgs"] and fast.pgs_iters == 4 and fast.cc_points == 0 and fast.finger_floor_condim == 4
+        assert fast.finger_cube_condim == (6 if task in ("push_loop", "stack") else 4)   # rounds 1-4: rolling rows where they matter
+        same = _capi.LcrConfig()
+        assert hip_lib.lcr_config_preset(ctypes.byref(same), tid, _capi.PRESETS["faithful"]) == 0
+        assert bytes(same) == bytes(cfg)
         k = hip_lib.lcr_action_dim(ctypes.byref(cfg))
         assert k == (5 if task in ("reach", "push", "push_loop") else 6)  # block_gripper defaults reach:82 / lift:82
         cfg.action_mode = _capi.ACTION_MODES["ee"]
@@ -66,13 +77,16 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
     cfg.finger_cube_condim = 5
     assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
     assert b"finger_cube_condim" in hip_lib.lcr_last_error()
-    for field, bad, msg in (("step_kernel", 3, b"step_kernel"), ("cc_points", 6, b"cc_points")):
-        hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS["stack"])
+    assert hip_lib.lcr_config_preset(ctypes.byref(cfg), 0, 7) == _capi.LCR_ERR_INVALID
+    assert b"preset" in hip_lib.lcr_last_error()
+    FAST = _capi.PRESETS["fast"]
+    for field, bad, msg in (("step_kernel", 3, b"step_kernel"), ("cc_points", 6, b"cc_points"), ("solver", 2, b"solver"), ("finger_floor_condim", 5, b"finger_floor_condim")):
+        hip_lib.lcr_config_preset(ctypes.byref(cfg), _capi.TASKS["stack"], FAST)
         setattr(cfg, field, bad)
         assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_INVALID
         assert msg in hip_lib.lcr_last_error()
-    hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS["stack"])
-    cfg.cc_points, cfg.pgs_iters = 8, -1          # the eight-point manifold lives in the two-wave kernels, the converged mode in the one-wave kernels
+    hip_lib.lcr_config_preset(ctypes.byref(cfg), _capi.TASKS["stack"], FAST)
+    cfg.cc_points, cfg.pgs_iters = 8, -1          # (sweeps) the eight-point manifold lives in the two-wave kernels, the converged mode in the one-wave kernels
     assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LCR_ERR_UNSUPPORTED
     # combinations no kernel implements are refused instead of silently degraded (each check runs before any device is touched)
     for task, setup, code, msg in (
@@ -85,8 +99,13 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
         ("push", dict(diagnostics=-1), _capi.LCR_ERR_INVALID, b"diagnostics must be"),
         ("push", dict(global_envs=-5), _capi.LCR_ERR_INVALID, b"global_envs"),
         ("push", dict(n_envs=64, env_id_offset=100, global_envs=128), _capi.LCR_ERR_INVALID, b"does not lie inside the job"),
+        # the Newton kernels (faithful preset) carry six-row finger contacts and are one-wave kernels; six-row finger<->floor contacts exist only there
+        ("push", dict(solver=1, finger_cube_condim=4), _capi.LCR_ERR_UNSUPPORTED, b"six-row finger contacts"),
+        ("push", dict(solver=1, finger_cube_condim=6, finger_floor_condim=6, step_kernel=2), _capi.LCR_ERR_UNSUPPORTED, b"one-wave kernels"),
+        ("push", dict(finger_floor_condim=6), _capi.LCR_ERR_UNSUPPORTED, b"Newton kernels"),
+        ("push", dict(solver=1, finger_cube_condim=6, finger_floor_condim=6, newton_iters=0), _capi.LCR_ERR_INVALID, b"newton_iters"),
     ):
-        hip_lib.lcr_config_default(ctypes.byref(cfg), _capi.TASKS[task])
+        hip_lib.lcr_config_preset(ctypes.byref(cfg), _capi.TASKS[task], FAST)
         for k, v in setup.items():
             setattr(cfg, k, v)
         assert hip_lib.lcr_create(ctypes.byref(cfg), ctypes.byref(h)) == code, (task, setup)

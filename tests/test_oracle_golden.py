@@ -306,7 +306,7 @@ def test_pinch_grasp_holds_the_cube():
     assert np.abs(o.qpos[0, 6:9] - 0.5 * (sph[0] + sph[1])).max() < 1e-3   # still centred between the fingers
     assert o.qpos[0, 8] > 0.15 and abs(o.qvel[0, 8]) < 1e-2                # and still up in the air
     rows, cons, _ = o.diag()
-    assert cons == 2 and rows == 8
+    assert cons == 2 and rows == 12   # (two finger<->cube contacts of six rows each: follower.xml:15 condim="6")
     h = orc.Oracle("pick_place", 1, auto_reset=0, max_episode_steps=0)
     h.reset(seeds=[0])
     util.pinch_setup(h)
@@ -413,7 +413,7 @@ def test_kat_resting_penetration_of_the_soft_contact_model():
         d = d0 + y * (dmax - d0)
         R = (1 - d) / d * (1.0 / m)
         r = (m * g / 4) * R / (k * d)
-    o = orc.Oracle("reach", 1, auto_reset=0, max_episode_steps=0, pgs_iters=30)
+    o = orc.Oracle("reach", 1, auto_reset=0, max_episode_steps=0, preset="fast", pgs_iters=30)
     o.reset(seeds=[0])
     o.qpos[0, 6:9] = [0.3, 0.3, 0.015]
     for _ in range(40):
@@ -455,7 +455,7 @@ def test_kat_warm_start_four_sweeps_near_converged_solution():
     over three control steps, closer than 10 cold sweeps; the rounds 1-3 iteration (rows + radial projection, cone = 0) is an order of magnitude further away
     (its fixed point is not the optimum: tools/kkt_distance.py)"""
     def run(**kw):
-        o = orc.Oracle("push", 16, auto_reset=0, max_episode_steps=0, **kw)
+        o = orc.Oracle("push", 16, auto_reset=0, max_episode_steps=0, preset="fast", **kw)
         o.reset(seeds=np.arange(16))
         rng = np.random.default_rng(0)
         for _ in range(3):
@@ -546,8 +546,8 @@ def test_converged_mode_reaches_the_tolerance():
     errs = {}
     for name, kw in (("adaptive", dict(pgs_iters=-1, pgs_tol=1e-8)), ("adaptive500", dict(pgs_iters=-1, pgs_tol=1e-8, pgs_cap=500)), ("four", dict(pgs_iters=4)),
                      ("legacy", dict(pgs_iters=-1, pgs_tol=1e-8, cone=0))):
-        o = orc.Oracle("push", n, **kw)
-        ref = orc.Oracle("push", n, solver=1, kkt=True)
+        o = orc.Oracle("push", n, preset="fast", **kw)
+        ref = orc.Oracle("push", n, preset="fast", solver=1, kkt=True)
         for s in (o, ref):
             s.reset(seeds=np.arange(n))
         rng = np.random.default_rng(1)
@@ -619,7 +619,9 @@ def test_rolling_rows_of_the_finger_cube_contacts():
             res[task, c6] = o.qvel[:, 9:12].copy()
     assert np.abs(res["push_loop", 0][:, 1]).min() > 0.1 and np.abs(res["push_loop", 1][:, 1]).max() < 0.01, (res["push_loop", 0][0], res["push_loop", 1][0])
     assert np.abs(res["lift", 1] - res["lift", 0]).max() < 1e-2 * np.abs(res["lift", 0]).max()
-    assert [orc.Oracle(t, 1).params.condim6 for t in ("reach", "lift", "push", "pick_place", "stack", "push_loop")] == [0, 0, 0, 0, 1, 1]   # defaults by task
+    TASKS6 = ("reach", "lift", "push", "pick_place", "stack", "push_loop")
+    assert [orc.Oracle(t, 1).params.condim6 for t in TASKS6] == [2] * 6                              # default (preset "faithful"): six rows on every finger contact
+    assert [orc.Oracle(t, 1, preset="fast").params.condim6 for t in TASKS6] == [0, 0, 0, 0, 1, 1]   # preset "fast": rolling rows where they matter (D4)
 
 
 def test_carrying_the_constraint_forces_across_control_steps_is_more_accurate():

@@ -18,7 +18,7 @@ STATE = ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time
 
 
 def _rollout(task, n, steps, seed=0, **kw):
-    o = orc.Oracle(task, n, kkt=True, auto_reset=0, max_episode_steps=0, **kw)
+    o = orc.Oracle(task, n, kkt=True, auto_reset=0, max_episode_steps=0, **({} if "solver" in kw or "preset" in kw else {"preset": "fast"}), **kw)
     o.reset(seeds=np.arange(n, dtype=np.uint64) + 5)
     rng = np.random.default_rng(seed)
     worst = np.zeros(n)
@@ -60,10 +60,10 @@ def test_two_independent_algorithms_reach_the_same_optimum():
     """the block projected-gradient iteration (dual, first order) swept to convergence and the Newton solve (primal, second order) share no code beyond the problem
     data: from identical states incl. carried forces they land on the same accelerations"""
     n = 48
-    walk = orc.Oracle("push", n, auto_reset=0, max_episode_steps=0)
-    pg = orc.Oracle("push", n, kkt=True, auto_reset=0, max_episode_steps=0, pgs_iters=-1, pgs_tol=1e-12, pgs_cap=20000)
-    qc = orc.Oracle("push", n, kkt=True, auto_reset=0, max_episode_steps=0, pgs_iters=-1, pgs_tol=1e-12, pgs_cap=20000, cone=1)
-    nt = orc.Oracle("push", n, kkt=True, auto_reset=0, max_episode_steps=0, solver=1)
+    walk = orc.Oracle("push", n, auto_reset=0, max_episode_steps=0, preset="fast")
+    pg = orc.Oracle("push", n, kkt=True, auto_reset=0, max_episode_steps=0, preset="fast", pgs_iters=-1, pgs_tol=1e-12, pgs_cap=20000)
+    qc = orc.Oracle("push", n, kkt=True, auto_reset=0, max_episode_steps=0, preset="fast", pgs_iters=-1, pgs_tol=1e-12, pgs_cap=20000, cone=1)
+    nt = orc.Oracle("push", n, kkt=True, auto_reset=0, max_episode_steps=0, preset="fast", solver=1)
     walk.reset(seeds=np.arange(n, dtype=np.uint64) + 9)
     rng = np.random.default_rng(2)
     d_pg, d_qc = [], []
@@ -96,9 +96,9 @@ def test_default_four_sweeps_distance_from_the_optimum():
     """the number DESIGN.md quotes for deviation D1 (tools/kkt_distance.py at larger n): one control step of the default solve against the exact optimum from identical
     states incl. carried forces -- median at rounding level, 90th percentile below 1e-3, and closer than the rounds 1-3 iteration at the 90th / 99th percentile"""
     n = 128
-    walk = orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0)
-    var = {"default": orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0), "legacy": orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0, cone=0),
-           "exact": orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0, solver=1)}
+    walk = orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0, preset="fast")
+    var = {"default": orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0, preset="fast"), "legacy": orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0, preset="fast", cone=0),
+           "exact": orc.Oracle("reach", n, auto_reset=0, max_episode_steps=0, preset="fast", solver=1)}
     walk.reset(seeds=np.arange(n, dtype=np.uint64) + 77)
     rng = np.random.default_rng(5)
     d = {"default": [], "legacy": []}

@@ -13,11 +13,11 @@ COLD = 2   # ORC_COMPAT_COLD_SOLVE_EACH_STEP
 
 
 def measure(task, n=512, steps=50, seed=3):
-    cold = orc.Oracle(task, n, pgs_iters=4, compat=COLD, auto_reset=0, max_episode_steps=0)
-    carried = orc.Oracle(task, n, pgs_iters=4, compat=0, auto_reset=0, max_episode_steps=0)
+    cold = orc.Oracle(task, n, preset="fast", pgs_iters=4, compat=COLD, auto_reset=0, max_episode_steps=0)
+    carried = orc.Oracle(task, n, preset="fast", pgs_iters=4, compat=0, auto_reset=0, max_episode_steps=0)
     # reference: the EXACT optimum of every substep's convex problem (primal Newton, orc_params.solver = 1, certified by orc_io.kkt) -- rounds 1-3 compared
     # against 300 cold sweeps of the same iteration, whose fixed point was not the optimum (tools/kkt_distance.py)
-    ref = orc.Oracle(task, n, solver=1, auto_reset=0, max_episode_steps=0)
+    ref = orc.Oracle(task, n, preset="fast", solver=1, auto_reset=0, max_episode_steps=0)
     seeds = np.arange(n, dtype=np.uint64) + 1000
     for o in (cold, carried, ref):
         o.reset(seeds)
