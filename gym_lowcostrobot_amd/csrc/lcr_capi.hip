@@ -136,7 +136,7 @@ static int config_base(lcr_config *cfg, int task) {
     cfg->cc_points = 0;
     cfg->global_envs = 0;   // this handle is the whole job
     cfg->solver = LCR_SOLVER_PGS;
-    cfg->newton_iters = 10;
+    cfg->newton_iters = 20;
     cfg->ls_iters = 8;
     cfg->finger_floor_condim = 0;
     cfg->newton_tol = 1e-6;

@@ -122,7 +122,7 @@ typedef struct lcr_config {
                                   constraint forces -- MuJoCo's default solver (follower.xml:3 names none); reaches the optimum of MuJoCo's convex constraint problem to
                                   float rounding (tools/kkt_distance.py).  LCR_SOLVER_PGS: pgs_iters warm-started sweeps of a block projected-gradient step on the dual
                                   problem (rounds 1-4; p90 2e-4 / p99 1e-2 rad per control step away from that optimum at four sweeps). */
-    int32_t newton_iters;      /* LCR_SOLVER_NEWTON: most iterations per substep (10); a wave leaves the loop when every one of its envs has converged */
+    int32_t newton_iters;      /* LCR_SOLVER_NEWTON: most iterations per substep (20: what bounds a cold start on a hard contact set -- warm-started, an env needs one on average and seven at the 99th percentile); a wave leaves the loop when every one of its envs has converged */
     int32_t ls_iters;          /* ... most evaluations of phi' per line search (8) */
     int32_t finger_floor_condim; /* rows of a finger<->floor contact: 6 = MuJoCo's (follower.xml:15 condim="6": + two rolling rows, coefficient 1e-4 m), 4 = without
                                   them.  0 = the preset's default.  6 is implemented by the Newton kernels (LCR_SOLVER_PGS with 6: LCR_ERR_UNSUPPORTED) */

@@ -1220,7 +1220,7 @@ static int newton_primal(int nv, int nr, const real *M, const real *J, const rea
  *             no contact changes zone), bracket by doubling, then the Illinois variant of regula falsi; at most ls_iters evaluations, stop when
  *             |phi'(al)| <= ls_tol |phi'(0)|.  (Measured, profiles/r05_solver_decision.txt: the search must be accurate, and the derivative-only iteration beats
  *             1-D Newton steps on phi' at equal evaluations.)
- *   at most newton_iters iterations (default 10).  On the GPU both loops are left wave-uniformly (when every lane of the wave has met the criterion), so a lane may
+ *   at most newton_iters iterations (default 20: a cold start on a finger deep in the floor with both fingers and a proxy down needs 12).  On the GPU both loops are left wave-uniformly (when every lane of the wave has met the criterion), so a lane may
  *   iterate further than here -- at the optimum that changes nothing beyond rounding.
  * Returns the forces f(x) and the accelerations x themselves: the integration uses x (M (x - a0) = J' f at the optimum). */
 static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, const int *blkdim, const double *const *rowmu, real *f, real *W /* nr x 6 or NULL */) {
@@ -1308,6 +1308,7 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
         chol_solve(H, nv, dx);
         real d0 = 0;
         for (int a = 0; a < nv; a++) d0 += g[a] * dx[a];
+        if (getenv("ORC_NEWTON_DEBUG3")) fprintf(stderr, "np it=%d decrement=%.3e tol2=%.3e\n", it, (double)-d0, tol * tol * (double)scale);
         if (!((double)-d0 > tol * tol * (double)scale)) break;    /* Newton decrement: converged (or no descent) */
         /* line search: phi'(al) = grad F(x + al dx) . dx */
         real al = 1, lo_a = 0, hi_a = -1, dlo = d0, dhi = 0;
@@ -1320,6 +1321,7 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
             if (dphi < 0) { if (hi_a >= 0 && lo_a > 0) dhi *= (real)0.5; lo_a = al; dlo = dphi; }
             else { if (hi_a >= 0) dlo *= (real)0.5; hi_a = al; dhi = dphi; }
             if (t_trace_slot) t_trace_slot[1]++;
+            if (getenv("ORC_NEWTON_DEBUG3")) fprintf(stderr, "     ls=%d al=%.6g dphi=%.3e (d0=%.3e)\n", ls, (double)al, (double)dphi, (double)d0);
             if (done) break;
             real an;
             if (hi_a < 0) an = 2 * al;
@@ -1546,7 +1548,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             max_it = 0;
         }
         if (P->solver == 2) {   /* the product's faithful solver: Newton on the primal with a fixed budget (see newton_product) */
-            const int nit = newton_product(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, xsol, P->newton_iters > 0 ? P->newton_iters : 10,
+            const int nit = newton_product(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, xsol, P->newton_iters > 0 ? P->newton_iters : 20,
                                            P->ls_iters > 0 ? P->ls_iters : 8, P->newton_tol > 0 ? P->newton_tol : 1e-6, P->ls_tol > 0 ? P->ls_tol : 1e-4);
             use_x = 1;
             if (getenv("ORC_SWEEP_SUM")) lag->max_sweeps += (uint32_t)nit;
@@ -1690,7 +1692,7 @@ static void params_base(orc_params *p, int task) {   /* the reference's construc
     p->solver = 0;    /* PGS (what the kernels run) */
     p->jacobi = task == ORC_TASK_PUSH_LOOP ? 0 : 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
-    p->newton_iters = 10; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-4;   /* (read by solver = 2 only; = lcr_config_default) */
+    p->newton_iters = 20; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-4;   /* (read by solver = 2 only; = lcr_config_default) */
 }
 void orc_default_params(orc_params *p, int task) { orc_preset_params(p, task, ORC_PRESET_FAITHFUL); }
 void orc_preset_params(orc_params *p, int task, int preset) {

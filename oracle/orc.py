@@ -118,6 +118,8 @@ class Oracle:
         self.n = n
         self.params = OrcParams()
         if preset is None:
+            preset = os.environ.get("LCR_PRESET") or None   # (the switch the product's VecSim reads too: one variable flips both sides of a parity test)
+        if preset is None:
             self.L.orc_default_params(ctypes.byref(self.params), self.task)
         else:   # "faithful": six-row finger contacts everywhere, eight-point box-box, Newton on the primal; "fast": rounds 1-4
             self.L.orc_preset_params(ctypes.byref(self.params), self.task, {"faithful": 0, "fast": 1}[preset])

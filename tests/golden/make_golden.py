@@ -239,11 +239,12 @@ def main():
                                    "target": captured["target"].tolist(), "ctrl5": float(np.asarray(env.data.ctrl)[5])})
 
     # ---- inverse_kinematics loop (reach:148-221) run UNMODIFIED, with mj_forward / mj_jacSite / site xpos served by
-    #      this repo's kinematics (oracle FK and Jacobian, themselves pinned to the SURVEY.md 8(c) known answers).
+    #      plain-numpy kinematics derived from the extracted model numbers alone (tests/golden/kin_numpy.py: no oracle, no kernel code -- VERDICT r4 weak #1a).
     #      Pins the reference's own loop arithmetic: DLS solve, unit-norm clamp, 0.5 step, joint limits, early break,
     #      and the qpos overwrite (REF-QUIRK-3).
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-    from oracle import orc as _orc
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kin_numpy
+    _arm = kin_numpy.Arm()
     import mujoco as _mj
 
     class _IKData(_FakeData):
@@ -255,11 +256,11 @@ def main():
             return _Site(self._site)
 
     def _mj_forward(model, data):
-        data._site[:] = _orc.fk(np.array(data.qpos[:6], dtype=np.float64))[1]
+        data._site[:] = _arm.site(np.array(data.qpos[:6], dtype=np.float64))
 
     def _mj_jacsite(model, data, jacp, jacr, sid):
         jacp[:] = 0
-        jacp[:, :6] = _orc.site_jac(np.array(data.qpos[:6], dtype=np.float64))
+        jacp[:, :6] = _arm.site_jac(np.array(data.qpos[:6], dtype=np.float64))
 
     _mj.mj_forward = _mj_forward
     _mj.mj_jacSite = _mj_jacsite
@@ -272,7 +273,7 @@ def main():
         q0 = rng.uniform(-1.2, 1.2, 6)
         q0[5] = rng.uniform(-2.45, 0.06)  # occasionally beyond the upper gripper limit: IK clamps it (teleport of joint 6)
         env.data.qpos[:6] = q0
-        site0 = _orc.fk(q0)[1]
+        site0 = _arm.site(q0)
         reach = rng.choice([0.004, 0.03, 0.08, 0.25])
         tgt = site0 + rng.normal(0, 1, 3) * reach
         tgt[2] = max(0.0, tgt[2])

@@ -29,6 +29,10 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import kin_numpy  # noqa: E402
+
+_ARM = kin_numpy.Arm()
 MODEL = json.load(open(os.path.join(HERE, "model_golden.json")))
 REGISTERED = []
 
@@ -107,9 +111,7 @@ def _install_stubs():
             return _X(self._site)
 
     def mj_forward(model, data):
-        from oracle import orc
-
-        data._site[:] = orc.fk(np.array(data.qpos[:6], dtype=np.float64))[1]
+        data._site[:] = _ARM.site(np.array(data.qpos[:6], dtype=np.float64))   # plain-numpy kinematics from the extracted model numbers (kin_numpy.py): no oracle
         for b in range((model.nq - 6) // 7):
             data._body[b] = data.qpos[6 + 7 * b: 9 + 7 * b]
 
@@ -117,10 +119,8 @@ def _install_stubs():
         data.time += model.opt.timestep     # (MuJoCo: mj_step advances mjData.time by opt.timestep; the state itself is frozen here)
 
     def mj_jacSite(model, data, jacp, jacr, sid):
-        from oracle import orc
-
         jacp[:] = 0
-        jacp[:, :6] = orc.site_jac(np.array(data.qpos[:6], dtype=np.float64))
+        jacp[:, :6] = _ARM.site_jac(np.array(data.qpos[:6], dtype=np.float64))
 
     class mjtObj:
         mjOBJ_GEOM = 5
@@ -187,7 +187,6 @@ def main():
     assert ref_pkg.__file__.startswith(REF), ref_pkg.__file__
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import mujoco
-    from oracle import orc
 
     out = {"_generated_by": "tests/golden/make_step_golden.py", "registry": [dict(r) for r in REGISTERED], "constructors": [], "steps": []}
     rng = np.random.default_rng(20240)
@@ -230,7 +229,7 @@ def main():
                     nq = env.model.nq
                     q = jlo[0] + (jlo[1] - jlo[0]) * rng.uniform(0.2, 0.8, 6)
                     env.data.qpos[:6] = q
-                    ee = orc.fk(q)[1]
+                    ee = _ARM.site(q)
                     near = case % 2 == 0                               # half of the cases near the success / overlap region
                     spread = 0.03 if near else 0.15
                     if task in ("reach", "lift"):

@@ -24,16 +24,25 @@ N = 512
 MAX_DQ, MAX_DV = util.MAX_DQ, util.MAX_DV
 
 
-@pytest.fixture(autouse=True, params=["auto", "single"])
+@pytest.fixture(autouse=True, params=["faithful", "auto", "single"])
 def kernel_family(request, monkeypatch):
-    """every test of this module runs against both step-kernel families: "auto" = what lcr_create dispatches for the shard size (test sizes:
-    the two-cooperating-waves kernels of lcr_kernels2.hip; larger shards: test_default_dispatch_of_the_step_kernel_families) and "single" = the one-wave-per-64-envs
-    kernels of lcr_kernels.hip forced at every size (LCR_STEP_KERNEL, read by lcr_create)"""
-    if request.param != "auto":
-        monkeypatch.setenv("LCR_STEP_KERNEL", request.param)
+    """every test of this module runs against the product's default -- "faithful": the Newton kernels, six-row finger contacts, eight-point box-box (both sides of a
+    pair at their defaults) -- and against both step-kernel families of preset "fast" (LCR_PRESET, read by VecSim and by the oracle binding): "auto" = what lcr_create
+    dispatches for the shard size (test sizes: the two-cooperating-waves kernels of lcr_kernels2.hip; larger shards: test_default_dispatch_of_the_step_kernel_families)
+    and "single" = the one-wave-per-64-envs kernels of lcr_kernels.hip forced at every size (LCR_STEP_KERNEL, read by lcr_create)"""
+    monkeypatch.delenv("LCR_STEP_KERNEL", raising=False)
+    if request.param == "faithful":
+        monkeypatch.delenv("LCR_PRESET", raising=False)
     else:
-        monkeypatch.delenv("LCR_STEP_KERNEL", raising=False)
+        monkeypatch.setenv("LCR_PRESET", "fast")
+        if request.param != "auto":
+            monkeypatch.setenv("LCR_STEP_KERNEL", request.param)
     return request.param
+
+
+def _sweeps_only(kernel_family):
+    if kernel_family == "faithful":
+        pytest.skip("a property of the sweep kernels (preset fast)")
 
 
 def _cmp_step(sim, o, rng, steps, atol_q=2e-5, atol_v=2e-3, frac=0.99, act_scale=1.0, max_dq=MAX_DQ, max_dv=MAX_DV):
@@ -390,7 +399,7 @@ def test_pinch_grasp_finger_cube_contacts(hip_lib, monkeypatch, task, carry):
 
 @pytest.mark.parametrize("carry", [False, True], ids=["cold", "carry"])
 @pytest.mark.parametrize("task", ["lift", "stack", "push_loop", "pick_place"])
-def test_rolling_rows_finger_cube_condim6(hip_lib, monkeypatch, task, carry):
+def test_rolling_rows_finger_cube_condim6(hip_lib, kernel_family, monkeypatch, task, carry):
     """finger_cube_condim = 6: the finger<->cube slots carry MuJoCo's two rolling-friction rows (follower.xml:15 condim="6"; rolling
     coefficient 1e-4, PushCubeLoop 1.5); pinched cube (both slots active in every env) and a free rollout, kernel vs oracle(condim6=1)"""
     monkeypatch.setattr(util, "CARRY_DEFAULT", carry)   # both sides start each step from the oracle's carried forces / from zero forces
@@ -413,8 +422,12 @@ def test_rolling_rows_finger_cube_condim6(hip_lib, monkeypatch, task, carry):
         # (every outlier is explained: parity_step; the pinched 50 g PushCubeLoop cube with torsional / rolling coefficients 1.5 is a stiff
         #  12-row problem that 4 PGS sweeps leave far from converged: the documented exception.  Observed over both kernel families and both
         #  solver-start modes: 243-247 of the 256 envs within tolerance; WHICH envs fall out moves with the families' rounding)
-        assert ok.mean() >= (0.94 if task == "push_loop" else 0.99), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
+        #  -- of the SWEEP kernels only: Newton's method (the default preset) solves that problem, and the pinched cube is held to the 0.99 of every other test)
+        assert ok.mean() >= (0.94 if task == "push_loop" and kernel_family != "faithful" else 0.99), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
         assert ((o.active_mask >> 12) & 3).astype(bool).mean() > 0.5 or t > 2   # finger<->cube slots really are active
+    if kernel_family == "faithful":   # (the Newton kernels have no four-row variant to compare with)
+        sim.close()
+        return
     # the rolling rows change the result (else the test would not see them): same state, kernel without them
     sim4, o4 = util.make_pair(task, n, auto_reset=False, max_episode_steps=0, finger_cube_condim=4)
     for name in ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time"):
@@ -665,8 +678,9 @@ def test_link_proxy_contacts(hip_lib, monkeypatch, task, bit, near, mode, carry)
 
 @pytest.mark.parametrize("carry", [False, True], ids=["cold", "carry"])
 @pytest.mark.parametrize("task", ["reach", "lift", "stack"])
-def test_converged_solver_mode(hip_lib, monkeypatch, task, carry):
+def test_converged_solver_mode(hip_lib, kernel_family, monkeypatch, task, carry):
     """pgs_iters = -1: sweep until the force change of a sweep is <= pgs_tol (1 + max |f|) (kernel: in every lane of the wave)"""
+    _sweeps_only(kernel_family)
     monkeypatch.setattr(util, "CARRY_DEFAULT", carry)   # both sides start each step from the oracle's carried forces / from zero forces
     rng = np.random.default_rng(9)
     n = 256
@@ -725,10 +739,11 @@ def test_image_observations_vs_cpu_raycaster(hip_lib, task):
 
 
 @pytest.mark.parametrize("which", ["rollout_joint", "rollout_ee", "cube_on_cube", "rolling_rows", "link_proxy", "converged"])
-def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which):
+def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, kernel_family, monkeypatch, which):
     """StackTwoCubes has two kernel variants: shards of at most three waves per CU (<= 49 152 envs on an MI355X; every other Stack test
     here) keep all g rows in LDS; larger ones keep the proxy slot's and the rolling rows in a global scratch array.  LCR_STACK_LDS=small
     forces the second variant at test sizes."""
+    _sweeps_only(kernel_family)
     monkeypatch.setenv("LCR_STACK_LDS", "small")
     monkeypatch.setenv("LCR_STEP_KERNEL", "single")   # (the storage variants belong to the one-wave kernels)
     if which == "rollout_joint":
@@ -745,9 +760,10 @@ def test_stack_variant_with_g_rows_in_global_scratch(hip_lib, monkeypatch, which
         test_converged_solver_mode(hip_lib, monkeypatch, "stack", False)
 
 
-def test_stack_variants_are_bit_identical(hip_lib, monkeypatch):
+def test_stack_variants_are_bit_identical(hip_lib, kernel_family, monkeypatch):
     """the two Stack kernel variants (g rows in LDS / partly in global scratch) differ in storage only: same bits out, so a Stack
     batch gives the same trajectory whatever the shard size selects"""
+    _sweeps_only(kernel_family)
     n = 512
     sims = []
     monkeypatch.setenv("LCR_STEP_KERNEL", "single")
@@ -768,10 +784,11 @@ def test_stack_variants_are_bit_identical(hip_lib, monkeypatch):
                                                   ("pick_place", "ee", 4, None), ("lift", "joint", 6, None), ("push_loop", "joint", 6, None),
                                                   ("push_loop", "ee", 4, None), ("stack", "joint", 6, "small"), ("stack", "ee", 6, "small"),
                                                   ("stack", "ee", 4, "small"), ("stack", "joint", 6, "big"), ("stack", "ee", 6, "big")])
-def test_every_kernel_variant_is_deterministic(hip_lib, monkeypatch, task, mode, condim, lds):
+def test_every_kernel_variant_is_deterministic(hip_lib, kernel_family, monkeypatch, task, mode, condim, lds):
     """the same (state, action) stepped four times gives the same bits, and a converged-mode step too -- every template variant of
     the step kernel (this test found a scalar-store / float2-load aliasing violation that let the compiler move g-row loads above
     their stores in ONE variant: results differed by 1e-6 from launch to launch)"""
+    _sweeps_only(kernel_family)
     if lds:
         monkeypatch.setenv("LCR_STACK_LDS", lds)
     n = 512
@@ -889,12 +906,13 @@ def test_graft_entry_smoke(hip_lib):
 
 
 @pytest.mark.parametrize("task,mode", [("reach", "joint"), ("push", "joint"), ("lift", "joint"), ("pick_place", "ee"), ("stack", "joint")])
-def test_kernel_families_agree_and_are_race_free(hip_lib, monkeypatch, task, mode):
+def test_kernel_families_agree_and_are_race_free(hip_lib, kernel_family, monkeypatch, task, mode):
     """the one-wave kernels and both variants of the two-cooperating-waves kernels (compiled for one / two waves per SIMD) step the same
     states to the same result within fp32 rounding (they group the same arithmetic differently), take the same discrete decisions, and
     the two-wave kernels give the same bits run after run (their LDS hand-overs between the arm wave and the cube wave are ordered by
     barriers: a missing one shows up as run-to-run differences -- found once, in round 3's two-wave PushCubeLoop kernel; that task has one kernel since
     round 4, lcr_kernels_loop.hip)"""
+    _sweeps_only(kernel_family)
     n = 4096
     sims = {}
     for fam in ("single", "coop1", "coop2", "coop2b"):
@@ -937,6 +955,7 @@ def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, mo
     Stack jobs of <= 32 768 envs, the one-wave kernels for larger Stack jobs; PushCubeLoop has one kernel (one wave per 64 envs; pinning the two-wave
     family is refused); the converged solver mode always runs the one-wave kernels.  Which BUILD of the two-wave family a
     shard runs (one / two waves per SIMD: 1 / 2) follows the shard size.  (MI355X: 256 CUs -> one wave per SIMD up to 32 768 envs.)"""
+    _sweeps_only(kernel_family)
     import torch
     from gym_lowcostrobot_amd import VecSim
 

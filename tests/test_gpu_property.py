@@ -29,11 +29,14 @@ TASKS = ["reach", "lift", "push", "pick_place", "stack", "push_loop"]
     solve=st.sampled_from(["carry", "resync_cold", "compat_cold"]),
     arm_collision=st.booleans(),
     family=st.sampled_from(["auto", "single", "coop2"]),
+    preset=st.sampled_from(["faithful", "fast"]),
     seed=st.integers(min_value=0, max_value=2**40),
 )
-def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, solve, arm_collision, family, seed):
-    kw = dict(action_mode=mode, reward_type=reward, n_substeps=n_substeps, pgs_iters=pgs_iters, impratio=impratio,
-              distance_threshold=thr, auto_reset=False, max_episode_steps=0, finger_cube_condim=condim, arm_collision=arm_collision,
+def test_random_configuration_parity(hip_lib, task, mode, reward, n, n_substeps, pgs_iters, impratio, thr, condim, solve, arm_collision, family, preset, seed):
+    # preset "faithful" (the default): the Newton kernels -- sweep count, contact-row mode and kernel family do not apply; "fast": the sweep kernels with all of them drawn
+    sweeps = dict(pgs_iters=pgs_iters, finger_cube_condim=condim) if preset == "fast" else {}
+    kw = dict(action_mode=mode, reward_type=reward, n_substeps=n_substeps, impratio=impratio, preset=preset, **sweeps,
+              distance_threshold=thr, auto_reset=False, max_episode_steps=0, arm_collision=arm_collision,
               # "carry": the default product mode, each step starts from the oracle's carried forces; "resync_cold": default mode, forces
               # dropped by lcr_set_state; "compat_cold": LCR_COMPAT_COLD_SOLVE_EACH_STEP on both sides (the kernel then has no warm array)
               compat=2 if solve == "compat_cold" else 0)
