@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the bench line of the plain command (no profiler attached), default step counts
 python $REPO/bench.py $* > $OUT/bench_line.json 2> $OUT/bench_line.err
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --repeats 1 --no-cpu-baseline --calibrate 20 $*"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --repeats 1 --no-cpu-baseline --no-fast-side --calibrate 20 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o p -- $BENCH > $OUT/pmc_$C.log 2>&1
