@@ -5,8 +5,8 @@
 //     F(x) = 1/2 (x - a0)' M (x - a0) + sum_b s_b(J_b x - aref_b),      s_b(z) = max_{f in K_b} ( -f'z - 1/2 f'R_b f ),
 // the constraint forces are f_b = argmax.  Unknowns here: the arm in the coordinates y = L' qacc (M = L L': its metric is the identity) and per cube the linear
 // and angular acceleration (metric: mass, isotropic inertia).  One iteration: gradient g and Hessian H = M + J'WJ at x (W: Jacobian of -f w.r.t. the row
-// residuals), dx = -H^-1 g by Cholesky, line search on phi'(al) = grad F(x + al dx).dx (derivative only: one gradient pass per evaluation; Illinois variant of
-// regula falsi after bracketing), x += al dx.  Rounds 1-4 swept per-contact blocks of the DUAL problem; what those sweeps cannot resolve in any sane number of
+// residuals), dx = -H^-1 g by Cholesky, line search on phi'(al) = grad F(x + al dx).dx (one gradient pass per evaluation gives phi' and phi'': safeguarded Newton
+// steps on phi' from both ends of the bracket, see the loop), x += al dx.  Rounds 1-4 swept per-contact blocks of the DUAL problem; what those sweeps cannot resolve in any sane number of
 // passes is the redundancy of contacts that share a body (two fingers on the floor, the four vertices of a resting cube) -- here that is one 12 x 12 factorisation.
 #pragma once
 #include "lcr_step_common.h"
@@ -374,17 +374,29 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
             }
         }
     };
-    // sum over the constraints of f(zs + al jd) . jd: the constraint part of phi'(al) -- registers only (cube<->cube: their regulariser from LDS)
-    auto ls_eval = [&](float al) -> float {
-        float acc = 0.f;
+    // sum over the constraints of f(zs + al jd) . jd and of jd' W(zs + al jd) jd: the constraint parts of phi'(al) and phi''(al) -- registers only (cube<->cube: their
+    // regulariser from LDS).  Per block  jd'W jd = av (jd_n - u)^2 - gam u^2 + kap sum_t m2_t jd_t^2,  u = sum_t c_t jd_t  (the same av / gam / kap / c as in h_block)
+    struct LsVal { float f, h; };
+    auto ls_eval = [&](float al) -> LsVal {
+        float acc = 0.f, hac = 0.f;
         if (wave_lim) {
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 if (!((C.lim_wave >> j) & 1u)) continue;
                 const float z = fmaf(al, jd[Z_LIM + j], zs[Z_LIM + j]);
-                acc = fmaf(z < 0.f ? -z * lim_iR[j] : 0.f, jd[Z_LIM + j], acc);
+                const float wl = z < 0.f ? lim_iR[j] : 0.f;
+                acc = fmaf(-z * wl, jd[Z_LIM + j], acc);
+                hac = fmaf(wl * jd[Z_LIM + j], jd[Z_LIM + j], hac);
             }
         }
+        auto curv = [&](auto nr_tag, const auto &B, const auto &m2, int zoff) {
+            constexpr int NR = decltype(nr_tag)::value;
+            float u = 0.f, tt = 0.f;
+#pragma unroll
+            for (int r = 1; r < NR; r++) { u = fmaf(B.c[r], jd[zoff + r], u); tt = fmaf(m2[r] * jd[zoff + r], jd[zoff + r], tt); }
+            const float sn = jd[zoff] - u;
+            hac = fmaf(B.av * sn, sn, fmaf(-B.gam * u, u, fmaf(B.kap, tt, hac)));
+        };
         auto arm = [&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
             if (!arm_here(s)) return;
@@ -397,6 +409,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
             blk_eval<NR>(z, C.AS[s].Rn, C.AS[s].Rn * P.inv_impratio * m2[1], m2, C.AS[s].act, B);
 #pragma unroll
             for (int r = 0; r < NR; r++) acc = fmaf(B.f[r], jd[Z_ARM + 6 * s + r], acc);
+            curv(std::integral_constant<int, NR>{}, B, m2, Z_ARM + 6 * s);
         };
         arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
         arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
@@ -409,6 +422,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
             blk_eval<4>(z, Rn, Rn * P.inv_impratio * P.mu_c2, m2, act, B);
 #pragma unroll
             for (int q = 0; q < 4; q++) acc = fmaf(B.f[q], jd[zoff + q], acc);
+            curv(std::integral_constant<int, 4>{}, B, m2, zoff);
         };
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -428,7 +442,62 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
                 for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC + 15) * 64], C.cc_act[s], Z_CC + 4 * s);
             }
         }
-        return acc;
+        return LsVal{acc, hac};
+    };
+    // line-search fall-back (see the loop below): among the contact blocks whose N(al) = |w_t(zs + al jd)| has its minimiser inside the open bracket (lo, hi) AND that are
+    // in their sticking zone there (N_min Rn <= -w_n Rt), the minimiser closest to `sec`; none: `sec`
+    auto kink_cand = [&](float lo, float hi, float sec) -> float {
+        float best = sec, bestd = -1.f;
+        auto blk = [&](auto nr_tag, const auto &m2, float Rn, float Rt, bool act, int zoff) {
+            constexpr int NR = decltype(nr_tag)::value;
+            float qa = 0.f, qb = 0.f, qc = 0.f;
+#pragma unroll
+            for (int r = 1; r < NR; r++) {
+                const float mj = m2[r] * jd[zoff + r];
+                qa = fmaf(mj, jd[zoff + r], qa); qb = fmaf(mj, zs[zoff + r], qb); qc = fmaf(m2[r] * zs[zoff + r], zs[zoff + r], qc);
+            }
+            const float iqa = rcp(fmaxf(qa, 1e-30f));
+            const float am = -qb * iqa;
+            const float n2 = fmaxf(fmaf(-qb * qb, iqa, qc), 0.f), wn = fmaf(am, jd[zoff], zs[zoff]);
+            const bool ok = act && qa > 0.f && am > lo && am < hi && wn < 0.f && !(n2 * Rn * Rn > wn * wn * Rt * Rt);
+            const float dist = fabsf(am - sec);
+            const bool take = ok && (bestd < 0.f || dist < bestd);
+            best = take ? am : best;
+            bestd = take ? dist : bestd;
+        };
+        auto arm = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if (!arm_here(s)) return;
+            constexpr int NR = s < 4 ? 6 : 4;
+            float m2a[6], m2[NR];
+            arm_m2(s_tag, m2a);
+#pragma unroll
+            for (int r = 0; r < NR; r++) m2[r] = m2a[r];
+            blk(std::integral_constant<int, NR>{}, m2, C.AS[s].Rn, C.AS[s].Rn * P.inv_impratio * m2[1], C.AS[s].act, Z_ARM + 6 * s);
+        };
+        arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
+        arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
+        const float m2c[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
+        auto cube_con = [&](float Rn, bool act, int zoff) { blk(std::integral_constant<int, 4>{}, m2c, Rn, Rn * P.inv_impratio * P.mu_c2, act, zoff); };
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (!HAS_C[c] || !fl_any[c]) continue;
+#pragma unroll
+            for (int s = 0; s < 4; s++) cube_con(C.FS[c][s].Rn, C.FS[c][s].act, Z_FLOOR + 16 * c + 4 * s);
+        }
+        if constexpr (WALLS) {
+            if (HAS_C[0] && C.wall_any) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) cube_con(C.WS[s].Rn, C.WS[s].act, Z_WALL + 4 * s);
+            }
+        }
+        if constexpr (HAS_CC) {
+            if (C.cc_any) {
+#pragma unroll
+                for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC + 15) * 64], C.cc_act[s], Z_CC + 4 * s);
+            }
+        }
+        return best;
     };
     // gradient and Hessian of F at x (residuals zs) -- or, with OUT, the forces at x into the slot records
     auto assemble = [&](auto out_tag, float (&g)[NX], float (&Hm)[NH]) {
@@ -583,28 +652,55 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         if (!__any(live)) break;
         lane_its += live ? 1 : 0;
         dots(std::false_type{}, dx, jd);
-        // line search on phi'(al) = q0 + al q1 - sum f(zs + al jd) . jd: first the full step (exact while no contact changes zone), bracket by doubling, then the
-        // Illinois variant of regula falsi
+        // line search on phi'(al) = q0 + al q1 - sum f(zs + al jd) . jd (monotone increasing), with phi''(al) = q1 + sum jd'W jd from the same pass: first the full step
+        // (exact while no contact changes zone); no bracket yet: the Newton step on phi' from the last point; bracket [lo, hi]: the Newton candidate from the end with the
+        // smaller |phi'| (from the stale end after two updates of the same end in a row), a candidate outside the open bracket being none; both ends pointing outside:
+        // a steep piece hides between two flat ones -- a sliding contact that comes to rest within the step --, try the minimiser of that block's N(al) (kink_cand),
+        // else the Illinois secant point, else the midpoint.  Budget spent without meeting ls_tol: the lower end of the bracket (F decreases on [0, root]).
+        // (oracle: newton_product)
         float q1 = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++) q1 = fmaf(mdiag(i) * dx[i], dx[i], q1);
-        const float q0 = d0 + ls_eval(0.f);
-        float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f;
-        bool done = !live;
+        const float q0 = d0 + ls_eval(0.f).f;
+        float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f, hlo = -d0, hhi = 0.f, dlo_m = d0, dhi_m = 0.f;
+        int last_side = 0, same = 0;
+        bool done = !live, conv = !live;
         for (int ls = 0; ls < P.ls_iters; ls++) {
-            const float dphi = fmaf(al, q1, q0) - ls_eval(al);
+            const LsVal e = ls_eval(al);
+            const float dphi = fmaf(al, q1, q0) - e.f, ddphi = q1 + e.h;
+            float an = al, sec = al;
+            bool need = false;
             if (!done) {
                 const bool fin = fabsf(dphi) <= P.ls_tol * fabsf(d0);
-                if (dphi < 0.f) { if (hi_a >= 0.f && lo_a > 0.f) dhi *= 0.5f; lo_a = al; dlo = dphi; }
-                else { if (hi_a >= 0.f) dlo *= 0.5f; hi_a = al; dhi = dphi; }
-                float an;
-                if (hi_a < 0.f) an = 2.f * al;
-                else { an = lo_a - dlo * (hi_a - lo_a) * rcp(dhi - dlo); if (!(an > lo_a && an < hi_a)) an = 0.5f * (lo_a + hi_a); }
-                al = fin ? al : an;
+                const int side = dphi < 0.f ? -1 : 1;
+                if (dphi < 0.f) { if (last_side < 0) dhi_m *= 0.5f; lo_a = al; dlo = dphi; hlo = ddphi; dlo_m = dphi; }
+                else { if (last_side > 0) dlo_m *= 0.5f; hi_a = al; dhi = dphi; hhi = ddphi; dhi_m = dphi; }
+                same = side == last_side ? same + 1 : 0;
+                last_side = side;
+                if (hi_a < 0.f) an = lo_a - dlo * rcp(hlo);
+                else {
+                    const float cl = lo_a - dlo * rcp(hlo), ch = hi_a - dhi * rcp(hhi);
+                    const float mg = 1e-4f * (hi_a - lo_a), blo = lo_a + mg, bhi = hi_a - mg;   // (inside by a margin: a candidate that repeats an end teaches nothing)
+                    const bool vl = cl > blo && cl < bhi, vh = ch > blo && ch < bhi;
+                    bool from_lo = fabsf(dlo) <= fabsf(dhi);
+                    if (same >= 2) from_lo = side > 0;
+                    sec = lo_a - dlo_m * (hi_a - lo_a) * rcp(dhi_m - dlo_m);
+                    if (!(sec > lo_a && sec < hi_a)) sec = 0.5f * (lo_a + hi_a);
+                    an = from_lo ? (vl ? cl : ch) : (vh ? ch : cl);
+                    need = !fin && !vl && !vh;
+                }
+                conv = fin;
                 done = fin;
             }
+            if (__any(need)) {   // (rare: the block minimisers are computed only when some lane asks for them)
+                const float mg = 1e-4f * (hi_a - lo_a);
+                const float kc = kink_cand(lo_a + mg, hi_a - mg, sec);
+                an = need ? kc : an;
+            }
+            al = done ? al : an;
             if (__all(done)) break;
         }
+        if (!conv) al = lo_a > 0.f ? lo_a : hi_a;
         const float step = live ? al : 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++) x[i] = fmaf(step, dx[i], x[i]);

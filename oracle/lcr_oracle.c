@@ -1216,10 +1216,16 @@ static int newton_primal(int nv, int nr, const real *M, const real *J, const rea
  *   start     x0 = a0 + M^-1 J' f_carried   (the constraint forces carried from the previous substep / control step; MuJoCo: qacc_warmstart)
  *   iteration g = M (x - a0) - J' f(x),  H = M + J' W(x) J  (W: block-diagonal Jacobian of -f w.r.t. the row residuals, zero / diagonal / rank-structured in
  *             the top / bottom / middle zone of a contact's cone),  dx = -H^-1 g  (Cholesky);  stop when the Newton decrement -g'dx <= newton_tol^2 (1 + |x0|_M^2)
- *   line search on phi(al) = F(x + al dx), convex and C^1: derivative-only -- phi'(al) = grad F(x + al dx) . dx costs one gradient pass --, first al = 1 (exact while
- *             no contact changes zone), bracket by doubling, then the Illinois variant of regula falsi; at most ls_iters evaluations, stop when
- *             |phi'(al)| <= ls_tol |phi'(0)|.  (Measured, profiles/r05_solver_decision.txt: the search must be accurate, and the derivative-only iteration beats
- *             1-D Newton steps on phi' at equal evaluations.)
+ *   line search on phi(al) = F(x + al dx), convex and C^1: one gradient pass gives phi'(al) = grad F(x + al dx) . dx and phi''(al) = dx'M dx + sum_b jd_b'W_b jd_b.
+ *             First al = 1 (exact while no contact changes zone); no bracket yet: the Newton step on phi' from the last point; bracket [lo, hi]: the Newton candidate
+ *             from the end with the smaller |phi'| (from the stale end after two updates of the same end in a row), a candidate outside the open bracket being none
+ *             (phi' is piecewise linear apart from the cones' middle zones: a candidate is the exact root unless a kink lies in between -- a joint limit or contact
+ *             switching on along the step is found in one evaluation from the steep side).  Both ends pointing outside: a steep piece hides between two flat ones,
+ *             a sliding contact that comes to rest within the step (its friction force turns around where N(al) = |w_t(al)| passes its minimum) -- try the closed-form
+ *             minimiser of that block's N(al), else the Illinois secant point, else the midpoint.  At most ls_iters evaluations, stop when |phi'(al)| <= ls_tol |phi'(0)|;
+ *             budget spent: the lower end of the bracket (F decreases on [0, root]).  (Round-5 record, profiles/r05_solver_decision.txt: the search must be accurate.
+ *             The first round-5 kernels ran a derivative-only Illinois search, ORC_LS_ILLINOIS=1 here: it needs a third more evaluations and creeps when a limit row
+ *             of 1e4 x the slope switches on inside the bracket -- tests/test_gpu_parity.py::test_joint_limit_rows was 0.08 rad off.)
  *   at most newton_iters iterations (default 20: a cold start on a finger deep in the floor with both fingers and a proxy down needs 12).  On the GPU both loops are left wave-uniformly (when every lane of the wave has met the criterion), so a lane may
  *   iterate further than here -- at the optimum that changes nothing beyond rounding.
  * Returns the forces f(x) and the accelerations x themselves: the integration uses x (M (x - a0) = J' f at the optimum). */
@@ -1272,7 +1278,9 @@ static __thread int32_t *t_trace_slot = NULL;
 static int newton_product(int nv, int nr, const real *M, const real *Lm, const real *J, const real *aref, const real *Rr, const real *a0, const int *kind,
                           const int *blkdim, const double *const *rowmu, real *f, real *x_out, int iters, int ls_iters, double tol, double ls_tol) {
     real x[ORC_NV_MAX], xa[ORC_NV_MAX], g[ORC_NV_MAX], H[ORC_NV_MAX * ORC_NV_MAX], dx[ORC_NV_MAX], tmp[ORC_NV_MAX];
-    real *z = (real *)malloc(sizeof(real) * (size_t)(nr + 1) * 8), *W = z + nr + 1;
+    real *z = (real *)malloc(sizeof(real) * (size_t)(nr + 1) * 10), *W = z + nr + 1, *jd = W + (size_t)(nr + 1) * 6 + nr + 1, *z0 = jd + nr + 1;
+    static int np_debug = -1, ls_illinois = 0;
+    if (np_debug < 0) { ls_illinois = getenv("ORC_LS_ILLINOIS") != NULL; np_debug = getenv("ORC_NEWTON_DEBUG3") != NULL; }
     for (int d = 0; d < nv; d++) { real acc = 0; for (int i = 0; i < nr; i++) acc += J[(size_t)i * nv + d] * f[i]; tmp[d] = acc; }
     chol_solve(Lm, nv, tmp);
     real scale = 1;
@@ -1308,26 +1316,100 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
         chol_solve(H, nv, dx);
         real d0 = 0;
         for (int a = 0; a < nv; a++) d0 += g[a] * dx[a];
-        if (getenv("ORC_NEWTON_DEBUG3")) fprintf(stderr, "np it=%d decrement=%.3e tol2=%.3e\n", it, (double)-d0, tol * tol * (double)scale);
+        if (np_debug) {
+            fprintf(stderr, "np it=%d decrement=%.3e tol2=%.3e  zones:", it, (double)-d0, tol * tol * (double)scale);
+            for (int i = 0; i < nr; i++) { if (kind[i] == 2) continue; fprintf(stderr, " [%d k%d z=%.3e f=%.3e R=%.1e]", i, kind[i], (double)z[i], (double)f[i], (double)Rr[i]); }
+            fprintf(stderr, "\n");
+        }
         if (!((double)-d0 > tol * tol * (double)scale)) break;    /* Newton decrement: converged (or no descent) */
-        /* line search: phi'(al) = grad F(x + al dx) . dx */
-        real al = 1, lo_a = 0, hi_a = -1, dlo = d0, dhi = 0;
+        /* line search on phi'(al) = grad F(x + al dx) . dx, monotone increasing, with phi''(al) = dx'M dx + sum_b jd_b' W_b(al) jd_b from the same pass */
+        real q1 = 0;
+        for (int a = 0; a < nv; a++) { real acc = 0; for (int c = 0; c < nv; c++) acc += M[a * nv + c] * dx[c]; q1 += dx[a] * acc; }
+        for (int i = 0; i < nr; i++) { real acc = 0; for (int d = 0; d < nv; d++) acc += J[(size_t)i * nv + d] * dx[d]; jd[i] = acc; }
+        real al = 1, lo_a = 0, hi_a = -1, dlo = d0, dhi = 0, hlo = -d0, hhi = 0, dlo_m = d0, dhi_m = 0;
+        int last_side = 0, same = 0, ls_done = 0;
+        for (int i = 0; i < nr; i++) z0[i] = z[i];
+        if (np_debug && getenv("ORC_LS_SCAN")) {
+            for (double e = -14; e <= 0; e += 1) {
+                const real aa = e < -13.5 ? 0 : (real)pow(10.0, e);
+                for (int d = 0; d < nv; d++) xa[d] = x[d] + aa * dx[d];
+                NP_GRAD(xa, W);
+                real dphi = 0;
+                for (int a = 0; a < nv; a++) dphi += g[a] * dx[a];
+                fprintf(stderr, "   scan al=%.1e dphi=%.6e  |", (double)aa, (double)dphi);
+                for (int i = 0; i < nr; i++) fprintf(stderr, " %.3e", (double)z[i]);
+                fprintf(stderr, "\n");
+            }
+        }
         for (int ls = 0; ls < ls_iters; ls++) {
             for (int d = 0; d < nv; d++) xa[d] = x[d] + al * dx[d];
-            NP_GRAD(xa, NULL);
-            real dphi = 0;
+            NP_GRAD(xa, W);
+            real dphi = 0, ddphi = q1;
             for (int a = 0; a < nv; a++) dphi += g[a] * dx[a];
+            for (int i = 0; i < nr; i++) {
+                if (kind[i] == 2) continue;
+                const int dm = kind[i] == 0 ? 1 : blkdim[i];
+                for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) ddphi += jd[i + r] * W[(size_t)(i + r) * 6 + c] * jd[i + c];
+            }
             const int done = fabs((double)dphi) <= ls_tol * fabs((double)d0);
-            if (dphi < 0) { if (hi_a >= 0 && lo_a > 0) dhi *= (real)0.5; lo_a = al; dlo = dphi; }
-            else { if (hi_a >= 0) dlo *= (real)0.5; hi_a = al; dhi = dphi; }
             if (t_trace_slot) t_trace_slot[1]++;
-            if (getenv("ORC_NEWTON_DEBUG3")) fprintf(stderr, "     ls=%d al=%.6g dphi=%.3e (d0=%.3e)\n", ls, (double)al, (double)dphi, (double)d0);
-            if (done) break;
+            if (np_debug) fprintf(stderr, "     ls=%d al=%.6g dphi=%.3e ddphi=%.3e (d0=%.3e)\n", ls, (double)al, (double)dphi, (double)ddphi, (double)d0);
+            if (done) { ls_done = 1; break; }
             real an;
-            if (hi_a < 0) an = 2 * al;
-            else { an = lo_a - dlo * (hi_a - lo_a) / (dhi - dlo); if (!(an > lo_a && an < hi_a)) an = (real)0.5 * (lo_a + hi_a); }
+            if (ls_illinois) {   /* (study: the derivative-only search of the first round-5 kernels) */
+                if (dphi < 0) { if (hi_a >= 0 && lo_a > 0) dhi *= (real)0.5; lo_a = al; dlo = dphi; }
+                else { if (hi_a >= 0) dlo *= (real)0.5; hi_a = al; dhi = dphi; }
+                if (hi_a < 0) an = 2 * al;
+                else { an = lo_a - dlo * (hi_a - lo_a) / (dhi - dlo); if (!(an > lo_a && an < hi_a)) an = (real)0.5 * (lo_a + hi_a); }
+            } else {
+                const int side = dphi < 0 ? -1 : 1;
+                /* (the Illinois rule for the secant fall-back: a second update of the same end in a row halves the value kept for the stale end) */
+                if (dphi < 0) { if (last_side < 0) dhi_m *= (real)0.5; lo_a = al; dlo = dphi; hlo = ddphi; dlo_m = dphi; }
+                else { if (last_side > 0) dlo_m *= (real)0.5; hi_a = al; dhi = dphi; hhi = ddphi; dhi_m = dphi; }
+                same = side == last_side ? same + 1 : 0;
+                last_side = side;
+                if (hi_a < 0) an = lo_a - dlo / hlo;      /* no bracket yet: the Newton step from the last point (phi'' >= dx'M dx > 0) moves right */
+                else {
+                    /* bracket [lo, hi]: Newton candidates from both ends -- on a piecewise linear phi' each is the exact root unless a kink lies in between.  Take
+                     * the one from the end whose |phi'| is smaller (from the stale end after two updates of the same side in a row); a candidate outside the open
+                     * bracket is no candidate.  When both ends point outside, a steep piece hides between two flat ones: a sliding contact that comes to rest within
+                     * the step -- its tangential residual passes (almost) through zero, where the friction force turns around; the root sits in the narrow sticking
+                     * zone around the minimum of that block's N(al) = |w_t(al)|, a quadratic in al whose minimiser is known in closed form.  Take the block minimiser
+                     * inside the bracket that is closest to the (Illinois) secant point; without one, the secant point; then the midpoint */
+                    const real cl = lo_a - dlo / hlo, ch = hi_a - dhi / hhi;
+                    const real mg = (real)1e-4 * (hi_a - lo_a), blo = lo_a + mg, bhi = hi_a - mg;   /* (inside by a margin: a candidate that repeats an end teaches nothing) */
+                    const int vl = cl > blo && cl < bhi, vh = ch > blo && ch < bhi;
+                    int from_lo = fabs((double)dlo) <= fabs((double)dhi);
+                    if (same >= 2) from_lo = side > 0;
+                    real sec = lo_a - dlo_m * (hi_a - lo_a) / (dhi_m - dlo_m);
+                    if (!(sec > lo_a && sec < hi_a)) sec = (real)0.5 * (lo_a + hi_a);
+                    if (vl || vh) an = from_lo ? (vl ? cl : ch) : (vh ? ch : cl);
+                    else {
+                        an = sec;
+                        real bestd = -1;
+                        for (int i = 0; i < nr; i++) {
+                            if (kind[i] != 1) continue;
+                            const double *mu = rowmu[i];
+                            real qa = 0, qb = 0;
+                            for (int r = 1; r < blkdim[i]; r++) { const real m2 = (real)(mu[r - 1] * mu[r - 1]); qa += m2 * jd[i + r] * jd[i + r]; qb += m2 * z0[i + r] * jd[i + r]; }
+                            if (!(qa > 0)) continue;
+                            const real am = -qb / qa;
+                            if (!(am > blo && am < bhi)) continue;
+                            /* ... and only where the block IS in its sticking (bottom) zone at the minimiser: N_min Rn <= -w_n Rt */
+                            real qc = 0;
+                            for (int r = 1; r < blkdim[i]; r++) qc += (real)(mu[r - 1] * mu[r - 1]) * z0[i + r] * z0[i + r];
+                            const real n2 = qc - qb * qb / qa, wn = z0[i] + am * jd[i], Rtb = Rr[i + 1] * (real)(mu[0] * mu[0]);
+                            if (!(wn < 0) || (n2 > 0 ? n2 : 0) * Rr[i] * Rr[i] > wn * wn * Rtb * Rtb) continue;
+                            const real dist = (real)fabs((double)(am - sec));
+                            if (bestd < 0 || dist < bestd) { bestd = dist; an = am; }
+                        }
+                    }
+                }
+            }
             al = an;
         }
+        /* budget spent without meeting ls_tol: step to the lower end of the bracket (F decreases on [0, root]); none found: to the smallest point evaluated */
+        if (!ls_done && !ls_illinois) al = lo_a > 0 ? lo_a : hi_a;
         for (int d = 0; d < nv; d++) x[d] += al * dx[d];
         if (t_trace_slot) t_trace_slot[0]++;
     }
