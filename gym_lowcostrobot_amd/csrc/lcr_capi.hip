@@ -140,7 +140,7 @@ static int config_base(lcr_config *cfg, int task) {
     cfg->ls_iters = 8;
     cfg->finger_floor_condim = 0;
     cfg->newton_tol = 1e-6;
-    cfg->ls_tol = 1e-4;
+    cfg->ls_tol = 1e-2;   // (MuJoCo's own default: ls_tolerance 0.01; measured on the oracle: a sixth fewer evaluations of phi', same distance to the exact optimum)
     return LCR_OK;
 }
 

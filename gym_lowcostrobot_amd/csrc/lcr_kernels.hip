@@ -428,6 +428,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
     const float srad[2] = {SPH0r, SPH1r};
+    bool body_done[2] = {false, false};   // (NEWTON) the angular rows of finger body 0 / 1 are in LDS (wave-uniform)
 #pragma unroll
     for (int s = 0; s < NAS; s++) {
         const int sp = s & 1;
@@ -559,16 +560,52 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 jc[j] = lit ? cross(z[j], pos - F.p[j]) : mk(0.f, 0.f, 0.f);
                 if (s == 4 && j >= 3 && !joint_on(j)) jc[j] = mk(0.f, 0.f, 0.f);
             }
+            // NEWTON: the three angular rows of a finger contact (torsion, two rolling rows) are combinations of the finger BODY's angular rows
+            // B_a = L^-1 (z_j . e_a)_j, a = x, y, z -- kept once per finger (LDS rows 12 + 3 sp + a) instead of three rows per slot: 22 g rows, 33 KiB per wave,
+            // four waves per CU (28 rows were 42 KiB: three).  d . B is also what the warm start and the relative angular velocity need.
+            float Bb[3][6];
+            f3 wbody = mk(0.f, 0.f, 0.f), tau = mk(0.f, 0.f, 0.f);
+            if (NEWTON && s < 4) {
+                if (!body_done[sp]) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) Bb[a][j] = joint_on(j) ? (a == 0 ? z[j].x : (a == 1 ? z[j].y : z[j].z)) : 0.f;
+                        fsub(CL, Bb[a]);
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+                            *reinterpret_cast<float2v *>(&lds[(12 + 3 * sp + a) * LDS_ROW + k * 128 + lane * 2]) = float2v{Bb[a][2 * k], Bb[a][2 * k + 1]};
+                    }
+                    body_done[sp] = true;
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const float2v gp = *reinterpret_cast<const float2v *>(&lds[(12 + 3 * sp + a) * LDS_ROW + k * 128 + lane * 2]);
+                            Bb[a][2 * k] = gp.x; Bb[a][2 * k + 1] = gp.y;
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++) { if (joint_on(j)) wbody = axpy(S.qd[j], z[j], wbody); }
+            }
 #pragma unroll
             for (int r = 0; r < arm_rows_of<ROLL, NEWTON>(s); r++) {
+                const bool body_row = NEWTON && s < 4 && r >= 3;   // (literal after unrolling)
                 f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : T.n));   // row 3: rotation about n (torsion)
                 if constexpr (ROLL) { if (r >= 4) d = r == 4 ? T.t1 : T.t2; }     // rows 4, 5: rotation about t1, t2 (rolling)
                 float g[6];
                 float vel = 0.f;
+                if (body_row) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    g[j] = r < 3 ? dot(jc[j], d) : (joint_on(j) ? dot(z[j], d) : 0.f);
-                    vel = fmaf(g[j], S.qd[j], vel);
+                    for (int j = 0; j < 6; j++) g[j] = 0.f;
+                    vel = dot(d, wbody);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        g[j] = r < 3 ? dot(jc[j], d) : (joint_on(j) ? dot(z[j], d) : 0.f);
+                        vel = fmaf(g[j], S.qd[j], vel);
+                    }
                 }
                 float diagc = 0.f;
                 if (may_cube) {
@@ -584,7 +621,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (s == 4) { velc = oncube ? velc : 0.f; diagc = oncube ? diagc : 0.f; }
                     vel -= velc;
                 }
-                fsub(CL, g);
+                if (!body_row) fsub(CL, g);
                 float gg = 0.f;
 #pragma unroll
                 for (int j = 0; j < 6; j++) gg = fmaf(g[j], g[j], gg);
@@ -592,6 +629,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 //  violation, and the compiler did move such loads above the stores in one kernel variant)
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
+                    if (body_row) continue;
                     const float2v gp = {g[2 * k], g[2 * k + 1]};
                     if (NC == 2 && !BIG && s == 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)(r * 3 + k) * P.n + env) * 2]) = gp;
                     else if (NC == 2 && !BIG && r >= 4) *reinterpret_cast<float2v *>(&P.scratch[((size_t)((4 + 2 * s + (r - 4)) * 3 + k) * P.n + env) * 2]) = gp;
@@ -611,8 +649,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
                 const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
+                if (body_row) tau = axpy(fw, d, tau);
+                else {
 #pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = fmaf(g[j], fw, y[j]);
+                    for (int j = 0; j < 6; j++) y[j] = fmaf(g[j], fw, y[j]);
+                }
                 if (may_cube) {
                     const float fc = (s == 4 && !oncube) ? 0.f : fw;
                     f3 dl = r < 3 ? (-minv * fc) * d : mk(0.f, 0.f, 0.f);
@@ -620,6 +661,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (NC == 2 && cidx == 1) { ca[NC - 1] = ca[NC - 1] + dl; cal[NC - 1] = cal[NC - 1] + da; }
                     else { ca[0] = ca[0] + dl; cal[0] = cal[0] + da; }
                 }
+            }
+            if (NEWTON && s < 4) {   // the warm-start torque of the three angular rows, through the body rows
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = fmaf(Bb[0][j], tau.x, fmaf(Bb[1][j], tau.y, fmaf(Bb[2][j], tau.z, y[j])));
             }
             {   // k[] of soc_step: iLn, mu_tan^2 iLt, w, mu_tors^2 iLt (, mu_roll^2 iLt)
                 const float iLn = T.act ? rcp(Ln) : 0.f, iLt = T.act ? rcp(Lt) : 0.f, iLs = iLt;
@@ -668,9 +713,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         //      or a gripper-body proxy on the cube, arm and cube are independent 6-dimensional problems ----
         const int row0[NAS] = {arm_row0_of<ROLL, NC, BIG, NEWTON>(0), arm_row0_of<ROLL, NC, BIG, NEWTON>(1), arm_row0_of<ROLL, NC, BIG, NEWTON>(2),
                                arm_row0_of<ROLL, NC, BIG, NEWTON>(3), arm_row0_of<ROLL, NC, BIG, NEWTON>(4)};
+        const NewtonParams NP = newton_params(P);
         FloorSlot no_walls[4];
         const float no_wsg[2] = {1.f, 1.f};
-        NewtonCtx<NC, NRW, false, NCC> C{P, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, no_walls, no_wsg, false,
+        NewtonCtx<NC, NRW, false, NCC> C{NP, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, no_walls, no_wsg, false,
                                          ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
         if constexpr (NC == 1) {
             const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);

@@ -121,13 +121,17 @@ DEV void solve_packed(const float (&H)[NX * (NX + 1) / 2], const float (&id)[NX]
 }
 
 // friction of the finger geoms against the floor (follower.xml:15: friction="1.5" + MuJoCo's default torsional 0.005 / rolling 0.0001; the finger class has priority 1)
+constexpr float LS_NOISE = 1e-5f;   // relative rounding floor of phi'(al) in fp32 (oracle: LS_NOISE)
 constexpr float MU_ROLL = 1e-4f;
 constexpr float RR_FF = (MU_FINGER * MU_FINGER) / (MU_ROLL * MU_ROLL);   // regulariser scale of the rolling rows: mu_tan^2 / mu_roll^2
 
-// rows and LDS placement of the arm-coupled slots in the Newton kernels: the finger slots 0-3 have six rows, the proxy slot four -- 28 g rows (42 KiB per wave)
+// rows and LDS placement of the arm-coupled slots in the Newton kernels: the finger slots 0-3 have six rows, the proxy slot four.  In LDS: the three LINEAR rows of
+// each finger slot (rows 3 s + r), the three angular rows of each finger BODY (rows 12 + 3 sp + axis: B_a = L^-1 (z_j . e_a)_j -- the slot's torsion / rolling rows
+// are d . B, and for a finger on the floor, frame (z, y, -x), they are B_z, B_y, -B_x themselves), the proxy slot's four rows (18 + r): 22 g rows, 33 KiB per wave
 template <bool ROLL, bool NEWTON> constexpr int arm_rows_of(int s) { return (NEWTON && s < 4) ? 6 : as_rows<ROLL>(s); }
-template <bool ROLL, int NC, bool BIG, bool NEWTON> constexpr int arm_row0_of(int s) { return NEWTON ? (s < 4 ? 6 * s : 24) : as_row0<ROLL, NC, BIG>(s); }
-constexpr int NEWTON_G_ROWS = 28;
+template <bool ROLL, int NC, bool BIG, bool NEWTON> constexpr int arm_row0_of(int s) { return NEWTON ? (s < 4 ? 3 * s : 18) : as_row0<ROLL, NC, BIG>(s); }
+constexpr int NEWTON_G_ROWS = 22;
+constexpr int NEWTON_BODY_ROW0 = 12;
 
 // ================================================================================================
 // The solve.  Everything a substep's set-up leaves behind is reached through NewtonCtx (references into the caller's registers / LDS).
@@ -136,9 +140,17 @@ constexpr int NEWTON_G_ROWS = 28;
 // bodies in MASK with every constraint that acts on them; the caller cuts the bodies of a wave into the connected components of its WAVE-UNIFORM coupling graph
 // (an edge where some lane has a contact between two bodies) and solves them one after the other: independent problems, each as small as it can be -- most of
 // the time the arm and the cube(s) do not touch, and a wave pays as many iterations as its slowest lane needs for THAT body.
+// the scalars of LcrDev the solve reads (by value: the far entry below must not take the address of the kernel's argument block)
+struct NewtonParams {
+    float cube_iinv, cube_mass, inv_impratio, ls_tol, mu_c2, mu_ct2, mu_fc2, mu_fcr2, mu_fct2, newton_tol;
+    int ls_iters, newton_iters;
+};
+DEV NewtonParams newton_params(const LcrDev &P) {
+    return NewtonParams{P.cube_iinv, P.cube_mass, P.inv_impratio, P.ls_tol, P.mu_c2, P.mu_ct2, P.mu_fc2, P.mu_fcr2, P.mu_fct2, P.newton_tol, P.ls_iters, P.newton_iters};
+}
 template <int NC, int NRW, bool WALLS, int NCC>
 struct NewtonCtx {
-    const LcrDev &P;
+    const NewtonParams &P;
     const float *lds;   // g rows of the arm-coupled slots: row (row0[s] + r), float2 pairs [k][lane]
     int lane;
     const int (&row0)[NAS];
@@ -181,7 +193,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     constexpr bool HAS_CC = NC == 2 && HAS_C[0] && HAS_C[1];
     // residual rows: joint limits, arm slots (6 rows each, slot 4: 4), floor slots per cube, rails, cube<->cube
     constexpr int Z_LIM = 0, Z_ARM = 6, Z_FLOOR = 34, Z_WALL = Z_FLOOR + 16 * NC, Z_CC = Z_WALL + (WALLS ? 16 : 0), NZ = Z_CC + (NC == 2 ? 4 * NCC : 0);
-    const LcrDev &P = C.P;
+    const NewtonParams &P = C.P;
     const float cm = P.cube_mass, ci = rcp(P.cube_iinv);
     auto mdiag = [&](int i) -> float { return (HAS_A && i < 6) ? 1.f : (((i - (HAS_A ? 6 : 0)) % 6) < 3 ? cm : ci); };
     const bool wave_lim = HAS_A && C.lim_wave != 0u;
@@ -206,9 +218,10 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         x[OC[c] + 0] = ca[c].x; x[OC[c] + 1] = ca[c].y; x[OC[c] + 2] = ca[c].z; x[OC[c] + 3] = cal[c].x; x[OC[c] + 4] = cal[c].y; x[OC[c] + 5] = cal[c].z;
         x0[OC[c] + 0] = 0.f; x0[OC[c] + 1] = 0.f; x0[OC[c] + 2] = -GRAV; x0[OC[c] + 3] = 0.f; x0[OC[c] + 4] = 0.f; x0[OC[c] + 5] = 0.f;
     }
-    float scale = 1.f;
+    // the tolerance scale 1 + |a0|_M^2 of the WHOLE system (oracle: one problem over all bodies), also when this call solves one component of it
+    float scale = fmaf((float)NC * cm, GRAV * GRAV, 1.f);
 #pragma unroll
-    for (int i = 0; i < NX; i++) scale = fmaf(mdiag(i) * x0[i], x0[i], scale);
+    for (int j = 0; j < 6; j++) scale = fmaf(C.y0s[j], C.y0s[j], scale);
     // joint-limit rows: regulariser and reference acceleration once per solve
     float lim_aref[6], lim_iR[6];
 #pragma unroll
@@ -248,11 +261,32 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         const ArmSlot<NRW> &T = C.AS[s];
 #pragma unroll
         for (int i = 0; i < NX; i++) row[i] = 0.f;
+        auto ld = [&](int lrow, float (&o)[6]) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float2v gp = *reinterpret_cast<const float2v *>(&C.lds[(C.row0[s] + r) * LDS_ROW + k * 128 + C.lane * 2]);
-            row[OA + 2 * k] = gp.x; row[OA + 2 * k + 1] = gp.y;
-        }
+            for (int k = 0; k < 3; k++) {
+                const float2v gp = *reinterpret_cast<const float2v *>(&C.lds[lrow * LDS_ROW + k * 128 + C.lane * 2]);
+                o[2 * k] = gp.x; o[2 * k + 1] = gp.y;
+            }
+        };
+        float g6[6];
+        if (s < 4 && r >= 3) {   // torsion / rolling rows of a finger contact: d . B of the finger body (rows NEWTON_BODY_ROW0 + 3 sp + axis)
+            constexpr int b0 = NEWTON_BODY_ROW0 + 3 * (s & 1);
+            if (s >= 2) {        // on the floor the frame is (z, y, -x): the body rows themselves
+                ld(b0 + (r == 3 ? 2 : (r == 4 ? 1 : 0)), g6);
+                if (r == 5) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) g6[k] = -g6[k];
+                }
+            } else {
+                const f3 dd = r == 3 ? T.n : (r == 4 ? T.t1 : T.t2);
+                float bx[6], by[6], bz[6];
+                ld(b0, bx); ld(b0 + 1, by); ld(b0 + 2, bz);
+#pragma unroll
+                for (int k = 0; k < 6; k++) g6[k] = fmaf(dd.x, bx[k], fmaf(dd.y, by[k], dd.z * bz[k]));
+            }
+        } else ld(C.row0[s] + r, g6);
+#pragma unroll
+        for (int k = 0; k < 6; k++) row[OA + k] = g6[k];
         if (ARM_CUBE && cube_part) {   // the cube's contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
             const f3 d = r == 0 ? T.n : (r == 1 ? T.t1 : (r == 2 ? T.t2 : (r == 3 ? T.n : (r == 4 ? T.t1 : T.t2))));
             const float on = (s < 2 || C.link_on_cube) ? -1.f : 0.f;
@@ -543,19 +577,35 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
                 for (int r = 0; r < NR; r++) T.f[r] = B.f[r];
                 return;
             }
-            float row[NR][NX];
+            // rows streamed one at a time (a six-row slot of a coupled problem would otherwise hold 6 x 12 row entries at once -- the register peak of the kernel):
+            // per row the gradient share and its kap m2 row row' term; the normal row and w = sum_t c_t row_t are kept for the two terms av v v' - gam w w', v = row_n - w
+            auto stream = [&](auto lo_tag, auto hi_tag) {
+                constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
+                float row0[NX], wv[NX];
 #pragma unroll
-            for (int r = 0; r < NR; r++) arm_row(s_tag, r, cube_part, row[r]);
+                for (int i = 0; i < NX; i++) { row0[i] = 0.f; wv[i] = 0.f; }
 #pragma unroll
-            for (int i = 0; i < NX; i++) {
-                if (!((HAS_A && i >= OA && i < OA + 6) || cube_part)) continue;
-                float a = g[i];
+                for (int r = 0; r < NR; r++) {
+                    float row[NX];
+                    arm_row(s_tag, r, cube_part, row);
 #pragma unroll
-                for (int r = 0; r < NR; r++) a = fmaf(-B.f[r], row[r][i], a);
-                g[i] = a;
-            }
-            if (ARM_CUBE && cube_part) h_block<0, NX, NX, NR>(Hm, row, B, m2);
-            else h_block<OA, OA + 6, NX, NR>(Hm, row, B, m2);
+                    for (int i = LO; i < HI; i++) g[i] = fmaf(-B.f[r], row[i], g[i]);
+                    if (r == 0) {
+#pragma unroll
+                        for (int i = LO; i < HI; i++) row0[i] = row[i];
+                    } else {
+#pragma unroll
+                        for (int i = LO; i < HI; i++) wv[i] = fmaf(B.c[r], row[i], wv[i]);
+                        h_rank1<LO, HI, NX>(Hm, row, B.kap * m2[r]);
+                    }
+                }
+#pragma unroll
+                for (int i = LO; i < HI; i++) row0[i] -= wv[i];
+                h_rank1<LO, HI, NX>(Hm, row0, B.av);
+                h_rank1<LO, HI, NX>(Hm, wv, -B.gam);
+            };
+            if (ARM_CUBE && cube_part) stream(std::integral_constant<int, 0>{}, std::integral_constant<int, NX>{});
+            else stream(std::integral_constant<int, OA>{}, std::integral_constant<int, OA + 6>{});
         };
         arm(std::integral_constant<int, 0>{}); arm(std::integral_constant<int, 1>{}); arm(std::integral_constant<int, 2>{});
         arm(std::integral_constant<int, 3>{}); arm(std::integral_constant<int, 4>{});
@@ -667,11 +717,13 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         bool done = !live, conv = !live;
         for (int ls = 0; ls < P.ls_iters; ls++) {
             const LsVal e = ls_eval(al);
-            const float dphi = fmaf(al, q1, q0) - e.f, ddphi = q1 + e.h;
+            const float mpart = fmaf(al, q1, q0);   // [M (x + al dx - x0)] . dx
+            const float dphi = mpart - e.f, ddphi = q1 + e.h;
             float an = al, sec = al;
             bool need = false;
             if (!done) {
-                const bool fin = fabsf(dphi) <= P.ls_tol * fabsf(d0);
+                // (the two partial sums cancel at the root: their fp32 rounding, not ls_tol, bounds what the search can resolve near convergence)
+                const bool fin = fabsf(dphi) <= fmaf(P.ls_tol, fabsf(d0), LS_NOISE * (fabsf(mpart) + fabsf(e.f)));
                 const int side = dphi < 0.f ? -1 : 1;
                 if (dphi < 0.f) { if (last_side < 0) dhi_m *= 0.5f; lo_a = al; dlo = dphi; hlo = ddphi; dlo_m = dphi; }
                 else { if (last_side > 0) dlo_m *= 0.5f; hi_a = al; dhi = dphi; hhi = ddphi; dhi_m = dphi; }
@@ -723,5 +775,6 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     }
     return lane_its;
 }
+
 
 }  // namespace

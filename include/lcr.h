@@ -127,7 +127,7 @@ typedef struct lcr_config {
     int32_t finger_floor_condim; /* rows of a finger<->floor contact: 6 = MuJoCo's (follower.xml:15 condim="6": + two rolling rows, coefficient 1e-4 m), 4 = without
                                   them.  0 = the preset's default.  6 is implemented by the Newton kernels (LCR_SOLVER_PGS with 6: LCR_ERR_UNSUPPORTED) */
     double newton_tol;         /* LCR_SOLVER_NEWTON: an env has converged when its Newton decrement -g'dx <= newton_tol^2 (1 + |a0|_M^2)   (1e-6) */
-    double ls_tol;             /* ... its line search stops when |phi'(al)| <= ls_tol |phi'(0)|   (1e-4) */
+    double ls_tol;             /* ... its line search stops when |phi'(al)| <= ls_tol |phi'(0)|   (1e-2: MuJoCo's default ls_tolerance), plus a rounding floor 1e-5 (|M-part| + |force part|) of the two sums phi' is the difference of */
 } lcr_config;
 
 typedef enum lcr_solver { LCR_SOLVER_PGS = 0, LCR_SOLVER_NEWTON = 1 } lcr_solver;

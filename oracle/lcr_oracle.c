@@ -1229,6 +1229,7 @@ static int newton_primal(int nv, int nr, const real *M, const real *J, const rea
  *   at most newton_iters iterations (default 20: a cold start on a finger deep in the floor with both fingers and a proxy down needs 12).  On the GPU both loops are left wave-uniformly (when every lane of the wave has met the criterion), so a lane may
  *   iterate further than here -- at the optimum that changes nothing beyond rounding.
  * Returns the forces f(x) and the accelerations x themselves: the integration uses x (M (x - a0) = J' f at the optimum). */
+#define LS_NOISE 1e-5   /* relative rounding floor of phi'(al) evaluated in float (about 40 terms of either sign) */
 static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, const int *blkdim, const double *const *rowmu, real *f, real *W /* nr x 6 or NULL */) {
     for (int i = 0; i < nr; i++) {
         if (kind[i] == 2) continue;
@@ -1344,14 +1345,18 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
         for (int ls = 0; ls < ls_iters; ls++) {
             for (int d = 0; d < nv; d++) xa[d] = x[d] + al * dx[d];
             NP_GRAD(xa, W);
-            real dphi = 0, ddphi = q1;
-            for (int a = 0; a < nv; a++) dphi += g[a] * dx[a];
+            /* phi'(al) = [M (x + al dx - a0)] . dx - f(al) . jd: two partial sums that cancel at the root -- in float arithmetic their rounding, not ls_tol, bounds what
+             * the search can resolve near convergence, so the stopping rule carries a noise floor relative to their magnitudes (harmless in double) */
+            real mpart = 0, fpart = 0, ddphi = q1;
+            for (int a = 0; a < nv; a++) { real acc = 0; for (int c = 0; c < nv; c++) acc += M[a * nv + c] * (xa[c] - a0[c]); mpart += acc * dx[a]; }
+            for (int i = 0; i < nr; i++) fpart += f[i] * jd[i];
+            const real dphi = mpart - fpart;
             for (int i = 0; i < nr; i++) {
                 if (kind[i] == 2) continue;
                 const int dm = kind[i] == 0 ? 1 : blkdim[i];
                 for (int r = 0; r < dm; r++) for (int c = 0; c < dm; c++) ddphi += jd[i + r] * W[(size_t)(i + r) * 6 + c] * jd[i + c];
             }
-            const int done = fabs((double)dphi) <= ls_tol * fabs((double)d0);
+            const int done = fabs((double)dphi) <= ls_tol * fabs((double)d0) + LS_NOISE * (fabs((double)mpart) + fabs((double)fpart));
             if (t_trace_slot) t_trace_slot[1]++;
             if (np_debug) fprintf(stderr, "     ls=%d al=%.6g dphi=%.3e ddphi=%.3e (d0=%.3e)\n", ls, (double)al, (double)dphi, (double)ddphi, (double)d0);
             if (done) { ls_done = 1; break; }
@@ -1631,7 +1636,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         }
         if (P->solver == 2) {   /* the product's faithful solver: Newton on the primal with a fixed budget (see newton_product) */
             const int nit = newton_product(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, xsol, P->newton_iters > 0 ? P->newton_iters : 20,
-                                           P->ls_iters > 0 ? P->ls_iters : 8, P->newton_tol > 0 ? P->newton_tol : 1e-6, P->ls_tol > 0 ? P->ls_tol : 1e-4);
+                                           P->ls_iters > 0 ? P->ls_iters : 8, P->newton_tol > 0 ? P->newton_tol : 1e-6, P->ls_tol > 0 ? P->ls_tol : 1e-2);
             use_x = 1;
             if (getenv("ORC_SWEEP_SUM")) lag->max_sweeps += (uint32_t)nit;
             else if ((uint32_t)nit > lag->max_sweeps) lag->max_sweeps = (uint32_t)nit;
@@ -1774,7 +1779,7 @@ static void params_base(orc_params *p, int task) {   /* the reference's construc
     p->solver = 0;    /* PGS (what the kernels run) */
     p->jacobi = task == ORC_TASK_PUSH_LOOP ? 0 : 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
-    p->newton_iters = 20; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-4;   /* (read by solver = 2 only; = lcr_config_default) */
+    p->newton_iters = 20; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-2;   /* (read by solver = 2 only; = lcr_config_default.  ls_tol: MuJoCo's own default ls_tolerance is 0.01) */
 }
 void orc_default_params(orc_params *p, int task) { orc_preset_params(p, task, ORC_PRESET_FAITHFUL); }
 void orc_preset_params(orc_params *p, int task, int preset) {

@@ -450,7 +450,7 @@ def test_vecenv_single_env_observations_do_not_alias_the_fetch_buffer(hip_lib):
 @pytest.mark.gpu
 def test_vecenv_step_is_vectorised(hip_lib):
     """no per-env python work: infos of unfinished envs share one dict, and a 65 536-env step through the SB3-style adapter
-    (host actions in, packed device-to-host copy out) runs at > 1e7 env-steps/s"""
+    (host actions in, packed device-to-host copy out) runs at > 1e6 env-steps/s even with the GPU shared by the suite's workers"""
     import time
 
     from gym_lowcostrobot_amd import LowCostRobotVecEnv
@@ -469,7 +469,9 @@ def test_vecenv_step_is_vectorised(hip_lib):
     live = np.nonzero(~dones)[0]
     assert infos[live[0]] is infos[live[-1]]            # shared dict for envs that did not finish
     print(f"[vecenv] {n} envs: {dt * 1e3:.2f} ms per step = {n / dt:.3e} env-steps/s through LowCostRobotVecEnv.step")
-    assert n / dt > 1e7
+    # alone on the GPU: 4.3 ms per step with the default (faithful, Newton) preset, 1.6 ms with preset fast (tools/facade_latency2.py); the suite runs four GPU
+    # processes at once (-n 4), so the bound only has to tell a vectorised host path from a per-env python loop (which is > 100 ms)
+    assert n / dt > 1e6
     v.close()
 
 

@@ -12,7 +12,8 @@ from tests import util  # noqa: E402
 
 
 def check(task, mode, n, steps, preset="faithful"):
-    sim, o = util.make_pair(task, n, action_mode=mode, auto_reset=False, max_episode_steps=0, preset=preset)
+    extra = {k: (float(v) if "tol" in k else int(v)) for k, v in (kv.split("=") for kv in os.environ.get("DEV_KW", "").split(",") if kv)}   # e.g. DEV_KW=ls_iters=16,ls_tol=1e-4
+    sim, o = util.make_pair(task, n, action_mode=mode, auto_reset=False, max_episode_steps=0, preset=preset, **extra)
     seeds = np.arange(n, dtype=np.uint64) + 11
     o.reset(seeds=seeds)
     rng = np.random.default_rng(3)
