@@ -136,7 +136,7 @@ static int config_base(lcr_config *cfg, int task) {
     cfg->cc_points = 0;
     cfg->global_envs = 0;   // this handle is the whole job
     cfg->solver = LCR_SOLVER_PGS;
-    cfg->newton_iters = 20;
+    cfg->newton_iters = 30;
     cfg->ls_iters = 8;
     cfg->finger_floor_condim = 0;
     cfg->newton_tol = 1e-6;
@@ -351,7 +351,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             const size_t waves2 = 2 * ((N + 63) / 64), simds = 4 * (size_t)prop.multiProcessorCount;
             const int64_t job = cfg->global_envs > 0 ? cfg->global_envs : (int64_t)N;
             D.cc8 = (cfg->task == LCR_TASK_STACK && cfg->cc_points == 8) ? 1 : 0;
-            bool two_wave = job <= 32768 || cfg->task != LCR_TASK_STACK;
+            // StackTwoCubes: two-wave workgroups while the JOB's 2 x job / 64 waves fit one per SIMD -- 32 envs per SIMD of the part the job runs on (MI355X: 1 024 SIMDs
+            // -> 32 768 envs).  Every shard of a job runs on the same part and declares the same global_envs: the same family on all of them
+            const int64_t stack_two_wave_max = 32 * (int64_t)simds;
+            bool two_wave = job <= stack_two_wave_max || cfg->task != LCR_TASK_STACK;
             if (cfg->step_kernel == 1) two_wave = false;
             else if (cfg->step_kernel == 2) two_wave = true;
             if (D.cc8) two_wave = true;                               // the eight-point manifold lives in the two-wave kernels only

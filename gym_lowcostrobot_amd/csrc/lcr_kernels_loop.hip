@@ -498,6 +498,10 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
     const float srad[2] = {SPH0r, SPH1r};
+    // (NEWTON = the faithful preset) the finger pads as boxes: centre, link axes, half extents (lcr_step_common.h pad_box / pad_floor; oracle finger_geom = 1)
+    const f3 padc[2] = {local_point(F, 4, PAD0cx, PAD0cy, PAD0cz), local_point(F, 5, PAD1cx, PAD1cy, PAD1cz)};
+    const f3 padh[2] = {mk(PAD0hx, PAD0hy, PAD0hz), mk(PAD1hx, PAD1hy, PAD1hz)};
+    const float padr[2] = {0.01293f, 0.01369f};   // |half extents|: bounding radius for the broad phase
     bool body_done[2] = {false, false};   // (NEWTON) the angular rows of finger body 0 / 1 are in LDS (wave-uniform)
 #pragma unroll
     for (int s = 0; s < NAS; s++) {
@@ -516,22 +520,35 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             bool near_any = false;
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const f3 dd = sph[sp] - S.cp[c];
-                near_any = near_any || dot(dd, dd) < (srad[sp] + 1.7321f * CH) * (srad[sp] + 1.7321f * CH);
+                const f3 dd = (NEWTON ? padc[sp] : sph[sp]) - S.cp[c];
+                const float reach_ = (NEWTON ? padr[sp] : srad[sp]) + 1.7321f * CH;
+                near_any = near_any || dot(dd, dd) < reach_ * reach_;
             }
             if (__any(near_any))
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const SBHit hit = sphere_box(sph[sp], srad[sp], S.cp[c], CR[c]);
-                if (hit.dist < bestd) { bestd = hit.dist; cidx = c; n = hit.n; pos = hit.pos; sel = 8 * c + hit.code; }  // deepest cube wins (tie: cube 0)
+                if constexpr (NEWTON) {
+                    const int L = sp == 0 ? 4 : 5;
+                    const SBHit hit = pad_box(padc[sp], F.X[L], F.Y[L], F.Z[L], padh[sp], S.cp[c], CR[c]);
+                    if (hit.dist < bestd) { bestd = hit.dist; cidx = c; n = hit.n; pos = hit.pos; sel = c + 4 * hit.code; }  // deepest cube wins (tie: cube 0)
+                } else {
+                    const SBHit hit = sphere_box(sph[sp], srad[sp], S.cp[c], CR[c]);
+                    if (hit.dist < bestd) { bestd = hit.dist; cidx = c; n = hit.n; pos = hit.pos; sel = 8 * c + hit.code; }  // deepest cube wins (tie: cube 0)
+                }
             }
             dist = bestd;
             slot_cube[sp] = cidx;
         } else if (s < 4) {
-            const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
-            dist = sph[sp].z - srad[sp] - htop;
-            pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
-            sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
+            if constexpr (NEWTON) {
+                const int L = sp == 0 ? 4 : 5;
+                const PadFloorHit hit = pad_floor<WALLS>(PadBox{padc[sp], padh[sp].x * F.X[L], padh[sp].y * F.Y[L], padh[sp].z * F.Z[L]});
+                dist = hit.dist; pos = hit.pos; sel = hit.code;
+            } else {
+                const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
+                dist = sph[sp].z - srad[sp] - htop;
+                pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
+                sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
+            }
         } else if (P.arm_collision) {
             // arm-link proxies (D3): both ends of link_3, link_4 motor, link_5 motor body, link_6 jaw root.  One contact: the
             // deepest candidate in the order proxy 0 floor, proxy 1 floor, proxy 2 floor, proxy 3 floor, proxy 3 cubes, proxy 4
@@ -580,7 +597,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
         T.act = dist < 0.f;
         if (P.diag) {
-            if (may_cube && (s < 2 || oncube)) sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : 16;   // branch of make_frame
+            if (may_cube && (s < 2 || oncube)) sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : ((NEWTON && s < 2) ? 2 : 16);   // branch of make_frame (pad boxes: sel = cube + 2 branch + 4 code)
             diag_choice(DG, T.act, 12 + s, sel);
         }
         slot_any[s] = __any(T.act) != 0;

@@ -121,6 +121,7 @@ DEV void solve_packed(const float (&H)[NX * (NX + 1) / 2], const float (&id)[NX]
 }
 
 // friction of the finger geoms against the floor (follower.xml:15: friction="1.5" + MuJoCo's default torsional 0.005 / rolling 0.0001; the finger class has priority 1)
+constexpr float DEC_FLOOR = 3e-10f;   // a Newton decrement below DEC_FLOOR |x - a0|_M^2 that no longer shrinks is rounding (oracle: DEC_FLOOR)
 constexpr float LS_NOISE = 1e-5f;   // relative rounding floor of phi'(al) in fp32 (oracle: LS_NOISE)
 constexpr float MU_ROLL = 1e-4f;
 constexpr float RR_FF = (MU_FINGER * MU_FINGER) / (MU_ROLL * MU_ROLL);   // regulariser scale of the rolling rows: mu_tan^2 / mu_roll^2
@@ -686,6 +687,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     dots(std::true_type{}, x, zs);
     const float tol2 = P.newton_tol * P.newton_tol * scale;
     int lane_its = 0;   // iterations in which THIS env still moved (what the oracle counts per env)
+    float dprev = 3.0e38f;
     for (int it = 0; it < P.newton_iters; it++) {
         float dx[NX], d0 = 0.f;
         {
@@ -698,7 +700,14 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
 #pragma unroll
             for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
         }
-        const bool live = -d0 > tol2;   // Newton decrement above the tolerance: this lane still moves
+        // Newton decrement above the tolerance: this lane still moves.  Second exit (oracle: DEC_FLOOR): the gradient M (x - a0) - J'f carries the cancellation of stiff
+        // rows (f = -z / R), its fp32 rounding leaves a decrement that no iteration removes and that can lie far above newton_tol^2 (1 + |a0|_M^2) -- recognised as a
+        // decrement at rounding level relative to the problem (<= 3e-10 |x - a0|_M^2) that has stopped shrinking (not below a quarter of the previous iteration's)
+        float dist2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) dist2 = fmaf(mdiag(i) * (x[i] - x0[i]), x[i] - x0[i], dist2);
+        const bool live = -d0 > tol2 && !(-d0 <= DEC_FLOOR * dist2 && -d0 >= 0.25f * dprev);
+        dprev = -d0;
         if (!__any(live)) break;
         lane_its += live ? 1 : 0;
         dots(std::false_type{}, dx, jd);

@@ -365,6 +365,110 @@ DEV SBHit sphere_box(f3 centre, float rad, f3 cp, const CubeRot &R) {
     return h;
 }
 
+// ---- finger pads as boxes (the faithful preset; oracle: collide_plane_pad / collide_box_pad, orc_params.finger_geom = 1): one box per finger fitted to the two outermost
+// slabs of the finger's collision hull (lcr_model_gen.h PAD*; follower.xml:15,89,97).  Against the floor the lowest vertex decides, against a cube vertex-in-box tests both
+// ways (the pad's vertices in the cube, the cube's in the pad); the vertices of the same face within PAD_BLEND of the deepest one share the contact point. ----
+constexpr float PAD_BLEND = 0.0005f;
+struct PadBox { f3 c, ax, ay, az; };   // centre and the link's axes scaled by the half extents
+DEV f3 pad_vertex(const PadBox &B, int i) { return B.c + ((i & 1) ? B.ax : neg(B.ax)) + ((i & 2) ? B.ay : neg(B.ay)) + ((i & 4) ? B.az : neg(B.az)); }
+struct PadFloorHit { float dist, htop; f3 pos; int code; };
+template <bool WALLS>
+DEV PadFloorHit pad_floor(const PadBox &B) {
+    float depth[8], htop[8];
+    f3 v[8];
+    int best = 0;
+    float bd = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        v[i] = pad_vertex(B, i);
+        htop[i] = WALLS ? rail_top(v[i].x, v[i].y) : 0.f;
+        depth[i] = htop[i] - v[i].z;
+        if (depth[i] > bd) { bd = depth[i]; best = i; }
+    }
+    float hb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) hb = best == i ? htop[i] : hb;
+    float wsum = 0.f, px = 0.f, py = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float w = (htop[i] == hb) ? fmaxf(depth[i] - bd + PAD_BLEND, 0.f) : 0.f;
+        wsum += w; px = fmaf(w, v[i].x, px); py = fmaf(w, v[i].y, py);
+    }
+    const float iw = rcp(fmaxf(wsum, 1e-30f));
+    PadFloorHit h;
+    h.dist = -bd; h.htop = hb;
+    h.pos = mk(px * iw, py * iw, fmaf(-0.5f, bd, hb));
+    h.code = 2 * best + (hb > 0.f ? 1 : 0);
+    return h;
+}
+// point q inside the box (centre c, unit axes X, Y, Z, half extents h)?  depth to the nearest face, that face (2 k + (negative side)), local coordinates
+DEV bool point_in_box(f3 q, f3 c, f3 X, f3 Y, f3 Z, f3 h, float &depth, int &face, f3 &l) {
+    const f3 d = q - c;
+    l = mk(dot(X, d), dot(Y, d), dot(Z, d));
+    const float dx = h.x - fabsf(l.x), dy = h.y - fabsf(l.y), dz = h.z - fabsf(l.z);
+    int k = 0; float bd = dx;
+    if (dy < bd) { bd = dy; k = 1; }
+    if (dz < bd) { bd = dz; k = 2; }
+    depth = bd;
+    face = 2 * k + (((k == 0 ? l.x : (k == 1 ? l.y : l.z)) < 0.f) ? 1 : 0);
+    return dx > 0.f && dy > 0.f && dz > 0.f;
+}
+// pad box (link axes PX, PY, PZ unit, half extents ph, centre pc) vs cube: SBHit as sphere_box, code = (kind * 6 + face) * 8 + vertex
+DEV SBHit pad_box(f3 pc, f3 PX, f3 PY, f3 PZ, f3 ph, f3 cp, const CubeRot &R) {
+    const f3 hc = mk(CH, CH, CH);
+    float depth[16];
+    int face[16];
+    bool in[16];
+    f3 loc[16];
+    int best = -1;
+    float bd = -1.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i < 8) {
+            const f3 w = pc + ((i & 1) ? ph.x : -ph.x) * PX + ((i & 2) ? ph.y : -ph.y) * PY + ((i & 4) ? ph.z : -ph.z) * PZ;
+            in[i] = point_in_box(w, cp, R.X, R.Y, R.Z, hc, depth[i], face[i], loc[i]);
+        } else {
+            const int j = i - 8;
+            const f3 u = cp + ((j & 1) ? CH : -CH) * R.X + ((j & 2) ? CH : -CH) * R.Y + ((j & 4) ? CH : -CH) * R.Z;
+            in[i] = point_in_box(u, pc, PX, PY, PZ, ph, depth[i], face[i], loc[i]);
+        }
+        if (in[i] && depth[i] > bd) { bd = depth[i]; best = i; }
+    }
+    SBHit h;
+    h.dist = 1.f; h.n = mk(0.f, 0.f, 1.f); h.pos = mk(0.f, 0.f, 0.f); h.code = 0;
+    if (best < 0) return h;
+    const bool typeB = best >= 8;
+    int fb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) fb = best == i ? face[i] : fb;
+    const int k = fb >> 1;
+    const float sg = (fb & 1) ? -1.f : 1.f;
+    float wsum = 0.f;
+    f3 q = mk(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const bool same = in[i] && (i >= 8) == typeB && face[i] == fb;
+        const float w = same ? fmaxf(depth[i] - bd + PAD_BLEND, 0.f) : 0.f;
+        wsum += w; q = axpy(w, loc[i], q);
+    }
+    q = rcp(fmaxf(wsum, 1e-30f)) * q;
+    const float dist = -bd;
+    const float hk = typeB ? (k == 0 ? ph.x : (k == 1 ? ph.y : ph.z)) : CH;
+    const float qk = sg * hk + sg * dist * 0.5f;
+    q = mk(k == 0 ? qk : q.x, k == 1 ? qk : q.y, k == 2 ? qk : q.z);
+    const f3 nl = mk(k == 0 ? sg : 0.f, k == 1 ? sg : 0.f, k == 2 ? sg : 0.f);
+    if (!typeB) {
+        h.n = axpy(nl.x, R.X, axpy(nl.y, R.Y, nl.z * R.Z));
+        h.pos = axpy(q.x, R.X, axpy(q.y, R.Y, axpy(q.z, R.Z, cp)));
+    } else {
+        h.n = neg(axpy(nl.x, PX, axpy(nl.y, PY, nl.z * PZ)));
+        h.pos = axpy(q.x, PX, axpy(q.y, PY, axpy(q.z, PZ, pc)));
+    }
+    h.dist = dist;
+    h.code = ((typeB ? 6 : 0) + fb) * 8 + (best & 7);
+    return h;
+}
+
 // per-env diagnostics of one control step (written only when LcrDev.diag): which constraint slots were active (bit = slot id:
 // 0-7 floor<->cube, 8-11 cube<->cube / rails, 12-13 finger<->cube, 14-15 finger<->floor, 16 arm-link proxies, 18+j limit j),
 // the number of (slot, substep) activations, and the largest PGS sweep count of a substep

@@ -270,6 +270,8 @@ class VecSim:
         """last frames (camera_front, camera_top) of the episodes the last step ended in the listed envs, ray-cast as ONE batch from their
         terminal poses (the envs themselves have already been reset): two (len(env_ids), 240, 320, 3) uint8 arrays"""
         ids = np.ascontiguousarray(env_ids, np.int32)
+        if ids.size and self.image_front is not None and ids.min() >= 0 and ids.max() < self.n and not self.did_reset.numpy()[ids].all():   # (lcr.h: the terminal poses belong to envs the LAST step reset; anything else is a stale frame)
+            raise ValueError("render_terminal: every listed env must have finished an episode in the last step (did_reset)")
         front = np.empty((ids.size, _capi.IMG_H, _capi.IMG_W, 3), np.uint8)
         top = np.empty_like(front)
         check(self.L.lcr_render_terminal(self.handle, _vp(ids), int(ids.size), _vp(front), _vp(top)))

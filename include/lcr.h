@@ -100,7 +100,7 @@ typedef struct lcr_config {
                                   DESIGN.md).  0 = the task's default */
     int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by task and JOB size (global_envs below, never the shard size n_envs): two
                                   cooperating waves per 64 envs for ReachCube / LiftCube / PushCube / PickPlaceCube at every size and for StackTwoCubes
-                                  jobs of <= 32 768 envs, one wave per 64 envs for larger Stack jobs -- the faster family when the job runs as ONE shard
+                                  jobs of <= 32 envs per SIMD of the device (MI355X: 32 768 envs), one wave per 64 envs for larger Stack jobs -- the faster family when the job runs as ONE shard
                                   on an MI355X; 1 = one wave per 64 envs always; 2 = two cooperating waves always (the faster family on shards of
                                   <= 32 768 envs whatever the job size: a Stack job sharded that finely pins 2).  PushCubeLoop has ONE kernel (one wave
                                   per 64 envs, its own row-wise solver): 0 and 1 run it, 2 is LCR_ERR_UNSUPPORTED.  The families
@@ -122,7 +122,7 @@ typedef struct lcr_config {
                                   constraint forces -- MuJoCo's default solver (follower.xml:3 names none); reaches the optimum of MuJoCo's convex constraint problem to
                                   float rounding (tools/kkt_distance.py).  LCR_SOLVER_PGS: pgs_iters warm-started sweeps of a block projected-gradient step on the dual
                                   problem (rounds 1-4; p90 2e-4 / p99 1e-2 rad per control step away from that optimum at four sweeps). */
-    int32_t newton_iters;      /* LCR_SOLVER_NEWTON: most iterations per substep (20: what bounds a cold start on a hard contact set -- warm-started, an env needs one on average and seven at the 99th percentile); a wave leaves the loop when every one of its envs has converged */
+    int32_t newton_iters;      /* LCR_SOLVER_NEWTON: most iterations per substep (30: what bounds a cold start on a hard contact set -- a finger set 5 mm into the floor -- warm-started, an env needs one on average and seven at the 99th percentile); a wave leaves the loop when every one of its envs has converged */
     int32_t ls_iters;          /* ... most evaluations of phi' per line search (8) */
     int32_t finger_floor_condim; /* rows of a finger<->floor contact: 6 = MuJoCo's (follower.xml:15 condim="6": + two rolling rows, coefficient 1e-4 m), 4 = without
                                   them.  0 = the preset's default.  6 is implemented by the Newton kernels (LCR_SOLVER_PGS with 6: LCR_ERR_UNSUPPORTED) */
@@ -287,7 +287,10 @@ int lcr_render_state(lcr_sim *sim, int camera, int width, int height, const doub
  * examples/gym_manipulation_sb3.py:34-39 with observation_mode image / both; reach_cube_env.py:288-292): the step kernel has already reset
  * those envs, so their frame buffers show the reset state; this draws camera_front / camera_top of the TERMINAL poses (terminal_obs +
  * terminal_quat of the last step) of the `count` listed envs with the observation ray-caster, as one batch, into
- * front_host / top_host [count][240][320][3].  Needs observation_mode image / both.  Synchronous. */
+ * front_host / top_host [count][240][320][3].  Needs observation_mode image / both.  Synchronous.
+ * PRECONDITION: every listed env was reset by the LAST lcr_step (out.did_reset[id] != 0) -- the terminal pose arrays are written only by lanes that auto-reset, an
+ * env that did not finish shows the last frame of an OLDER episode (or zeros before its first reset).  The library does not re-read did_reset here; the Python
+ * binding (VecSim.render_terminal) checks it and raises ValueError. */
 int lcr_render_terminal(lcr_sim *sim, const int32_t *env_ids_host, int count, uint8_t *front_host, uint8_t *top_host);
 
 /* Measurement support: copy n_floats floats from the start of the state arena to dst_dev with one dword load and

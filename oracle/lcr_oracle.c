@@ -83,6 +83,12 @@ static const double SITE_POS[3] = {-0.06429, 0.00327, 0.0011}; /* follower.xml:9
 static const int SPH_LINK[NSPH] = {4, 5};
 static const double SPH_POS[NSPH][3] = {{-0.0610, 0.0142, 0.0005}, {-0.0490, 0.0072, -0.0140}};
 static const double SPH_RAD[NSPH] = {0.0065, 0.0065};
+/* (round 5, orc_params.finger_geom = 1 = preset faithful) the finger pads as POLYTOPES: one box per finger -- the bounding box of the two outermost slabs of
+ * the finger's collision hull (tests/golden/model_golden.json "mesh_slabs_x" link_5_collision / link_6_collision [0..1]; follower.xml:15,89,97: the finger geoms
+ * are those hulls) -- in the link frame: centre, half extents.  17 x 12 x 15 mm and 16 x 15 x 16 mm; the spheres above are inscribed in them. */
+static const double PAD_C[NSPH][3] = {{-0.06051, 0.01414, 0.000345}, {-0.04772, 0.005415, -0.01394}};
+static const double PAD_H[NSPH][3] = {{0.0087, 0.00579, 0.007575}, {0.008, 0.007715, 0.00799}};
+#define PAD_BLEND 0.0005   /* vertices within 0.5 mm of the deepest one share the contact point (weights linear in depth): a flat pad face rests on its middle */
 /* (D3) arm-link proxies: the remaining arm geoms that can reach the floor or the cube (follower.xml:10 visual geoms have
  * contype=conaffinity=1, :13 collision hulls; geoms :70-98) are restated as spheres inscribed in the motor / bracket
  * volumes of their hulls (mesh extents: tests/golden/model_golden.json "mesh_aabb").  link_1 / link_2 / base cannot
@@ -525,6 +531,107 @@ static int collide_plane_sphere_g(const real *centre, double radius, int link, r
     make_frame(ct->frame, nz);
     ct->b1 = -1; ct->b2 = link; ct->dist = dist;
     ct->sel = htop > 0 ? 1 : 0;   /* which surface: part of the decision signature */
+    return 1;
+}
+/* ---- finger pads as boxes (orc_params.finger_geom = 1).  MuJoCo's convex collider returns ONE contact for a mesh hull against a box, and the deepest points of a
+ * hull against a plane; here: vertex-in-box tests both ways (the pad's 8 vertices in the cube, the cube's 8 in the pad; edge-edge crossings without a vertex
+ * inside are not seen -- remaining part of deviation D3), the deepest one decides face and normal, and the vertices of the same face within PAD_BLEND of it
+ * share the contact point. ---- */
+static void pad_vertices(const kin_t *K, int s, real v[8][3], real centre[3]) {
+    const real *R = K->R[SPH_LINK[s] + 1];
+    real c[3] = {(real)PAD_C[s][0], (real)PAD_C[s][1], (real)PAD_C[s][2]}, t[3];
+    m3v(t, R, c);
+    v3add(centre, K->p[SPH_LINK[s] + 1], t);
+    for (int i = 0; i < 8; i++) {
+        real l[3] = {(i & 1) ? (real)PAD_H[s][0] : (real)-PAD_H[s][0], (i & 2) ? (real)PAD_H[s][1] : (real)-PAD_H[s][1], (i & 4) ? (real)PAD_H[s][2] : (real)-PAD_H[s][2]};
+        m3v(t, R, l);
+        v3add(v[i], centre, t);
+    }
+}
+static int collide_plane_pad(const kin_t *K, int s, int walls, contact_t *ct) {
+    real v[8][3], pc[3], depth[8], htop[8];
+    pad_vertices(K, s, v, pc);
+    int best = 0;
+    for (int i = 0; i < 8; i++) {
+        htop[i] = walls ? rail_top(v[i][0], v[i][1]) : (real)0;
+        depth[i] = htop[i] - v[i][2];
+        if (depth[i] > depth[best]) best = i;
+    }
+    if (!(depth[best] > 0)) return 0;
+    real wsum = 0, px = 0, py = 0;
+    for (int i = 0; i < 8; i++) {
+        real w = depth[i] - depth[best] + (real)PAD_BLEND;
+        if (!(w > 0) || htop[i] != htop[best]) continue;
+        wsum += w; px += w * v[i][0]; py += w * v[i][1];
+    }
+    const real dist = -depth[best];
+    v3set(ct->pos, px / wsum, py / wsum, htop[best] + dist * (real)0.5);
+    real nz[3] = {0, 0, 1};
+    make_frame(ct->frame, nz);
+    ct->b1 = -1; ct->b2 = SPH_LINK[s]; ct->dist = dist;
+    ct->sel = 2 * best + (htop[best] > 0 ? 1 : 0);
+    ct->slot = 14 + s;
+    ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER;
+    ct->dim = 4;
+    return 1;
+}
+/* point q (world) inside the box (centre c, rotation R columns = axes, half extents h)?  depth to the nearest face, that face (2 k + (negative side)), local coords */
+static int point_in_box(const real *q, const real *c, const real *R, const real *h, real *depth, int *face, real *l) {
+    real d[3];
+    v3sub(d, q, c);
+    m3tv(l, R, d);
+    real bd = 0; int bf = -1;
+    for (int k = 0; k < 3; k++) {
+        const real a = l[k] < 0 ? -l[k] : l[k];
+        if (!(a < h[k])) return 0;
+        const real dk = h[k] - a;
+        if (bf < 0 || dk < bd) { bd = dk; bf = 2 * k + (l[k] < 0 ? 1 : 0); }
+    }
+    *depth = bd; *face = bf;
+    return 1;
+}
+static int collide_box_pad(const kin_t *K, int c, int s, contact_t *ct) {
+    real v[8][3], pc[3], cv[8][3];
+    pad_vertices(K, s, v, pc);
+    const real *Rp = K->R[SPH_LINK[s] + 1];
+    const real hc[3] = {(real)CUBE_HALF, (real)CUBE_HALF, (real)CUBE_HALF}, hp[3] = {(real)PAD_H[s][0], (real)PAD_H[s][1], (real)PAD_H[s][2]};
+    for (int i = 0; i < 8; i++) {
+        real l[3] = {(i & 1) ? hc[0] : -hc[0], (i & 2) ? hc[1] : -hc[1], (i & 4) ? hc[2] : -hc[2]}, t[3];
+        m3v(t, K->cR[c], l);
+        v3add(cv[i], K->cp[c], t);
+    }
+    /* candidates 0-7: pad vertex i inside the cube; 8-15: cube vertex i inside the pad */
+    real depth[16], loc[16][3];
+    int face[16], in[16], best = -1;
+    for (int i = 0; i < 16; i++) {
+        in[i] = i < 8 ? point_in_box(v[i], K->cp[c], K->cR[c], hc, &depth[i], &face[i], loc[i]) : point_in_box(cv[i - 8], pc, Rp, hp, &depth[i], &face[i], loc[i]);
+        if (in[i] && (best < 0 || depth[i] > depth[best])) best = i;
+    }
+    if (best < 0) return 0;
+    const int typeB = best >= 8, k = face[best] >> 1;
+    const real sg = (face[best] & 1) ? (real)-1 : (real)1;
+    /* contact point: the blended vertices projected onto the penetrated face, then half the depth back inside */
+    real wsum = 0, q[3] = {0, 0, 0};
+    for (int i = typeB ? 8 : 0; i < (typeB ? 16 : 8); i++) {
+        if (!in[i] || face[i] != face[best]) continue;
+        real w = depth[i] - depth[best] + (real)PAD_BLEND;
+        if (!(w > 0)) continue;
+        wsum += w;
+        for (int a = 0; a < 3; a++) q[a] += w * loc[i][a];
+    }
+    for (int a = 0; a < 3; a++) q[a] /= wsum;
+    const real dist = -depth[best];
+    q[k] = sg * (typeB ? hp[k] : hc[k]) + sg * dist * (real)0.5;
+    real nl[3] = {0, 0, 0}, nw[3], pw[3];
+    nl[k] = sg;
+    if (!typeB) { m3v(nw, K->cR[c], nl); m3v(pw, K->cR[c], q); v3add(ct->pos, pw, K->cp[c]); }          /* outward normal of the cube's face: cube -> finger */
+    else { m3v(nw, Rp, nl); for (int a = 0; a < 3; a++) nw[a] = -nw[a]; m3v(pw, Rp, q); v3add(ct->pos, pw, pc); }   /* outward normal of the pad's face points at the cube */
+    make_frame(ct->frame, nw);
+    ct->b1 = 6 + c; ct->b2 = SPH_LINK[s]; ct->dist = dist;
+    ct->dim = 4;
+    ct->sel = c + 2 * ((ct->frame[1] < (real)0.5 && ct->frame[1] > (real)-0.5) ? 0 : 1) + 4 * ((typeB * 6 + face[best]) * 8 + (best & 7));   /* cube, frame branch, (kind, face, vertex) */
+    ct->slot = 12 + s;
+    ct->mu = K->mu_finger_cube; ct->solimp = SOLIMP_FINGER_CUBE;
     return 1;
 }
 static int collide_plane_sphere(const kin_t *K, int s, int walls, contact_t *ct) {
@@ -1229,6 +1336,7 @@ static int newton_primal(int nv, int nr, const real *M, const real *J, const rea
  *   at most newton_iters iterations (default 20: a cold start on a finger deep in the floor with both fingers and a proxy down needs 12).  On the GPU both loops are left wave-uniformly (when every lane of the wave has met the criterion), so a lane may
  *   iterate further than here -- at the optimum that changes nothing beyond rounding.
  * Returns the forces f(x) and the accelerations x themselves: the integration uses x (M (x - a0) = J' f at the optimum). */
+#define DEC_FLOOR 3e-10   /* a Newton decrement below DEC_FLOOR |x - a0|_M^2 that no longer shrinks is rounding (see newton_product) */
 #define LS_NOISE 1e-5   /* relative rounding floor of phi'(al) evaluated in float (about 40 terms of either sign) */
 static void prim_forces(int nr, const real *z, const real *Rr, const int *kind, const int *blkdim, const double *const *rowmu, real *f, real *W /* nr x 6 or NULL */) {
     for (int i = 0; i < nr; i++) {
@@ -1299,6 +1407,7 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
         }                                                                                                                                      \
     } while (0)
     int it;
+    double dprev = 1e300;
     for (it = 0; it < iters; it++) {
         NP_GRAD(x, W);
         for (int a = 0; a < nv; a++) for (int c = 0; c < nv; c++) H[a * nv + c] = M[a * nv + c];
@@ -1318,11 +1427,22 @@ static int newton_product(int nv, int nr, const real *M, const real *Lm, const r
         real d0 = 0;
         for (int a = 0; a < nv; a++) d0 += g[a] * dx[a];
         if (np_debug) {
-            fprintf(stderr, "np it=%d decrement=%.3e tol2=%.3e  zones:", it, (double)-d0, tol * tol * (double)scale);
+            real dd2 = 0;
+            for (int a = 0; a < nv; a++) { real acc = 0; for (int c = 0; c < nv; c++) acc += M[a * nv + c] * (x[c] - a0[c]); dd2 += (x[a] - a0[a]) * acc; }
+            fprintf(stderr, "np it=%d decrement=%.3e tol2=%.3e dist2=%.3e zones:", it, (double)-d0, tol * tol * (double)scale, (double)dd2);
             for (int i = 0; i < nr; i++) { if (kind[i] == 2) continue; fprintf(stderr, " [%d k%d z=%.3e f=%.3e R=%.1e]", i, kind[i], (double)z[i], (double)f[i], (double)Rr[i]); }
             fprintf(stderr, "\n");
         }
-        if (!((double)-d0 > tol * tol * (double)scale)) break;    /* Newton decrement: converged (or no descent) */
+        /* Newton decrement: converged (or no descent).  Second exit, for float arithmetic: the gradient M (x - a0) - J'f is a difference of two vectors of the same
+         * size whose force part carries the cancellation of stiff rows (f = -z / R, z = J x - aref, R ~ 1e-4): its rounding leaves a decrement that no iteration
+         * removes -- a finger pressed 5 mm into the floor: 1e-5 against newton_tol^2 (1 + |a0|_M^2) = 4e-9, and the float solve ran into its iteration budget in
+         * 9 of 10 such envs.  The floor is recognised by what it is: a decrement at rounding level RELATIVE to the problem (<= 3e-10 |x - a0|_M^2) that has stopped
+         * shrinking (not below a quarter of the previous iteration's).  In double a converging iteration never meets both (it shrinks quadratically down there). */
+        real dist2 = 0;
+        for (int a = 0; a < nv; a++) { real acc = 0; for (int c = 0; c < nv; c++) acc += M[a * nv + c] * (x[c] - a0[c]); dist2 += (x[a] - a0[a]) * acc; }
+        if (!((double)-d0 > tol * tol * (double)scale)) break;
+        if ((double)-d0 <= DEC_FLOOR * (double)dist2 && (double)-d0 >= 0.25 * dprev) break;
+        dprev = (double)-d0;
         /* line search on phi'(al) = grad F(x + al dx) . dx, monotone increasing, with phi''(al) = dx'M dx + sum_b jd_b' W_b(al) jd_b from the same pass */
         real q1 = 0;
         for (int a = 0; a < nv; a++) { real acc = 0; for (int c = 0; c < nv; c++) acc += M[a * nv + c] * dx[c]; q1 += dx[a] * acc; }
@@ -1513,12 +1633,12 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
         int have = 0;
         for (int c = 0; c < nc; c++) {
             contact_t tmp;
-            if (collide_box_sphere(&K, c, s, &tmp) && (!have || tmp.dist < cand[0].dist)) { cand[0] = tmp; have = 1; }
+            if ((P->finger_geom == 1 ? collide_box_pad(&K, c, s, &tmp) : collide_box_sphere(&K, c, s, &tmp)) && (!have || tmp.dist < cand[0].dist)) { cand[0] = tmp; have = 1; }
         }
         if (have) con[ncon++] = cand[0];
     }
     for (int s = 0; s < NSPH; s++)
-        if (collide_plane_sphere(&K, s, T->walls, con + ncon)) ncon++;
+        if (P->finger_geom == 1 ? collide_plane_pad(&K, s, T->walls, con + ncon) : collide_plane_sphere(&K, s, T->walls, con + ncon)) ncon++;
     if (P->arm_collision)
         for (int g = 0; g < (P->proxy_groups == 3 ? 3 : 1); g++)
             if (collide_link_group(&K, g, P->proxy_groups == 3 ? 3 : 1, T->walls, con + ncon)) ncon++;
@@ -1635,7 +1755,7 @@ static void substep(const orc_params *P, const task_model *T, real *qpos, real *
             max_it = 0;
         }
         if (P->solver == 2) {   /* the product's faithful solver: Newton on the primal with a fixed budget (see newton_product) */
-            const int nit = newton_product(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, xsol, P->newton_iters > 0 ? P->newton_iters : 20,
+            const int nit = newton_product(nv, nr, M, L, J, aref, Rr, a0, kind, blkdim, rowmu, f, xsol, P->newton_iters > 0 ? P->newton_iters : 30,
                                            P->ls_iters > 0 ? P->ls_iters : 8, P->newton_tol > 0 ? P->newton_tol : 1e-6, P->ls_tol > 0 ? P->ls_tol : 1e-2);
             use_x = 1;
             if (getenv("ORC_SWEEP_SUM")) lag->max_sweeps += (uint32_t)nit;
@@ -1779,7 +1899,7 @@ static void params_base(orc_params *p, int task) {   /* the reference's construc
     p->solver = 0;    /* PGS (what the kernels run) */
     p->jacobi = task == ORC_TASK_PUSH_LOOP ? 0 : 1;    /* two sweep groups (arm-only rows | cube rows) that sweep concurrently: what the kernels' two waves do */
     p->condim6 = (task == ORC_TASK_PUSH_LOOP || task == ORC_TASK_STACK) ? 1 : 0; /* as lcr_config_default: rolling rows where they matter (D4) */
-    p->newton_iters = 20; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-2;   /* (read by solver = 2 only; = lcr_config_default.  ls_tol: MuJoCo's own default ls_tolerance is 0.01) */
+    p->newton_iters = 30; p->ls_iters = 8; p->newton_tol = 1e-6; p->ls_tol = 1e-2;   /* (read by solver = 2 only; = lcr_config_default.  ls_tol: MuJoCo's own default ls_tolerance is 0.01) */
 }
 void orc_default_params(orc_params *p, int task) { orc_preset_params(p, task, ORC_PRESET_FAITHFUL); }
 void orc_preset_params(orc_params *p, int task, int preset) {
@@ -1788,6 +1908,7 @@ void orc_preset_params(orc_params *p, int task, int preset) {
         p->solver = 2;                       /* Newton on the primal: MuJoCo's default solver (follower.xml:3 names none) */
         p->condim6 = 2;                      /* follower.xml:15 condim="6" on every finger contact */
         p->cc_points = 8;                    /* as many points as MuJoCo's box-box collider may return (stack_two_cubes.xml:25-35) */
+        p->finger_geom = 1;                  /* the finger pads as boxes fitted to the tips of the collision hulls (follower.xml:15,89,97) instead of inscribed spheres */
     }
 }
 int orc_nq(int task) { return task == ORC_TASK_STACK ? 20 : 13; }
@@ -2167,6 +2288,10 @@ int orc_model_table(double *out) {
 }
 
 /* ---- model queries ---- */
+/* the finger pad boxes (finger_geom = 1): NSPH x (centre3, half3), link frames of SPH_LINK */
+void orc_pad_table(double *out) {
+    for (int s = 0; s < NSPH; s++) for (int k = 0; k < 3; k++) { out[6 * s + k] = PAD_C[s][k]; out[6 * s + 3 + k] = PAD_H[s][k]; }
+}
 void orc_fk(const double *q6, double *link_pos, double *site, double *spheres) {
     real q[6]; kin_t K;
     for (int j = 0; j < 6; j++) q[j] = (real)q6[j];

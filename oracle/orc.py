@@ -45,6 +45,7 @@ class OrcParams(ctypes.Structure):
         ("ls_iters", ctypes.c_int32),      # ... most evaluations of phi' per line search
         ("newton_tol", ctypes.c_double),
         ("ls_tol", ctypes.c_double),
+        ("finger_geom", ctypes.c_int32),
     ]
 
 

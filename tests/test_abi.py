@@ -40,7 +40,7 @@ def test_config_defaults_match_reference_ctor_defaults(hip_lib):
         assert cfg.solver == _capi.SOLVERS["newton"]                 # follower.xml:3 names no solver -> Newton
         assert cfg.finger_cube_condim == 6 and cfg.finger_floor_condim == 6   # follower.xml:15 condim="6" on every finger contact
         assert cfg.cc_points == (8 if task == "stack" else 0)       # stack_two_cubes.xml:25-35: box-box, up to eight points
-        assert cfg.newton_iters == 20 and cfg.ls_iters == 8 and cfg.newton_tol == 1e-6 and cfg.ls_tol == 1e-2
+        assert cfg.newton_iters == 30 and cfg.ls_iters == 8 and cfg.newton_tol == 1e-6 and cfg.ls_tol == 1e-2
         assert cfg.step_kernel == 0
         assert cfg.global_envs == 0                                  # ABI v4: this handle is the whole job
         fast = _capi.LcrConfig()

@@ -576,14 +576,18 @@ def test_batched_terminal_frames_match_the_per_env_raycast(hip_lib):
             np.testing.assert_array_equal(infos[e]["terminal_observation"]["arm_qpos"], t[0:6])
         # frames of the reset state differ from the terminal frames (the arm went back to q = 0)
         assert np.abs(obs["image_front"][fin[0]].astype(int) - infos[fin[0]]["terminal_observation"]["image_front"].astype(int)).max() > 20
-        ids = np.arange(n, dtype=np.int32)
+        ids = fin.astype(np.int32)                       # (the envs the last step reset: lcr.h precondition)
         t0 = time.perf_counter()
         fr, tp = sim.render_terminal(ids)
         dt = time.perf_counter() - t0
-        assert fr.shape == (n, 240, 320, 3) and tp.std() > 5
-        print(f"[terminal frames] {task}: {n} envs x 2 cameras in {dt * 1e3:.1f} ms (batched; worst pixel mismatch fraction {worst:.2e})")
+        assert fr.shape == (len(ids), 240, 320, 3) and tp.std() > 5
+        print(f"[terminal frames] {task}: {len(ids)} envs x 2 cameras in {dt * 1e3:.1f} ms (batched; worst pixel mismatch fraction {worst:.2e})")
         with pytest.raises(ValueError):
             sim.render_terminal([n])                          # out of range
+        v.step(np.zeros((n, v.action_space.shape[0]), np.float32))
+        if not sim.did_reset.numpy()[0]:
+            with pytest.raises(ValueError, match="did_reset"):
+                sim.render_terminal([0])                      # env 0 did not finish an episode in the last step: its terminal pose is stale (lcr.h precondition)
         v.close()
     s2 = LowCostRobotVecEnv("reach", 4, observation_mode="state")
     from gym_lowcostrobot_amd._capi import LcrError

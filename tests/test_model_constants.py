@@ -137,6 +137,27 @@ def test_header_derived_quantities_agree_with_the_oracle():
         assert [h[f"LPX{s}{ax}"] for ax in "xyz"] == [float(np.float32(v)) for v in px["pos"]] and h[f"LPX{s}r"] == np.float32(px["rad"])
 
 
+def test_finger_pad_boxes_follow_the_hull_slabs():
+    """the pad boxes of the faithful preset (oracle PAD_C / PAD_H, kernel PAD* of lcr_model_gen.h) are the bounding boxes of the two outermost slabs of the
+    fingers' collision hulls in the golden model file, and the round 1-4 finger spheres lie inside them"""
+    import ctypes
+
+    from tools import gen_model_header as gen
+
+    want = gen.pad_boxes(G)
+    got = (ctypes.c_double * 12)()
+    orc.lib().orc_pad_table(got)
+    h = _header_values()
+    t = orc.model_table()
+    for s, (c, hh) in enumerate(want):
+        np.testing.assert_allclose(list(got[6 * s: 6 * s + 3]), c, rtol=0, atol=5e-7)
+        np.testing.assert_allclose(list(got[6 * s + 3: 6 * s + 6]), hh, rtol=0, atol=5e-7)
+        assert [h[f"PAD{s}c{ax}"] for ax in "xyz"] == [float(np.float32(v)) for v in c]
+        assert [h[f"PAD{s}h{ax}"] for ax in "xyz"] == [float(np.float32(v)) for v in hh]
+        sp = t["spheres"][s]
+        assert all(abs(sp["pos"][k] - c[k]) <= hh[k] for k in range(3)), (s, sp, c, hh)     # the sphere's centre lies in the box
+
+
 SLACK = 2.5e-3
 
 

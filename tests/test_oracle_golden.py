@@ -293,7 +293,7 @@ def test_stack_manifold_keeps_offset_rotated_stacks():
 
 
 def test_pinch_grasp_holds_the_cube():
-    """finger<->cube contacts (two sphere proxies, mu=1.5, torsional friction): a 0.1 kg cube pinched in mid-air stays
+    """finger<->cube contacts (the two finger pads, mu=1.5, torsional friction): a 0.1 kg cube pinched in mid-air stays
     between the fingers against gravity (Lift); the 10 kg PickPlace cube (REF-QUIRK-4) drags the arm down instead"""
     from tests import util
     o = orc.Oracle("lift", 1, auto_reset=0, max_episode_steps=0)
@@ -303,10 +303,11 @@ def test_pinch_grasp_holds_the_cube():
         a = np.zeros((1, 6), np.float32); a[0, 5] = 0.2  # keep squeezing
         o.step(a)
     _, _, sph = orc.fk(o.qpos[0, :6])
-    assert np.abs(o.qpos[0, 6:9] - 0.5 * (sph[0] + sph[1])).max() < 1e-3   # still centred between the fingers
+    # still between the fingers (within 2.5 mm of the midpoint of the inscribed spheres: the pad boxes of the default preset are not symmetric about it; spheres: < 1 mm)
+    assert np.abs(o.qpos[0, 6:9] - 0.5 * (sph[0] + sph[1])).max() < 2.5e-3
     assert o.qpos[0, 8] > 0.15 and abs(o.qvel[0, 8]) < 1e-2                # and still up in the air
     rows, cons, _ = o.diag()
-    assert cons == 2 and rows == 12   # (two finger<->cube contacts of six rows each: follower.xml:15 condim="6")
+    assert cons == 2 and rows in (12, 13)   # (two finger<->cube contacts of six rows each: follower.xml:15 condim="6"; + a joint-limit row when the squeeze ends at one)
     h = orc.Oracle("pick_place", 1, auto_reset=0, max_episode_steps=0)
     h.reset(seeds=[0])
     util.pinch_setup(h)
@@ -610,7 +611,8 @@ def test_rolling_rows_of_the_finger_cube_contacts():
         for c6 in (0, 1):
             # (a property of the MODEL: evaluated with the exact solver, solver = 1 -- four sweeps per substep of the default iteration have not locked the
             #  rotation yet after the five substeps of this test)
-            o = orc.Oracle(task, n, auto_reset=0, max_episode_steps=0, condim6=c6, n_substeps=5, solver=1)
+            # (finger spheres: their two off-centre contact points are what turns the spin into tumbling; the pad boxes of the default preset meet the cube face on face)
+            o = orc.Oracle(task, n, auto_reset=0, max_episode_steps=0, condim6=c6, n_substeps=5, solver=1, finger_geom=0)
             o.reset(seeds=np.arange(n))
             util.pinch_setup(o)
             o.qvel[:, 9:12] = np.array([0.0, 0.0, 3.0])

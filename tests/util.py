@@ -264,8 +264,15 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
                 op.step(a, threads=0)
                 pq = np.abs(op.qpos[:, : sim.nq] - o.qpos[:, : sim.nq]).max(axis=1)
                 pv = np.abs(op.qvel[:, : sim.nv] - o.qvel[:, : sim.nv]).max(axis=1)
-                sens |= (pq > 0.25 * atol_q) | (pv > 0.25 * atol_v) | (op.choice != o.choice)
-            STATS["out_sens"] = STATS.get("out_sens", 0) + int((~ok & ~flip & ~ill & sens).sum())
+                # (a flipped decision alone is no witness -- near a contact-set change that is easy to trigger: it counts only together with a spread of at
+                #  least a tenth of the tolerance)
+                spread = (pq > 0.25 * atol_q) | (pv > 0.25 * atol_v)
+                sens |= spread | ((op.choice != o.choice) & ((pq > 0.1 * atol_q) | (pv > 0.1 * atol_v)))
+            exc = ~ok & ~flip & ~ill & sens
+            STATS["out_sens"] = STATS.get("out_sens", 0) + int(exc.sum())
+            if exc.any():   # (auditable: which envs this witness excused)
+                print(f"[parity] {where}: excused as sensitive to two-ulp input noise: envs {np.nonzero(exc)[0][:16].tolist()}, |dq| {dq[exc][:4]}")
+                STATS.setdefault("out_sens_by_task", {})[sim.task_name] = STATS.get("out_sens_by_task", {}).get(sim.task_name, 0) + int(exc.sum())
             ill = ill | sens
         if o.params.solver == 2:
             # Newton kernels: an env whose solve ran into the iteration budget on either side has not converged -- where it stops depends on the path (the analogue

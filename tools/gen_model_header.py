@@ -58,6 +58,23 @@ LPX_RAD = [0.0120, 0.0120, 0.0105, 0.0150, 0.0078]
 LPX_CUBE = [0, 0, 0, 1, 1]
 
 
+def pad_boxes(golden=None):
+    """[(centre, half extents)] of the two finger pad boxes in their link frames, from the hull slabs of the golden model file"""
+    import json
+    import os
+
+    if golden is None:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "model_golden.json")) as fh:
+            golden = json.load(fh)
+    out = []
+    for name in ("link_5_collision", "link_6_collision"):
+        sl = golden["mesh_slabs_x"][name][:2]
+        lo = [min(s_[a][0] for s_ in sl) for a in "xyz"]
+        hi = [max(s_[a][1] for s_ in sl) for a in "xyz"]
+        out.append(([0.5 * (a + b) for a, b in zip(lo, hi)], [0.5 * (b - a) for a, b in zip(lo, hi)]))
+    return out
+
+
 def quat2mat(q):
     w, x, y, z = np.asarray(q, float) / np.linalg.norm(q)
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
@@ -151,6 +168,13 @@ def main():
         for k, ax in enumerate("xyz"):
             L.append(f"constexpr float SPH{s}{ax} = {f(SPH_POS[s][k])};")
         L.append(f"constexpr float SPH{s}r = {f(SPH_RAD[s])};")
+    # finger pads as boxes (the faithful preset): bounding box of the two outermost slabs of each finger's collision hull, link frame (centre, half extents)
+    L.append("// finger pad boxes (preset faithful; oracle PAD_C / PAD_H): the two outermost slabs of link_5_collision / link_6_collision (model_golden.json mesh_slabs_x)")
+    for s, (c, h) in enumerate(pad_boxes()):
+        for k, ax in enumerate("xyz"):
+            L.append(f"constexpr float PAD{s}c{ax} = {f(c[k])};")
+        for k, ax in enumerate("xyz"):
+            L.append(f"constexpr float PAD{s}h{ax} = {f(h[k])};")
     for s in range(len(LPX_LINK)):
         for k, ax in enumerate("xyz"):
             L.append(f"constexpr float LPX{s}{ax} = {f(LPX_POS[s][k])};")

@@ -3,12 +3,11 @@
 The yard-stick is solver-independent: the CPU oracle's Newton solve of the primal problem (orc_params.solver = 1, the algorithm MuJoCo runs by default --
 follower.xml:3 names no solver), certified by the natural residual of the DUAL problem's KKT conditions (orc_io.kkt).  From identical states incl. the carried
 constraint forces (the product's default mode), ONE control step (20 substeps) is made with
-  default        4 warm-started sweeps of the block projected-gradient step (round 4)  = what both kernel families and the oracle's default run (deviation D1)
-  default8 / *   8 sweeps / swept until converged                                       -> the same fixed point as `exact`
-  rows+radial    rounds 1-3: row-by-row updates + radial cone projection, 4 sweeps      (deviations D1 + D2)
-  rows+radial*   ... swept until converged                                               -> isolates D2: its fixed point is not the optimum
-  qcqp           MuJoCo's PGS block update (ray step + exact friction QCQP), 4 sweeps
-  exact          the optimum itself (primal Newton)
+  default        round 5: preset faithful -- Newton's method on the primal with a fixed budget, six-row finger contacts, eight-point box-box (= the Newton kernels)
+  default-f32    the same in float arithmetic (the oracle's fp32 build)
+  fast / fast8   preset fast: 4 / 8 warm-started sweeps of the block projected-gradient step on its own (smaller) row set -- the rounds 1-4 default; its distance
+                 contains the contact-model deviations D4 / D5 as well as the unconverged solve D1
+  exact          the optimum itself (primal Newton to 1e-13)
 and |dqpos| of each against `exact` is reported per task, together with the KKT residual each variant leaves.
     python tools/kkt_distance.py [--n 512] [--steps 40] [--json profiles/r04_kkt_distance.json]
 """
@@ -27,15 +26,12 @@ STATE = ("qpos", "qvel", "ee_lag", "target", "elapsed", "rng", "goal", "sim_time
 
 def measure(task, mode, n, steps, seed=5):
     kw = dict(auto_reset=0, max_episode_steps=0, action_mode={"joint": 0, "ee": 1}[mode])
-    walk = orc.Oracle(task, n, **kw)                                                  # generates the states (default solver, random policy)
-    var = {"default": orc.Oracle(task, n, kkt=True, **kw),                                                          # block step, 4 sweeps: the product
-           "gs": orc.Oracle(task, n, kkt=True, jacobi=0, **kw),                                                    # the same step, one Gauss-Seidel pass over all rows
-           "default8": orc.Oracle(task, n, kkt=True, pgs_iters=8, **kw),
-           "default*": orc.Oracle(task, n, kkt=True, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=20000, **kw),            # ... swept to convergence
-           "rows+radial": orc.Oracle(task, n, kkt=True, cone=0, **kw),                                              # rounds 1-3, 4 sweeps
-           "rows+radial*": orc.Oracle(task, n, kkt=True, cone=0, pgs_iters=-1, pgs_tol=1e-11, pgs_cap=5000, **kw),  # ... swept to convergence: NOT the optimum
-           "qcqp": orc.Oracle(task, n, kkt=True, cone=1, **kw),                                                    # MuJoCo's PGS block update, 4 sweeps
-           "exact": orc.Oracle(task, n, kkt=True, solver=1, **kw)}
+    walk = orc.Oracle(task, n, **kw)                                                  # generates the states (the default = faithful preset, random policy)
+    var = {"default": orc.Oracle(task, n, kkt=True, **kw),                                                          # round 5: preset faithful -- Newton with a fixed budget (newton_product) = the Newton kernels
+           "default-f32": orc.Oracle(task, n, f32=True, **kw),                                                     # ... the same C source in float arithmetic: what fp32 costs
+           "fast": orc.Oracle(task, n, kkt=True, preset="fast", **kw),                                             # preset fast: four block projected-gradient sweeps, fewer rows (rounds 1-4 default)
+           "fast8": orc.Oracle(task, n, kkt=True, preset="fast", pgs_iters=8, **kw),
+           "exact": orc.Oracle(task, n, kkt=True, solver=1, **kw)}                                                 # the optimum of the faithful preset's contact model (primal Newton to 1e-13)
     walk.reset(np.arange(n, dtype=np.uint64) + 77)
     rng = np.random.default_rng(seed)
     dq = {k: [] for k in var if k != "exact"}
@@ -44,15 +40,18 @@ def measure(task, mode, n, steps, seed=5):
     for t in range(steps):
         act = rng.uniform(-1, 1, (n, walk.action_dim)).astype(np.float32)
         if t >= 3:
-            for o in var.values():
+            for name, o in var.items():
                 for k in STATE:
-                    getattr(o, k)[:] = getattr(walk, k)
+                    if k == "warm" and name.endswith("f32"):
+                        o.warm.view(np.float32)[:, :192] = walk.warm.view(np.float64)[:, :192]
+                    else:
+                        getattr(o, k)[:] = getattr(walk, k)
                 o.step(act, 0)
             ex = var["exact"]
             for k in dq:
                 dq[k].append(np.abs(var[k].qpos[:, : ex.nq] - ex.qpos[:, : ex.nq]).max(1))
             for k, o in var.items():
-                kkt[k].append(o.kkt.copy())
+                kkt[k].append(o.kkt.copy() if o.kkt is not None else np.zeros(n))
             touched.append((ex.active_mask & 0x1F000) != 0)                            # an arm-coupled contact (finger / proxy) was active in the step
         walk.step(act, 0)
     out = {k: np.concatenate(v) for k, v in dq.items()}
