@@ -317,6 +317,15 @@ def test_pinch_grasp_holds_the_cube():
     assert h.qpos[0, 8] < 0.05                                              # 98 N of weight vs 10 N m actuators
 
 
+def test_grasp_lift_and_hold():
+    """the grasp the tasks are about (lift_cube_env.py:322-346 rewards the cube's height): a pinched cube is squeezed, raised by ~10 cm with the upper arm and
+    held -- 40 control steps with the default preset's pad boxes (six-row contacts, Newton): it comes along, both finger<->cube contacts stay active, and it slips
+    by less than 3 mm against the fingers.  (tools/pads_effect.py reports the same for the spheres of preset fast.)"""
+    from tools import pads_effect
+    dz, slip, both = pads_effect.grasp(1)
+    assert dz.min() > 0.05 and both.all() and slip.max() < 3e-3, (dz.min(), slip.max(), both.sum())
+
+
 # ---------------------------------------------------------------- PushCubeLoop-v0 glue (push_cube_loop_env.py:299-383)
 @pytest.mark.parametrize("rec", GOLD["loop_rewards"], ids=lambda r: f"goal{r['goal']}")
 def test_loop_reward_golden(rec):
