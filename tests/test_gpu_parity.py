@@ -1114,6 +1114,12 @@ def test_zz_outlier_census(hip_lib):
     assert S["envs_carry"] > 0.3 * S["envs"]     # the product's default mode (forces carried across steps) is really covered
 
 
+# bounds of the default (faithful) preset, from its full census (profiles/r05_rail_census.txt: 65 536 envs x 400 steps per task -- no cube above 4.2 m/s in 2.6e7 sampled
+# states; lowest cube centre 0.0 mm Reach / PickPlace, -2.1 Stack, -3.8 Push, -4.7 PushCubeLoop, -6.9 Lift: a finger pressing the cube into MuJoCo's soft floor contact
+# -- the product is within 1e-8 rad of the exact optimum of that model per control step, profiles/r05_kkt_distance.txt, so this is the model, not the solver)
+FAITHFUL_TAILS = {"reach": (5.0, -0.002), "push": (5.0, -0.006), "lift": (5.0, -0.010), "pick_place": (5.0, -0.002), "stack": (5.0, -0.004), "push_loop": (5.0, -0.007)}
+
+
 @pytest.mark.parametrize("task,mode,vmax,zmin", [("reach", "joint", 6.0, -0.005), ("push", "joint", 8.0, -0.005), ("lift", "joint", 8.0, -0.02),
                                                  ("pick_place", "ee", 4.0, -0.005), ("stack", "joint", 14.0, -0.02), ("push_loop", "joint", 8.0, -0.012)])
 def test_cubes_are_not_thrown(hip_lib, kernel_family, task, mode, vmax, zmin):
@@ -1123,6 +1129,8 @@ def test_cubes_are_not_thrown(hip_lib, kernel_family, task, mode, vmax, zmin):
     PushCubeLoop failed this by a wide margin (17.9 m/s, centres 121 mm under the floor) while every parity test was green -- hence the test."""
     from gym_lowcostrobot_amd import VecSim
     n = 16384
+    if kernel_family == "faithful":   # (VERDICT r4 #1: bounds tightened to the census of the converged default -- no cube above 5 m/s on any task)
+        vmax, zmin = FAITHFUL_TAILS[task]
     sim = VecSim(task, n, action_mode=mode, base_seed=3)
     act = sim.alloc_actions()
     worst_v, worst_z = 0.0, 1.0

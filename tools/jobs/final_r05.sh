@@ -1,0 +1,8 @@
+#!/bin/bash
+# GPU job: the round-5 evidence set (profiles/r05_*): bench line + rocprofv3 stats + PMC of the default, step times of every workload under both presets, per-wave cycles, tail census
+mkdir -p gpurun_out
+bash tools/profile_gpu.sh r05 > /dev/null 2>&1
+python tools/summarize_profile.py r05 r05 > gpurun_out/r05_summary.log 2>&1
+(python tools/quick_times.py --steps 200; python tools/quick_times.py --steps 200 --preset fast) 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_quick_times.txt
+python tools/rail_census.py 400 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_rail_census.txt
+python tools/newton_dev_check.py reach,push,lift,pick_place,stack,push_loop 4096 6 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_newton_parity.txt
