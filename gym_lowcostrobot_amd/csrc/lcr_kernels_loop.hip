@@ -451,7 +451,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     FloorSlot &T = WS[2 * pr + c];
-                    const float dist = c == 0 ? d1 : d2;
+                    const float dist = fmaxf(c == 0 ? d1 : d2, -RAIL_CLAMP);   // (round 5: a rail reports at most RAIL_CLAMP of penetration, lcr_step_common.h)
                     const f3 rw = c == 0 ? r1 : r2;
                     T.act = c == 0 ? h1 : h2;
                     if (P.diag) diag_choice(DG, T.act, 8 + 2 * pr + c, (c == 0 ? i1 : i2) + 8 * (2 * pr + (sg > 0.f ? 0 : 1)));
@@ -493,7 +493,8 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     bool link_on_cube = false;       // slot 4: this lane's contact is against a cube (else the floor)
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
     int link_bi = 0;             // slot 4: which proxy
-    float link_htop = 0.f;       // slot 4 on the floor: height of the surface under the proxy (PushCubeLoop: a rail's top face, D7)
+    f3 link_n = mk(0.f, 0.f, 1.f);   // slot 4 on the world: normal and code of the surface the proxy meets (floor, or a rail's top / side face: D7, world_surface)
+    int link_code = 0;
     int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
@@ -542,12 +543,12 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             if constexpr (NEWTON) {
                 const int L = sp == 0 ? 4 : 5;
                 const PadFloorHit hit = pad_floor<WALLS>(PadBox{padc[sp], padh[sp].x * F.X[L], padh[sp].y * F.Y[L], padh[sp].z * F.Z[L]});
-                dist = hit.dist; pos = hit.pos; sel = hit.code;
-            } else {
-                const float htop = WALLS ? rail_top(sph[sp].x, sph[sp].y) : 0.f;   // (PushCubeLoop: above a rail the finger meets the rail's top face)
-                dist = sph[sp].z - srad[sp] - htop;
-                pos = mk(sph[sp].x, sph[sp].y, htop + 0.5f * dist);
-                sel = htop > 0.f ? 1 : 0;   // (which surface: part of the decision signature)
+                dist = hit.dist; pos = hit.pos; sel = hit.code; n = hit.n;
+            } else {   // the floor, or a rail's top or SIDE face (world_surface)
+                const WorldHit w = world_surface<WALLS>(sph[sp], srad[sp]);
+                dist = -w.depth; n = w.n;
+                pos = axpy(-(srad[sp] + 0.5f * dist), w.n, sph[sp]);
+                sel = w.code;   // (which surface: part of the decision signature)
             }
         } else if (P.arm_collision) {
             // arm-link proxies (D3): both ends of link_3, link_4 motor, link_5 motor body, link_6 jaw root.  One contact: the
@@ -570,13 +571,14 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             for (int i = 0; i < 5; i++) {
                 const int L = plink[i];
                 const float cz = fmaf(px[i], F.X[L].z, fmaf(py[i], F.Y[L].z, fmaf(pz[i], F.Z[L].z, F.p[L].z)));
-                float df = cz - pr[i], hi = 0.f;
-                if constexpr (WALLS) {   // (D7) above a rail's footprint the surface is the rail's top face
-                    const f3 cw_ = local_point(F, L, px[i], py[i], pz[i]);
-                    hi = rail_top(cw_.x, cw_.y);
-                    df -= hi;
+                float df = cz - pr[i];
+                f3 wn = mk(0.f, 0.f, 1.f);
+                int wcode = 0;
+                if constexpr (WALLS) {   // (D7) the floor, or a rail's top or side face
+                    const WorldHit w = world_surface<WALLS>(local_point(F, L, px[i], py[i], pz[i]), pr[i]);
+                    df = -w.depth; wn = w.n; wcode = w.code;
                 }
-                if (df < bestd) { bestd = df; bi = i; oncube = false; link_htop = hi; }
+                if (df < bestd) { bestd = df; bi = i; oncube = false; link_n = wn; link_code = wcode; }
                 if (i >= 3 && wave_near) {
                     const f3 ci = local_point(F, L, px[i], py[i], pz[i]);
 #pragma unroll
@@ -587,7 +589,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 }
             }
             link_bi = bi;
-            if (!oncube) { n = mk(0.f, 0.f, 1.f); sel = link_htop > 0.f ? 1 : 0; }
+            if (!oncube) { n = link_n; sel = link_code; }
             sel += 64 * (bi + 1);
             dist = bestd;
             link_on_cube = oncube;
@@ -610,17 +612,18 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 // five computed points would be turned into a scratch array by the compiler)
                 const float qx[5] = {LPX0x, LPX1x, LPX2x, LPX3x, LPX4x}, qy[5] = {LPX0y, LPX1y, LPX2y, LPX3y, LPX4y}, qz[5] = {LPX0z, LPX1z, LPX2z, LPX3z, LPX4z};
                 const int ql[5] = {2, 2, 3, 4, 5};
-                f2v cb = {0.f, 0.f};
+                const float qr[5] = {LPX0r, LPX1r, LPX2r, LPX3r, LPX4r};
+                f3 cb = mk(0.f, 0.f, 0.f);
+                float rb = 0.f;
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
                     const float m = link_bi == i ? 1.f : 0.f;
-                    const int L = ql[i];
-                    const f2v ci = F.p[L].xy + f2v{qx[i], qx[i]} * F.X[L].xy + f2v{qy[i], qy[i]} * F.Y[L].xy + f2v{qz[i], qz[i]} * F.Z[L].xy;
-                    cb = f2v{m, m} * ci + cb;
+                    cb = axpy(m, local_point(F, ql[i], qx[i], qy[i], qz[i]), cb);
+                    rb = fmaf(m, qr[i], rb);
                 }
-                if (!oncube) pos = mk(cb.x, cb.y, link_htop + 0.5f * dist);
+                if (!oncube) pos = axpy(-(rb + 0.5f * dist), n, cb);   // midway between the proxy's surface and the world surface it is inside
             }
-            if (may_cube) make_frame(n, T.t1, T.t2);   // (for n = +z this is the floor frame t1 = +y, t2 = -x)
+            if (may_cube || WALLS) make_frame(n, T.t1, T.t2);   // (for n = +z this is the floor frame t1 = +y, t2 = -x; PushCubeLoop: a rail's side face has a horizontal normal)
             // joints that move the contact point: the finger spheres sit on link_5 / link_6, the proxies on link_3..link_6
             auto joint_on = [&](int j) -> bool {
                 if (s < 4) return j < (sp == 0 ? 5 : 6);

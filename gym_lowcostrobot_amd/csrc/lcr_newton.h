@@ -272,7 +272,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         float g6[6];
         if (s < 4 && r >= 3) {   // torsion / rolling rows of a finger contact: d . B of the finger body (rows NEWTON_BODY_ROW0 + 3 sp + axis)
             constexpr int b0 = NEWTON_BODY_ROW0 + 3 * (s & 1);
-            if (s >= 2) {        // on the floor the frame is (z, y, -x): the body rows themselves
+            if (s >= 2 && !WALLS) {   // on the floor the frame is (z, y, -x): the body rows themselves (PushCubeLoop: a rail's side face has another frame)
                 ld(b0 + (r == 3 ? 2 : (r == 4 ? 1 : 0)), g6);
                 if (r == 5) {
 #pragma unroll

@@ -95,14 +95,38 @@ DEV void soc_step(const float (&f)[NR], const float (&u)[NR], const float (&k)[N
 // outer rectangle of the rails (inner faces + the boxes' thickness).  A cube that was knocked over a rail lies outside the pen untouched, as next to the
 // reference's wall boxes, instead of being "deep inside" a half-space (which ejected it at up to 1 200 m/s: 0.5 % of the env-states of a random-policy run
 // had the cube out there).  The penetration a rail can see is thereby bounded by thickness + half a cube diagonal.
-// (D7) finger spheres ride over the rails: above a rail box's footprint the "floor" a finger sphere meets is the box's top face (push_cube_loop.xml:45-48:
-// left / right walls |x| in [0.115, 0.135], y in [0.08, 0.19]; top / bottom walls |x| < 0.125, y in [0.08, 0.10] / [0.17, 0.19]; top at z = 0.012).
-// The boxes' side faces are not modelled for the fingers: a finger that comes in low is lifted onto the rail instead of being stopped by it.
-DEV float rail_top(float x, float y) {
-    const bool in_y = y > WALL_Y0 - WALL_THICK && y < WALL_Y1 + WALL_THICK;
-    const bool side = fabsf(x) > WALL_X && fabsf(x) < WALL_X + WALL_THICK && in_y;
-    const bool ends = fabsf(x) < WALL_X + 0.5f * WALL_THICK && in_y && (y < WALL_Y0 || y > WALL_Y1);
-    return (side || ends) ? WALL_TOP : 0.f;
+// (D7, round 5: the rails as BOXES for the arm.)  The surface of the world a point p with a margin r (a sphere's radius; 0 for a pad vertex) is deepest inside: the floor
+// (depth r - p.z, normal +z, code 0) or one of the four rail boxes (push_cube_loop.xml:45-48: left / right |x| in [0.115, 0.135], y in [0.08, 0.19]; bottom / top
+// |x| < 0.125, y in [0.08, 0.10] / [0.17, 0.19]; top at z = 0.012), inflated by r -- inside one, the face it is shallowest below: the top (code 1 + 5 b) or a side
+// (+x, -x, +y, -y: 2 .. 5 + 5 b).  A finger that comes in sideways at floor height is stopped by the side face (rounds 2-4 knew the top faces only and lifted it).
+// oracle: world_surface
+constexpr float RAIL_CLAMP = 0.012f;   // largest penetration a rail's inner face reports for the CUBE (a cube re-entering the outer rectangle is not shot in)
+struct WorldHit { float depth; f3 n; int code; };
+template <bool WALLS>
+DEV WorldHit world_surface(f3 p, float r) {
+    WorldHit h;
+    h.depth = r - p.z; h.n = mk(0.f, 0.f, 1.f); h.code = 0;
+    if constexpr (WALLS) {
+        const float rcx[4] = {-(WALL_X + 0.5f * WALL_THICK), WALL_X + 0.5f * WALL_THICK, 0.f, 0.f};
+        const float rcy[4] = {0.5f * (WALL_Y0 + WALL_Y1), 0.5f * (WALL_Y0 + WALL_Y1), WALL_Y0 - 0.5f * WALL_THICK, WALL_Y1 + 0.5f * WALL_THICK};
+        const float rhx[4] = {0.5f * WALL_THICK, 0.5f * WALL_THICK, WALL_X + 0.5f * WALL_THICK, WALL_X + 0.5f * WALL_THICK};
+        const float rhy[4] = {0.5f * (WALL_Y1 - WALL_Y0) + WALL_THICK, 0.5f * (WALL_Y1 - WALL_Y0) + WALL_THICK, 0.5f * WALL_THICK, 0.5f * WALL_THICK};
+        const float ez = WALL_TOP + r - p.z;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const float dx = p.x - rcx[b], dy = p.y - rcy[b];
+            const float ex = rhx[b] + r - fabsf(dx), ey = rhy[b] + r - fabsf(dy);
+            const bool in = ex > 0.f && ey > 0.f && ez > 0.f;
+            float d = ez; int f = 0;
+            if (ex < d) { d = ex; f = dx < 0.f ? 2 : 1; }
+            if (ey < d) { d = ey; f = dy < 0.f ? 4 : 3; }
+            const bool take = in && d > h.depth;
+            h.depth = take ? d : h.depth;
+            h.code = take ? 1 + 5 * b + f : h.code;
+            h.n = take ? mk(f == 1 ? 1.f : (f == 2 ? -1.f : 0.f), f == 3 ? 1.f : (f == 4 ? -1.f : 0.f), f == 0 ? 1.f : 0.f) : h.n;
+        }
+    }
+    return h;
 }
 DEV bool cube_in_pen(f3 c) {
     return fabsf(c.x) < WALL_X + WALL_THICK && c.y > WALL_Y0 - WALL_THICK && c.y < WALL_Y1 + WALL_THICK;
@@ -371,34 +395,37 @@ DEV SBHit sphere_box(f3 centre, float rad, f3 cp, const CubeRot &R) {
 constexpr float PAD_BLEND = 0.0005f;
 struct PadBox { f3 c, ax, ay, az; };   // centre and the link's axes scaled by the half extents
 DEV f3 pad_vertex(const PadBox &B, int i) { return B.c + ((i & 1) ? B.ax : neg(B.ax)) + ((i & 2) ? B.ay : neg(B.ay)) + ((i & 4) ? B.az : neg(B.az)); }
-struct PadFloorHit { float dist, htop; f3 pos; int code; };
+struct PadFloorHit { float dist; f3 pos, n; int code; };
 template <bool WALLS>
 DEV PadFloorHit pad_floor(const PadBox &B) {
-    float depth[8], htop[8];
-    f3 v[8];
+    float depth[8];
+    int code[8];
+    f3 v[8], nn[8];
     int best = 0;
     float bd = -1e30f;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         v[i] = pad_vertex(B, i);
-        htop[i] = WALLS ? rail_top(v[i].x, v[i].y) : 0.f;
-        depth[i] = htop[i] - v[i].z;
+        const WorldHit w = world_surface<WALLS>(v[i], 0.f);
+        depth[i] = w.depth; code[i] = w.code; nn[i] = w.n;
         if (depth[i] > bd) { bd = depth[i]; best = i; }
     }
-    float hb = 0.f;
+    int cb = 0;
+    f3 nb = mk(0.f, 0.f, 1.f), vb = v[0];
 #pragma unroll
-    for (int i = 0; i < 8; i++) hb = best == i ? htop[i] : hb;
-    float wsum = 0.f, px = 0.f, py = 0.f;
+    for (int i = 0; i < 8; i++) { cb = best == i ? code[i] : cb; nb = best == i ? nn[i] : nb; vb = best == i ? v[i] : vb; }
+    float wsum = 0.f;
+    f3 q = mk(0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const float w = (htop[i] == hb) ? fmaxf(depth[i] - bd + PAD_BLEND, 0.f) : 0.f;
-        wsum += w; px = fmaf(w, v[i].x, px); py = fmaf(w, v[i].y, py);
+    for (int i = 0; i < 8; i++) {   // the vertices on the SAME surface within PAD_BLEND of the deepest one share the contact point
+        const float w = (code[i] == cb) ? fmaxf(depth[i] - bd + PAD_BLEND, 0.f) : 0.f;
+        wsum += w; q = axpy(w, v[i], q);
     }
-    const float iw = rcp(fmaxf(wsum, 1e-30f));
+    q = rcp(fmaxf(wsum, 1e-30f)) * q;
     PadFloorHit h;
-    h.dist = -bd; h.htop = hb;
-    h.pos = mk(px * iw, py * iw, fmaf(-0.5f, bd, hb));
-    h.code = 2 * best + (hb > 0.f ? 1 : 0);
+    h.dist = -bd; h.n = nb;
+    h.pos = axpy(dot(vb, nb) - dot(q, nb) + 0.5f * bd, nb, q);   // the blended point at the deepest vertex' level along the normal, then midway to the surface
+    h.code = best + 8 * cb;
     return h;
 }
 // point q inside the box (centre c, unit axes X, Y, Z, half extents h)?  depth to the nearest face, that face (2 k + (negative side)), local coordinates

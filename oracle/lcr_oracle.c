@@ -136,6 +136,7 @@ static const double MU_LOOP[5] = {1.5, 1.5, 1.5, 1.5, 1.5};   /* push_cube_loop.
 #define WALL_Y0 0.10
 #define WALL_Y1 0.17
 #define WALL_TOP 0.012
+#define RAIL_CLAMP 0.012   /* largest penetration a rail's inner face reports for the cube */
 #define WALL_THICK 0.02   /* the rail boxes are 2 x 0.01 thick: outer faces WALL_THICK beyond the inner ones (push_cube_loop.xml:45-48 size) */
 
 typedef struct {
@@ -515,22 +516,43 @@ static int collide_box_sphere(const kin_t *K, int c, int s, contact_t *ct) { /* 
     ct->mu = K->mu_finger_cube; ct->solimp = SOLIMP_FINGER_CUBE;
     return 1;
 }
-/* (D7) height of the surface a finger sphere meets at (x, y): the top face of a rail box above its footprint (push_cube_loop.xml:45-48), else the floor */
-static real rail_top(real x, real y) {
-    real ax = x < 0 ? -x : x;
-    int in_y = y > (real)WALL_Y0 - (real)WALL_THICK && y < (real)WALL_Y1 + (real)WALL_THICK;
-    int side = ax > (real)WALL_X && ax < (real)WALL_X + (real)WALL_THICK && in_y;
-    int ends = ax < (real)WALL_X + (real)0.5 * (real)WALL_THICK && in_y && (y < (real)WALL_Y0 || y > (real)WALL_Y1);
-    return (side || ends) ? (real)WALL_TOP : (real)0;
+/* (round 5: the rails as BOXES for the arm -- VERDICT r3 / r4)  The surface of the world a point p with a margin r (a sphere's radius; 0 for a pad vertex)
+ * is deepest inside: the floor (depth r - p_z, normal +z) or one of the four rail boxes of push_cube_loop.xml:44-47, inflated by r -- inside one, the face it is
+ * shallowest below: the top (code 1 + 5 b) or a side (+x, -x, +y, -y: codes 2 .. 5 + 5 b), so a finger that comes in sideways at floor height is STOPPED by the rail's
+ * side face instead of being lifted onto its top (rounds 2-4 knew the top faces only).  Returns the depth (> 0: penetrating), the outward normal and the code. */
+static const double RAIL_C[4][2] = {{-(WALL_X + 0.5 * WALL_THICK), 0.5 * (WALL_Y0 + WALL_Y1)}, {WALL_X + 0.5 * WALL_THICK, 0.5 * (WALL_Y0 + WALL_Y1)},
+                                    {0.0, WALL_Y0 - 0.5 * WALL_THICK}, {0.0, WALL_Y1 + 0.5 * WALL_THICK}};
+static const double RAIL_H[4][2] = {{0.5 * WALL_THICK, 0.5 * (WALL_Y1 - WALL_Y0) + WALL_THICK}, {0.5 * WALL_THICK, 0.5 * (WALL_Y1 - WALL_Y0) + WALL_THICK},
+                                    {WALL_X + 0.5 * WALL_THICK, 0.5 * WALL_THICK}, {WALL_X + 0.5 * WALL_THICK, 0.5 * WALL_THICK}};
+static real world_surface(const real *p, real r, int walls, real *n, int *code) {
+    real best = r - p[2];
+    v3set(n, 0, 0, 1);
+    *code = 0;
+    if (!walls) return best;
+    for (int b = 0; b < 4; b++) {
+        const real dx = p[0] - (real)RAIL_C[b][0], dy = p[1] - (real)RAIL_C[b][1];
+        const real ex = (real)RAIL_H[b][0] + r - (dx < 0 ? -dx : dx), ey = (real)RAIL_H[b][1] + r - (dy < 0 ? -dy : dy), ez = (real)WALL_TOP + r - p[2];
+        if (!(ex > 0 && ey > 0 && ez > 0)) continue;
+        real d = ez; int f = 0;
+        if (ex < d) { d = ex; f = dx < 0 ? 2 : 1; }
+        if (ey < d) { d = ey; f = dy < 0 ? 4 : 3; }
+        if (d > best) {
+            best = d; *code = 1 + 5 * b + f;
+            v3set(n, f == 1 ? (real)1 : (f == 2 ? (real)-1 : 0), f == 3 ? (real)1 : (f == 4 ? (real)-1 : 0), f == 0 ? (real)1 : 0);
+        }
+    }
+    return best;
 }
-static int collide_plane_sphere_g(const real *centre, double radius, int link, real htop, contact_t *ct) {
-    real dist = centre[2] - (real)radius - htop;
-    if (!(dist < 0)) return 0;
-    v3set(ct->pos, centre[0], centre[1], htop + dist * (real)0.5);
-    real nz[3] = {0, 0, 1};
-    make_frame(ct->frame, nz);
+static int collide_plane_sphere_g(const real *centre, double radius, int link, int walls, contact_t *ct) {
+    real n[3];
+    int code;
+    const real depth = world_surface(centre, (real)radius, walls, n, &code);
+    if (!(depth > 0)) return 0;
+    const real dist = -depth, back = (real)radius + dist * (real)0.5;
+    v3set(ct->pos, centre[0] - n[0] * back, centre[1] - n[1] * back, centre[2] - n[2] * back);
+    make_frame(ct->frame, n);
     ct->b1 = -1; ct->b2 = link; ct->dist = dist;
-    ct->sel = htop > 0 ? 1 : 0;   /* which surface: part of the decision signature */
+    ct->sel = code;   /* which surface: part of the decision signature */
     return 1;
 }
 /* ---- finger pads as boxes (orc_params.finger_geom = 1).  MuJoCo's convex collider returns ONE contact for a mesh hull against a box, and the deepest points of a
@@ -549,27 +571,31 @@ static void pad_vertices(const kin_t *K, int s, real v[8][3], real centre[3]) {
     }
 }
 static int collide_plane_pad(const kin_t *K, int s, int walls, contact_t *ct) {
-    real v[8][3], pc[3], depth[8], htop[8];
+    real v[8][3], pc[3], depth[8], nn[8][3];
+    int code[8];
     pad_vertices(K, s, v, pc);
     int best = 0;
     for (int i = 0; i < 8; i++) {
-        htop[i] = walls ? rail_top(v[i][0], v[i][1]) : (real)0;
-        depth[i] = htop[i] - v[i][2];
+        depth[i] = world_surface(v[i], 0, walls, nn[i], &code[i]);
         if (depth[i] > depth[best]) best = i;
     }
     if (!(depth[best] > 0)) return 0;
-    real wsum = 0, px = 0, py = 0;
-    for (int i = 0; i < 8; i++) {
+    real wsum = 0, q[3] = {0, 0, 0};
+    for (int i = 0; i < 8; i++) {   /* the vertices on the SAME surface within PAD_BLEND of the deepest one share the contact point */
         real w = depth[i] - depth[best] + (real)PAD_BLEND;
-        if (!(w > 0) || htop[i] != htop[best]) continue;
-        wsum += w; px += w * v[i][0]; py += w * v[i][1];
+        if (!(w > 0) || code[i] != code[best]) continue;
+        wsum += w;
+        for (int a = 0; a < 3; a++) q[a] += w * v[i][a];
     }
     const real dist = -depth[best];
-    v3set(ct->pos, px / wsum, py / wsum, htop[best] + dist * (real)0.5);
-    real nz[3] = {0, 0, 1};
-    make_frame(ct->frame, nz);
+    const real *n = nn[best];
+    /* the blended point, set to the deepest vertex' level along the normal, then midway to the surface */
+    real lev = 0, levb = 0;
+    for (int a = 0; a < 3; a++) { q[a] /= wsum; lev += q[a] * n[a]; levb += v[best][a] * n[a]; }
+    for (int a = 0; a < 3; a++) ct->pos[a] = q[a] + n[a] * (levb - lev - dist * (real)0.5);
+    make_frame(ct->frame, n);
     ct->b1 = -1; ct->b2 = SPH_LINK[s]; ct->dist = dist;
-    ct->sel = 2 * best + (htop[best] > 0 ? 1 : 0);
+    ct->sel = best + 8 * code[best];
     ct->slot = 14 + s;
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER;
     ct->dim = 4;
@@ -635,7 +661,7 @@ static int collide_box_pad(const kin_t *K, int c, int s, contact_t *ct) {
     return 1;
 }
 static int collide_plane_sphere(const kin_t *K, int s, int walls, contact_t *ct) {
-    if (!collide_plane_sphere_g(K->sph[s], SPH_RAD[s], SPH_LINK[s], walls ? rail_top(K->sph[s][0], K->sph[s][1]) : (real)0, ct)) return 0;
+    if (!collide_plane_sphere_g(K->sph[s], SPH_RAD[s], SPH_LINK[s], walls, ct)) return 0;
     ct->slot = 14 + s;
     ct->mu = MU_FINGER; ct->solimp = SOLIMP_FINGER; /* P9: finger priority 1 beats floor */
     ct->dim = 4;
@@ -647,7 +673,7 @@ static int collide_link_group(const kin_t *K, int g, int ngroups, int walls, con
     for (int s = 0; s < NLPX; s++) {
         if ((ngroups == 3 ? LPX_GROUP3[s] : LPX_GROUP[s]) != g) continue;
         contact_t tmp;
-        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], walls ? rail_top(K->lpx[s][0], K->lpx[s][1]) : (real)0, &tmp)) {   /* (D7: rail tops) */
+        if (collide_plane_sphere_g(K->lpx[s], LPX_RAD[s], LPX_LINK[s], walls, &tmp)) {   /* (D7: floor or a rail's top / side face) */
             tmp.mu = MU_LINK_FLOOR; tmp.solimp = SOLIMP_DEFAULT; tmp.dim = 3;
             tmp.sel += 64 * (s + 1);
             if (!have || tmp.dist < out->dist) { *out = tmp; have = 1; }
@@ -711,6 +737,9 @@ static int collide_walls(const kin_t *K, contact_t *out) {
             contact_t *ct = &out[n];
             ct->slot = 8 + 2 * pr + c;
             n++;
+            /* (round 5) a rail sees at most RAIL_CLAMP of penetration: a cube whose centre has just come back inside the outer rectangle is 2 cm "deep" in the
+             * half-space at once -- it is pushed in as by a rail it has just touched, not shot in */
+            if (dist < (real)-RAIL_CLAMP) dist = (real)-RAIL_CLAMP;
             ct->b1 = -1; ct->b2 = 6; ct->dist = dist;
             v3set(ct->pos, P[i][0] - nw[0] * dist * (real)0.5, P[i][1] - nw[1] * dist * (real)0.5, P[i][2]);
             make_frame(ct->frame, nw);
@@ -2288,6 +2317,13 @@ int orc_model_table(double *out) {
 }
 
 /* ---- model queries ---- */
+/* test access to world_surface (the floor and PushCubeLoop's rail boxes as the arm sees them): depth, normal[3], code */
+double orc_world_surface(const double *p3, double r, int walls, double *n3, int *code) {
+    real p[3] = {(real)p3[0], (real)p3[1], (real)p3[2]}, n[3];
+    const real d = world_surface(p, (real)r, walls, n, code);
+    for (int k = 0; k < 3; k++) n3[k] = (double)n[k];
+    return (double)d;
+}
 /* the finger pad boxes (finger_geom = 1): NSPH x (centre3, half3), link frames of SPH_LINK */
 void orc_pad_table(double *out) {
     for (int s = 0; s < NSPH; s++) for (int k = 0; k < 3; k++) { out[6 * s + k] = PAD_C[s][k]; out[6 * s + 3 + k] = PAD_H[s][k]; }
