@@ -398,6 +398,32 @@ DEV f3 pad_vertex(const PadBox &B, int i) { return B.c + ((i & 1) ? B.ax : neg(B
 struct PadFloorHit { float dist; f3 pos, n; int code; };
 template <bool WALLS>
 DEV PadFloorHit pad_floor(const PadBox &B) {
+    if constexpr (!WALLS) {   // the floor only: heights of the eight vertices, nothing else (same result as the general path below; it costs the five tasks without rails
+                              // 10 % of their step when they run it -- registers, not arithmetic)
+        float z[8];
+        f2v xy[8];
+        int best = 0;
+        float zb = 1e30f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f3 v = pad_vertex(B, i);
+            z[i] = v.z; xy[i] = v.xy;
+            if (z[i] < zb) { zb = z[i]; best = i; }
+        }
+        float wsum = 0.f;
+        f2v q = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float w = fmaxf(zb - z[i] + PAD_BLEND, 0.f);
+            wsum += w; q = f2v{w, w} * xy[i] + q;
+        }
+        const float iw = rcp(fmaxf(wsum, 1e-30f));
+        PadFloorHit h;
+        h.dist = zb; h.n = mk(0.f, 0.f, 1.f);
+        h.pos = mk(q.x * iw, q.y * iw, 0.5f * zb);
+        h.code = best;
+        return h;
+    }
     float depth[8];
     int code[8];
     f3 v[8], nn[8];
