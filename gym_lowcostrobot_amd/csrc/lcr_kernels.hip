@@ -735,8 +735,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         const float no_wsg[2] = {1.f, 1.f};
         NewtonCtx<NC, NRW, false, NCC> C{NP, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, no_walls, no_wsg, false,
                                          ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
+        const long long tn0 = P.diag == 2 ? clock64() : 0;   // (profiling aid: cycles of the solves, of the coupled ones, iterations -- tools/newton_phases.py)
+        bool prof_coupled = false;
         if constexpr (NC == 1) {
             const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
+            prof_coupled = arm_on_cube;
             if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal);
             else {
                 const int ia = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal);
@@ -761,6 +764,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 i3 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal);
             }
             sweeps_done = max(i1, max(i2, i3));
+            prof_coupled = eA0 || eA1 || e01;
+        }
+        if (P.diag == 2) {
+            const unsigned dt = (unsigned)(clock64() - tn0);
+            DGtot.mask += dt; DGtot.count += prof_coupled ? dt : 0u; DGtot.choice += (prof_coupled ? 65536u : 0u) + (unsigned)C.wave_its;
         }
     }
     for (int it = 0; it < max_it; it++) {
@@ -1023,7 +1031,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         for (int k = 0; k < NRW; k++) W.arm[s][k] = AS[s].f[k];
 #pragma unroll
     for (int s = 0; s < NCC; s++) W.cc_prev[s] = cc_act[s];
-    if (P.diag) {   // wave-uniform
+    if (P.diag == 1 || (P.diag == 2 && !NEWTON)) {   // wave-uniform (diagnostics = 2 on the Newton kernels: the same fields carry cycle counts instead, see the solve above)
         unsigned m = 0u;
 #pragma unroll
         for (int c = 0; c < NC; c++)

@@ -175,6 +175,7 @@ struct NewtonCtx {
     const Chol6 &CL;
     float (&flim)[6];
     const float (&y0s)[6];
+    int wave_its = 0;            // iterations this wave has executed in its solves of the substep (profiling aid, lcr_config.diagnostics = 2)
 };
 
 template <int MASK> constexpr int nw_off(int body) {   // first compact index of a body of MASK
@@ -710,6 +711,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         dprev = -d0;
         if (!__any(live)) break;
         lane_its += live ? 1 : 0;
+        C.wave_its++;
         dots(std::false_type{}, dx, jd);
         // line search on phi'(al) = q0 + al q1 - sum f(zs + al jd) . jd (monotone increasing), with phi''(al) = q1 + sum jd'W jd from the same pass: first the full step
         // (exact while no contact changes zone); no bracket yet: the Newton step on phi' from the last point; bracket [lo, hi]: the Newton candidate from the end with the
