@@ -2328,6 +2328,18 @@ double orc_world_surface(const double *p3, double r, int walls, double *n3, int 
 void orc_pad_table(double *out) {
     for (int s = 0; s < NSPH; s++) for (int k = 0; k < 3; k++) { out[6 * s + k] = PAD_C[s][k]; out[6 * s + 3 + k] = PAD_H[s][k]; }
 }
+/* world frames of the six links: rotation matrices (row-major 3 x 3, columns = the link's axes) and origins */
+void orc_link_frames(const double *q6, double *R54, double *p18) {
+    real q[6];
+    kin_t K;
+    for (int i = 0; i < 6; i++) q[i] = (real)q6[i];
+    K.ncube = 0;
+    arm_kinematics(q, &K);
+    for (int i = 0; i < 6; i++) {
+        for (int k = 0; k < 9; k++) R54[9 * i + k] = (double)K.R[i + 1][k];
+        for (int k = 0; k < 3; k++) p18[3 * i + k] = (double)K.p[i + 1][k];
+    }
+}
 void orc_fk(const double *q6, double *link_pos, double *site, double *spheres) {
     real q[6]; kin_t K;
     for (int j = 0; j < 6; j++) q[j] = (real)q6[j];

@@ -192,6 +192,14 @@ def fk(q):
     return lp, site, sph
 
 
+def link_frames(q):
+    """world rotation matrices [6][3][3] (columns = the link's axes) and origins [6][3] of link_1 .. link_6"""
+    q = np.ascontiguousarray(q, np.float64)
+    R, p = np.zeros((6, 3, 3)), np.zeros((6, 3))
+    lib().orc_link_frames(_p(q), _p(R), _p(p))
+    return R, p
+
+
 def proxies(q):
     """world centres and radii of the arm-link proxy spheres (D3)"""
     q = np.ascontiguousarray(q, np.float64)

@@ -10,8 +10,8 @@ tests/golden/model_golden.json), MuJoCo's default fovy of 45 degrees, cube size 
 alpha, the 0.1 m checker (texrepeat 5 over 1 m... groundplane material), headlight ambient 0.3 / diffuse 0.6.
 
 Scene model: checker floor z = 0, gradient sky, cubes as oriented boxes, target marker as a translucent box (alpha 0.3), the
-arm as 7 capsules between the link origins / finger spheres (radii as in lcr_render.hip), Lambert shading with the light
-at the camera (MuJoCo headlight), no shadows.
+arm -- since round 5 -- as the bounding boxes of its seven collision hulls (base_link, link_1 .. link_6: mesh_aabb of the golden model file, body frames;
+rounds 1-4: seven capsules between the link origins, kept as scene_capsule_arm), Lambert shading with the light at the camera (MuJoCo headlight), no shadows.
 """
 import json
 import os
@@ -54,10 +54,16 @@ def scene(task, qpos, target=None):
     qpos = np.asarray(qpos, float)
     lp, _, sph = orc.fk(qpos[:6])
     pts = [np.zeros(3)] + [lp[i] for i in range(6)]
-    caps = [(pts[i], pts[i + 1], CAP_RADII[i]) for i in range(5)]
-    caps.append((lp[4], sph[0], CAP_RADII[5]))     # fixed finger: link_5 origin -> finger-tip sphere
-    caps.append((lp[5], sph[1], CAP_RADII[6]))     # jaw: link_6 origin -> jaw-tip sphere
-    boxes = []
+    # the arm: the bounding boxes of its seven collision hulls (model_golden.json "mesh_aabb", body frames; follower.xml:54-97) -- round 5; rounds 1-4 drew capsules
+    R, p = orc.link_frames(qpos[:6])
+    RB = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])     # base_link: quat (-0.707, 0, 0, 0.707) = Rz(-90 deg) at the origin (follower.xml:51)
+    frames = [(RB, np.zeros(3))] + [(R[i], p[i]) for i in range(6)]
+    caps, boxes = [], []
+    for i, name in enumerate(("base_link_collision", "link_1_collision", "link_2_collision", "link_3_collision", "link_4_collision", "link_5_collision",
+                              "link_6_collision")):
+        lo, hi = np.array(_G["mesh_aabb"][name]["min"]), np.array(_G["mesh_aabb"][name]["max"])
+        Rf, pf = frames[i]
+        boxes.append((pf + Rf @ (0.5 * (lo + hi)), Rf, 0.5 * (hi - lo), np.full(3, 0.75 if i >= 5 else 0.8), 1.0))
     ncube = 2 if task == "stack" else 1
     for c in range(ncube):
         p = qpos[6 + 7 * c: 9 + 7 * c]
@@ -69,9 +75,19 @@ def scene(task, qpos, target=None):
     return caps, boxes
 
 
-def render(task, qpos, target=None, cam="camera_front", W=320, H=240):
+def scene_capsule_arm(task, qpos, target=None):
+    """the rounds 1-4 scene: the whole arm as 7 capsules between the link origins / finger spheres (kept for tools/arm_boxes_effect.py: how many pixels the boxes move)"""
+    qpos = np.asarray(qpos, float)
+    lp, _, sph = orc.fk(qpos[:6])
+    pts = [np.zeros(3)] + [lp[i] for i in range(6)]
+    caps = [(pts[i], pts[i + 1], CAP_RADII[i]) for i in range(5)] + [(lp[4], sph[0], CAP_RADII[5]), (lp[5], sph[1], CAP_RADII[6])]
+    _, boxes = scene(task, qpos, target)
+    return caps, boxes[7:]
+
+
+def render(task, qpos, target=None, cam="camera_front", W=320, H=240, prims=None):
     pos, X, Y, Z = camera(task, cam)
-    caps, boxes = scene(task, qpos, target)
+    caps, boxes = scene(task, qpos, target) if prims is None else prims
     s = 2.0 * np.tan(np.radians(45.0) / 2) / H
     v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     sx = (u + 0.5 - 0.5 * W) * s

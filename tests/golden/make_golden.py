@@ -440,6 +440,10 @@ def mk_model():
     # hull extents of the four links that carry sphere proxies: bounding box and slab extents along the link's long axis (x)
     mdir = os.path.join(ASSETS, "follower_meshes")
     aabb, slabs = {}, {}
+    # (round 5: the bounding boxes of all seven collision hulls -- what the ray-casters draw for the arm; slabs only for the four links that carry proxies)
+    for name in ("base_link_collision", "link_1_collision", "link_2_collision"):
+        v = _stl_vertices(os.path.join(mdir, meshes[name]))
+        aabb[name] = {"min": [round(float(x), 6) for x in v.min(0)], "max": [round(float(x), 6) for x in v.max(0)]}
     for name in ("link_3_collision", "link_4_collision", "link_5_collision", "link_6_collision"):
         v = _stl_vertices(os.path.join(mdir, meshes[name]))
         aabb[name] = {"min": [round(float(x), 6) for x in v.min(0)], "max": [round(float(x), 6) for x in v.max(0)]}

@@ -75,6 +75,21 @@ def pad_boxes(golden=None):
     return out
 
 
+def arm_boxes(golden=None):
+    """[(centre, half extents)] of the collision-hull bounding boxes of base_link, link_1 .. link_6, body frames"""
+    import json
+    import os
+
+    if golden is None:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "model_golden.json")) as fh:
+            golden = json.load(fh)
+    out = []
+    for name in ("base_link_collision", "link_1_collision", "link_2_collision", "link_3_collision", "link_4_collision", "link_5_collision", "link_6_collision"):
+        lo, hi = golden["mesh_aabb"][name]["min"], golden["mesh_aabb"][name]["max"]
+        out.append(([0.5 * (a + b) for a, b in zip(lo, hi)], [0.5 * (b - a) for a, b in zip(lo, hi)]))
+    return out
+
+
 def quat2mat(q):
     w, x, y, z = np.asarray(q, float) / np.linalg.norm(q)
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
@@ -168,6 +183,13 @@ def main():
         for k, ax in enumerate("xyz"):
             L.append(f"constexpr float SPH{s}{ax} = {f(SPH_POS[s][k])};")
         L.append(f"constexpr float SPH{s}r = {f(SPH_RAD[s])};")
+    # the renderers draw the arm as the bounding boxes of its seven collision hulls (model_golden.json "mesh_aabb", body frames) instead of capsules between the link origins
+    L.append("// bounding boxes of the collision hulls of base_link (0), link_1 .. link_6 (1 .. 6) in their body frames (centre, half extents): what lcr_render.hip / oracle/render_oracle.py draw for the arm")
+    for i, (c, h) in enumerate(arm_boxes()):
+        for k, ax in enumerate("xyz"):
+            L.append(f"constexpr float ARMB{i}c{ax} = {f(c[k])};")
+        for k, ax in enumerate("xyz"):
+            L.append(f"constexpr float ARMB{i}h{ax} = {f(h[k])};")
     # finger pads as boxes (the faithful preset): bounding box of the two outermost slabs of each finger's collision hull, link frame (centre, half extents)
     L.append("// finger pad boxes (preset faithful; oracle PAD_C / PAD_H): the two outermost slabs of link_5_collision / link_6_collision (model_golden.json mesh_slabs_x)")
     for s, (c, h) in enumerate(pad_boxes()):
