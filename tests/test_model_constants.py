@@ -158,6 +158,33 @@ def test_finger_pad_boxes_follow_the_hull_slabs():
         assert all(abs(sp["pos"][k] - c[k]) <= hh[k] for k in range(3)), (s, sp, c, hh)     # the sphere's centre lies in the box
 
 
+def test_arm_boxes_of_the_ray_casters_are_the_hull_bounding_boxes():
+    """what the ray-casters draw for the arm (round 5): the bounding boxes of the seven collision hulls of follower.xml:54-97 -- kernel constants ARMB0 .. ARMB6
+    of lcr_model_gen.h and the boxes of oracle/render_oracle.py:scene, both from the golden file's mesh_aabb; base_link's box stands on the floor around the origin,
+    every link's box contains its proxies' centres"""
+    from oracle import render_oracle
+
+    names = ("base_link_collision", "link_1_collision", "link_2_collision", "link_3_collision", "link_4_collision", "link_5_collision", "link_6_collision")
+    h = _header_values()
+    for i, name in enumerate(names):
+        lo, hi = np.array(G["mesh_aabb"][name]["min"]), np.array(G["mesh_aabb"][name]["max"])
+        assert [h[f"ARMB{i}c{ax}"] for ax in "xyz"] == [float(np.float32(v)) for v in 0.5 * (lo + hi)]
+        assert [h[f"ARMB{i}h{ax}"] for ax in "xyz"] == [float(np.float32(v)) for v in 0.5 * (hi - lo)]
+    q = np.zeros(13); q[9] = 1.0; q[6:9] = [0.0, 0.2, 0.015]
+    caps, boxes = render_oracle.scene("reach", q)
+    assert caps == [] and len(boxes) == 8          # seven arm boxes and the cube
+    bc, R, bh = boxes[0][:3]                       # base_link: Rz(-90 deg) at the origin
+    corners = np.array([bc + R @ (np.array([sx, sy, sz]) * bh) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    assert abs(corners[:, 2].min()) < 2e-3 and corners[:, 2].max() < 0.06         # stands on the floor, 4 cm high
+    assert corners[:, 0].min() < 0 < corners[:, 0].max() and corners[:, 1].min() < 0 < corners[:, 1].max()
+    t = orc.model_table()
+    Rl, pl = orc.link_frames(np.zeros(6))
+    for sp in t["spheres"] + t["proxies"]:          # link index 2 .. 5 = link_3 .. link_6 = boxes 3 .. 6
+        bc, R, bh = boxes[sp["link"] + 1][:3]
+        w = pl[sp["link"]] + Rl[sp["link"]] @ np.array(sp["pos"])
+        assert np.all(np.abs(R.T @ (w - bc)) <= bh + 1e-9), (sp, bc, bh)
+
+
 SLACK = 2.5e-3
 
 
