@@ -461,16 +461,19 @@ def test_vecenv_step_is_vectorised(hip_lib):
     a = np.random.default_rng(0).uniform(-1, 1, (n, 5)).astype(np.float32)
     for _ in range(3):
         obs, rew, dones, infos = v.step(a)
-    t0 = time.perf_counter()
+    dts = []
     for _ in range(10):
+        t0 = time.perf_counter()
         obs, rew, dones, infos = v.step(a)
-    dt = (time.perf_counter() - t0) / 10
+        dts.append(time.perf_counter() - t0)
+    dt = min(dts)   # (the fastest of ten: the other workers' kernels on the shared GPU only ever add time)
     assert len(infos) == n and obs["arm_qpos"].shape == (n, 6)
     live = np.nonzero(~dones)[0]
     assert infos[live[0]] is infos[live[-1]]            # shared dict for envs that did not finish
     print(f"[vecenv] {n} envs: {dt * 1e3:.2f} ms per step = {n / dt:.3e} env-steps/s through LowCostRobotVecEnv.step")
     # alone on the GPU: 4.3 ms per step with the default (faithful, Newton) preset, 1.6 ms with preset fast (tools/facade_latency2.py); the suite runs four GPU
-    # processes at once (-n 4), so the bound only has to tell a vectorised host path from a per-env python loop (which is > 100 ms)
+    # processes at once (-n 4: 69 ms per step seen as the MEAN of ten under a neighbour's Stack job), so the bound only has to tell a vectorised host path from a
+    # per-env python loop (which is > 100 ms)
     assert n / dt > 1e6
     v.close()
 
