@@ -348,7 +348,7 @@ def main():
             "config": {
                 "workload": f"{args.workload}, {n} envs/GPU, {action_mode} control, {args.obs} obs, sparse reward, "
                             f"n_substeps=20, max_episode_steps=50, auto-reset on, preset {args.preset}: "
-                            + ("Newton's method on the primal constraint problem (<= 10 iterations, Illinois line search), six-row finger contacts on cube and floor"
+                            + ("Newton's method on the primal constraint problem to its optimum (newton_tol 1e-6, <= 30 iterations, derivative line search with ls_tol 1e-2), six-row finger contacts on cube and floor, finger pads as boxes"
                                + (", eight-point box-box" if task == "stack" else "") if args.preset == "faithful"
                                else f"block projected-gradient sweeps, pgs_iters={4 if args.pgs_iters is None else args.pgs_iters}"),
                 "preset": args.preset,
