@@ -722,7 +722,9 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         float q1 = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++) q1 = fmaf(mdiag(i) * dx[i], dx[i], q1);
-        const float q0 = d0 + ls_eval(0.f).f;
+        float q0 = 0.f;   // [M (x - x0)] . dx  (M is diagonal in these variables; the oracle's mpart at al = 0)
+#pragma unroll
+        for (int i = 0; i < NX; i++) q0 = fmaf(mdiag(i) * (x[i] - x0[i]), dx[i], q0);
         float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f, hlo = -d0, hhi = 0.f, dlo_m = d0, dhi_m = 0.f;
         int last_side = 0, same = 0;
         bool done = !live, conv = !live;
