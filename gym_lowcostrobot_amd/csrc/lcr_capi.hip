@@ -274,7 +274,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     // a cube, 36 floats per lane of every (64-lane) workgroup
     size_t o_scr = off; off += al(sizeof(float) * 48 * (((N + 63) / 64) * 64));
     const bool carry_warm = !(cfg->compat & LCR_COMPAT_COLD_SOLVE_EACH_STEP);
-    size_t o_warm = off; if (carry_warm) off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps
+    size_t o_warm = off; off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps (without carry_warm: between the substeps of a step, LcrDev::warm_mem)
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
@@ -371,6 +371,8 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             D.newton = cfg->solver == LCR_SOLVER_NEWTON ? 1 : 0;
             D.newton_iters = cfg->newton_iters; D.ls_iters = cfg->ls_iters;
             D.newton_tol = (float)cfg->newton_tol; D.ls_tol = (float)cfg->ls_tol;
+            D.coop_max = 3;   // coupled envs a wave of the one-cube Newton kernels solves one by one (lcr_newton_coop.h); measurement override: LCR_COOP_MAX (0: never)
+            if (const char *cm_ov = getenv("LCR_COOP_MAX")) D.coop_max = atoi(cm_ov) < 0 ? 0 : (atoi(cm_ov) > 64 ? 64 : atoi(cm_ov));
             if (D.newton) { D.coop = 0; D.roll = 1; D.big_lds = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots, every g row in LDS (cc8: slots 4-7 of their eight cube<->cube records)
         }
     }
@@ -415,6 +417,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.ctrl_out = cfg->diagnostics ? (float *)(base + o_diag + 4 * al(sizeof(unsigned) * N)) : nullptr;
     D.scratch = (float *)(base + o_scr);
     D.warm = carry_warm ? (float *)(base + o_warm) : nullptr;
+    D.warm_mem = (float *)(base + o_warm);
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
     D.img_bg = s->has_images ? (unsigned char *)(base + o_bg) : nullptr;

@@ -22,6 +22,7 @@
 //   reset                     envs/reach_cube_env.py:297-311, push:308-328, pick_place:316-336, stack:307-324
 #include "lcr_step_common.h"
 #include "lcr_newton.h"
+#include "lcr_newton_coop.h"
 
 // translation-unit selection, see the launchers at the end of the file
 #ifndef LCR_PART
@@ -36,9 +37,17 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // NEWTON (the faithful preset): every finger contact has MuJoCo's six rows -- against the floor too (follower.xml:15 condim="6") -- and the constraint problem is solved
 // by Newton's method on the primal (lcr_newton.h) instead of sweeps on the dual
-template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
-DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
+// CPL (one-cube Newton kernels): the substep exists in two copies so that the coupled arm + cube problem (12 unknowns, 78-entry Hessian) does not set the register
+// allocation of the substeps that do not need it.  CPL_FAST: arm and cube are separate 6-dimensional problems; the copy returns false -- the env state untouched -- as
+// soon as some lane of the wave has a finger or a gripper-body proxy on its cube.  CPL_SLOW: the coupled solve; returns whether some lane was coupled (the caller
+// goes back to the fast copy when none was).  CPL_BOTH: one copy with both (Stack, PushCubeLoop).
+constexpr int CPL_BOTH = 0, CPL_FAST = 1, CPL_SLOW = 2;
+template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false, int CPL = CPL_BOTH, class WT = Warm<NC, ROLL ? 6 : 4>>
+DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], WT &W, Diag &DGtot, int sub_index) {
+    constexpr bool WMEM = std::is_same<WT, WarmMem>::value;
+    static_assert(!WMEM || NC == 1, "carried forces in memory: one-cube kernels");
     static_assert(!NEWTON || (ROLL && !ADAPT && (NC == 1 || BIG)), "the Newton kernels carry six-row finger slots and keep every g row in LDS");
+    static_assert(CPL == CPL_BOTH || (NEWTON && NC == 1), "two copies of the substep: one-cube Newton kernels only");
     constexpr int NCC = NEWTON ? 8 : 4;   // cube<->cube manifold points (Stack): the Newton kernels carry eight slots, 4-7 in use with lcr_config.cc_points = 8
     constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();   // first LDS row of the cube<->cube records
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
@@ -46,8 +55,11 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     using namespace lcrm;
     // ---- position stage -------------------------------------------------------------------------
     CubeRot CR[NC];
+    float cq_in[NC][4];   // (CPL_FAST) the quaternion as it came in: a bail-out leaves the state as it found it
 #pragma unroll
     for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cq_in[c][k] = S.cq[c][k];
         float n2 = S.cq[c][0] * S.cq[c][0] + S.cq[c][1] * S.cq[c][1] + S.cq[c][2] * S.cq[c][2] + S.cq[c][3] * S.cq[c][3];
         float in = rsq(n2);
 #pragma unroll
@@ -236,7 +248,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
             // warm start: forces of the previous substep if this slot was active then (inactive slots were zeroed)
 #pragma unroll
-            for (int k = 0; k < 4; k++) { T.f[k] = T.act ? W.floor[c][s][k] : 0.f; }
+            for (int k = 0; k < 4; k++) { T.f[k] = T.act ? w_floor(W, c, s, k) : 0.f; }
             const f3 r = T.r;
             ca[c].z = fmaf(minv, T.f[0], ca[c].z);
             ca[c].y = fmaf(minv, T.f[1], ca[c].y);
@@ -425,6 +437,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
     int link_bi = 0;             // slot 4: which proxy
     int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
+    bool coupled = false;          // (NEWTON) this lane's arm touches its cube: arm and cube are ONE problem
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
     const float srad[2] = {SPH0r, SPH1r};
@@ -520,6 +533,16 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             invw_link = bi < 2 ? INVW_TRAN_L3 : (bi == 2 ? INVW_TRAN_L4 : (bi == 3 ? INVW_TRAN_L5 : INVW_TRAN_L6));
         }
         T.act = dist < 0.f;
+        if (may_cube) coupled = coupled || (T.act && (s < 2 || oncube));
+        if constexpr (CPL == CPL_FAST) {   // more lanes with a finger or a gripper-body proxy on their cube than are solved one by one: this substep belongs to the other copy
+            if (may_cube && __popcll(__ballot(coupled)) > P.coop_max) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) S.cq[c][k] = cq_in[c][k];
+                return false;
+            }
+        }
         if (P.diag) {
             if (may_cube && (s < 2 || oncube)) sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : ((NEWTON && s < 2) ? 2 : 16);   // branch of make_frame (pad boxes: sel = cube + 2 branch + 4 code)
             diag_choice(DG, T.act, 12 + s, sel);
@@ -664,7 +687,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (r == 0) Ln = KF * arr;
                     else Lt = fmaf(row_on ? KF * m2r : 0.f, arr, Lt);
                 }
-                const float fw = row_on ? W.arm[s][r] : 0.f;
+                const float fw = row_on ? w_arm(W, s, r) : 0.f;
                 T.f[r] = fw;
                 if (body_row) tau = axpy(fw, d, tau);
                 else {
@@ -701,7 +724,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     for (int j = 0; j < 6; j++) {
         lim_act[j] = (S.q[j] < JLO[j]) || (S.q[j] > JHI[j]);
         if (P.diag) diag_choice(DG, lim_act[j], 18 + j, S.q[j] < JLO[j] ? 0 : 1);
-        flim[j] = lim_act[j] ? W.lim[j] : 0.f;
+        flim[j] = lim_act[j] ? w_lim(W, j) : 0.f;
         lim_wave |= __any(lim_act[j]) ? (1u << j) : 0u;
     }
     const bool wave_lim = lim_wave != 0u;
@@ -724,6 +747,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     //      of the wave, at most 50 sweeps ----
     const int max_it = NEWTON ? 0 : (ADAPT ? 50 : P.pgs_iters);
     int sweeps_done = 0;
+    bool coupled_any = false;   // (NEWTON, one cube) some lane of the wave had the arm on its cube in this substep
     if constexpr (NEWTON) {
         // ---- Newton on the primal (lcr_newton.h; oracle: newton_product).  The set-up above has already put the carried forces' accelerations into y / ca / cal:
         //      x0 = a0 + M^-1 J'f, MuJoCo's qacc_warmstart.  The bodies are solved per connected component of the wave's coupling graph: while no lane has a finger
@@ -740,11 +764,24 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         if constexpr (NC == 1) {
             const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
             prof_coupled = arm_on_cube;
-            if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal);
+            const unsigned long long cmask = __ballot(coupled);
+            coupled_any = __popcll(cmask) > P.coop_max;   // (CPL_SLOW: stay in this copy while more lanes are coupled than the cooperative solve takes)
+            if constexpr (CPL == CPL_SLOW) sweeps_done = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal);   // (uncoupled lanes: the same optimum, block-diagonal Hessian)
+            else if (CPL == CPL_BOTH && arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal);
             else {
+                // the lanes whose arm touches their cube sit out the two small solves and are then solved one by one by the whole wave (lcr_newton_coop.h)
+                C.enable = CPL == CPL_BOTH || !coupled;
                 const int ia = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal);
                 const int ic = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
                 sweeps_done = max(ia, ic);
+                if constexpr (CPL == CPL_FAST) {
+                    float *stage = lds + NEWTON_G_ROWS * LDS_ROW;
+                    for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
+                        const int L = __builtin_ctzll(m);
+                        const int ip = coop_solve<NC, NRW, NCC>(C, stage, lane, L, y, ca, cal);
+                        sweeps_done = lane == L ? ip : sweeps_done;
+                    }
+                }
             }
         } else {
             // edges of the wave's coupling graph: arm <-> cube c where some lane has a finger sphere or a gripper-body proxy on that cube, cube 0 <-> cube 1 where some
@@ -1024,13 +1061,15 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) W.floor[c][s][k] = FS[c][s].f[k];
+            for (int k = 0; k < 4; k++) w_set_floor(W, c, s, k, FS[c][s].f[k]);
 #pragma unroll
     for (int s = 0; s < NAS; s++)
 #pragma unroll
-        for (int k = 0; k < NRW; k++) W.arm[s][k] = AS[s].f[k];
+        for (int k = 0; k < NRW; k++) w_set_arm(W, s, k, AS[s].f[k]);
+    if constexpr (!WMEM) {
 #pragma unroll
-    for (int s = 0; s < NCC; s++) W.cc_prev[s] = cc_act[s];
+        for (int s = 0; s < NCC; s++) W.cc_prev[s] = cc_act[s];
+    }
     if (P.diag == 1 || (P.diag == 2 && !NEWTON)) {   // wave-uniform (diagnostics = 2 on the Newton kernels: the same fields carry cycle counts instead, see the solve above)
         unsigned m = 0u;
 #pragma unroll
@@ -1052,7 +1091,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         DGtot.choice += DG.choice * (unsigned)(2 * sub_index + 1);   // odd weight: the same choice in another substep hashes differently
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) W.lim[j] = flim[j];
+    for (int j = 0; j < 6; j++) w_set_lim(W, j, flim[j]);
 
     // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y -------------------
     float rhs[6];
@@ -1098,6 +1137,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             S.cq[c][0] = r0 * in; S.cq[c][1] = r1 * in; S.cq[c][2] = r2 * in; S.cq[c][3] = r3 * in;
         }
     }
+    return CPL == CPL_SLOW ? coupled_any : true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1105,7 +1145,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CC_REC * 64 : 0) : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records = 74 KiB)
+    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CC_REC * 64 : COOP_FLOATS) : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records = 74 KiB)
     constexpr int NCC = NEWTON ? 8 : 4;
     constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();
     const int lane = threadIdx.x;
@@ -1198,9 +1238,17 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     // Constraint forces for the warm start of the first substep: carried from the previous control step (P.warm: [LCR_NWARM][N],
     // zero after reset / set_state), as MuJoCo carries mjData.qacc_warmstart from one mj_step to the next -- the reference never
     // resets it between env.step calls.  With LCR_COMPAT_COLD_SOLVE_EACH_STEP (P.warm == nullptr) every control step starts from zero.
+#ifdef LCR_EXP_WMEM
+    constexpr bool WMEM = NEWTON && NC == 1;
+#else
+    constexpr bool WMEM = false;
+#endif
+    // the carried forces stay in memory (WarmMem, lcr_step_common.h)
     Warm<NC, ROLL ? 6 : 4> W;
+    WarmMem WM{__builtin_amdgcn_make_buffer_rsrc(P.warm_mem, 0, (int)(4u * (unsigned)LCR_DEV_NWARM * (unsigned)N), 0x00020000), 4 * e, 4u * (unsigned)N, P.warm == nullptr, valid};
     const bool carry = P.warm != nullptr;   // wave-uniform
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
+    if constexpr (!WMEM) {
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -1224,8 +1272,43 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
             for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r);
         }
     }
+    }
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    if constexpr (NEWTON && NC == 1) {
+        // two copies of the substep (see CPL above): the wave runs the fast one until some lane's arm touches its cube, then the coupled one until no lane's does
+        bool slow = false;   // wave-uniform
+        auto pick_w = [&]() -> auto & { if constexpr (WMEM) return WM; else return W; };
+        auto &WW = pick_w();
+#if defined(LCR_EXP_ONLY) && LCR_EXP_ONLY == 1
+        for (int s = 0; s < P.n_substeps; s++) { substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_FAST>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s); WM.zero = false; }
+#elif defined(LCR_EXP_ONLY) && LCR_EXP_ONLY == 2
+        for (int s = 0; s < P.n_substeps; s++) { substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_SLOW>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s); WM.zero = false; }
+#else
+        for (int s = 0; s < P.n_substeps; s++) {
+            if (!slow) {
+#ifdef LCR_EXP_MARK
+                asm volatile("; MARK_FAST_BEGIN");
+#endif
+                slow = !substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_FAST>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s);
+#ifdef LCR_EXP_MARK
+                asm volatile("; MARK_FAST_END");
+#endif
+            }
+            if (slow) {
+#ifdef LCR_EXP_MARK
+                asm volatile("; MARK_SLOW_BEGIN");
+#endif
+                slow = substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_SLOW>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s);
+#ifdef LCR_EXP_MARK
+                asm volatile("; MARK_SLOW_END");
+#endif
+            }
+            WM.zero = false;   // from the second substep on the forces of the previous one are there
+        }
+#endif
+    } else {
+        for (int s = 0; s < P.n_substeps; s++) substep<NC, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    }
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
@@ -1308,6 +1391,12 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
         if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);  // data.time advances in mj_step only
     }
+    if constexpr (WMEM) {   // the forces are in place; an env that was just reset starts from zero
+        if (carry && valid && do_reset) {
+#pragma unroll
+            for (int i = 0; i < 68; i++) { if (i < 16 || i >= 32) P.warm[(size_t)i * N + e] = 0.f; }   // WARM_FLOOR 0-15, WARM_ARM 32-61, WARM_LIM 62-67
+        }
+    } else
     if (carry && valid) {   // forces for the next control step's first substep; an env that was just reset starts from zero
         auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
 #pragma unroll

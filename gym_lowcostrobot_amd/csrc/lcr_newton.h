@@ -176,6 +176,7 @@ struct NewtonCtx {
     float (&flim)[6];
     const float (&y0s)[6];
     int wave_its = 0;            // iterations this wave has executed in its solves of the substep (profiling aid, lcr_config.diagnostics = 2)
+    bool enable = true;          // false: this lane's env is solved elsewhere (lcr_newton_coop.h) -- it never counts as live here and its accelerations stay as they are
 };
 
 template <int MASK> constexpr int nw_off(int body) {   // first compact index of a body of MASK
@@ -196,6 +197,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     // residual rows: joint limits, arm slots (6 rows each, slot 4: 4), floor slots per cube, rails, cube<->cube
     constexpr int Z_LIM = 0, Z_ARM = 6, Z_FLOOR = 34, Z_WALL = Z_FLOOR + 16 * NC, Z_CC = Z_WALL + (WALLS ? 16 : 0), NZ = Z_CC + (NC == 2 ? 4 * NCC : 0);
     const NewtonParams &P = C.P;
+    int ln = C.lane;   // the lane's LDS column; re-defined (an empty asm) at the top of every iteration: see the loop
     const float cm = P.cube_mass, ci = rcp(P.cube_iinv);
     auto mdiag = [&](int i) -> float { return (HAS_A && i < 6) ? 1.f : (((i - (HAS_A ? 6 : 0)) % 6) < 3 ? cm : ci); };
     const bool wave_lim = HAS_A && C.lim_wave != 0u;
@@ -266,7 +268,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         auto ld = [&](int lrow, float (&o)[6]) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float2v gp = *reinterpret_cast<const float2v *>(&C.lds[lrow * LDS_ROW + k * 128 + C.lane * 2]);
+                const float2v gp = *reinterpret_cast<const float2v *>(&C.lds[lrow * LDS_ROW + k * 128 + ln * 2]);
                 o[2 * k] = gp.x; o[2 * k + 1] = gp.y;
             }
         };
@@ -690,6 +692,12 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     int lane_its = 0;   // iterations in which THIS env still moved (what the oracle counts per env)
     float dprev = 3.0e38f;
     for (int it = 0; it < P.newton_iters; it++) {
+#ifndef LCR_EXP_NOPIN
+        // The constraint rows are constants of the solve and every one of them is rebuilt from LDS where it is used (twice per iteration).  Left alone, the compiler
+        // hoists those loads -- and what is computed from them -- out of the loop and then has to SPILL them (hundreds of values: an LDS load turned into a scratch load).
+        // Re-defining the lane's LDS column per iteration keeps the loads where they are.
+        asm volatile("" : "+v"(ln));
+#endif
         float dx[NX], d0 = 0.f;
         {
             float Hm[NH], g[NX], hid[NX];
@@ -707,7 +715,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         float dist2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++) dist2 = fmaf(mdiag(i) * (x[i] - x0[i]), x[i] - x0[i], dist2);
-        const bool live = -d0 > tol2 && !(-d0 <= DEC_FLOOR * dist2 && -d0 >= 0.25f * dprev);
+        const bool live = C.enable && -d0 > tol2 && !(-d0 <= DEC_FLOOR * dist2 && -d0 >= 0.25f * dprev);
         dprev = -d0;
         if (!__any(live)) break;
         lane_its += live ? 1 : 0;
