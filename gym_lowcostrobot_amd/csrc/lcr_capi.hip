@@ -214,6 +214,15 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     if (cfg->global_envs > 0 && (cfg->env_id_offset < 0 || cfg->env_id_offset + (int64_t)cfg->n_envs > cfg->global_envs))
         return fail(LCR_ERR_INVALID, "shard [env_id_offset, env_id_offset + n_envs) = [%lld, %lld) does not lie inside the job of global_envs = %lld",
                     (long long)cfg->env_id_offset, (long long)(cfg->env_id_offset + cfg->n_envs), (long long)cfg->global_envs);
+    // A wave (64 consecutive env ids) takes its shortcuts -- slots no lane touches, the coupled lanes it solves cooperatively, the exits of the solver loops -- for all of
+    // its lanes at once, so the low-order bits of an env's result depend on which envs share its wave.  "Identical bits for every sharding of a job" (lcr.h) therefore
+    // requires that shards are cut at wave boundaries: a shard of a larger job starts at a multiple of 64 and, unless it is the job's last, holds a multiple of 64 envs.
+    {
+        const bool last = cfg->global_envs <= 0 || cfg->env_id_offset + (int64_t)cfg->n_envs == cfg->global_envs;   // (no job declared: the handle is the job's only or last shard)
+        if (cfg->env_id_offset % 64 != 0 || (!last && cfg->n_envs % 64 != 0))
+            return fail(LCR_ERR_INVALID, "shard [%lld, %lld) of a job of %lld envs is not cut at wave boundaries: env_id_offset and (except for the last shard) n_envs must be multiples of 64 (lcr.h: global_envs)",
+                        (long long)cfg->env_id_offset, (long long)(cfg->env_id_offset + cfg->n_envs), (long long)cfg->global_envs);
+    }
     if (cfg->obs_mode < LCR_OBS_IMAGE || cfg->obs_mode > LCR_OBS_BOTH) return fail(LCR_ERR_INVALID, "invalid observation_mode");
     if (cfg->reward_type != LCR_REWARD_SPARSE && cfg->reward_type != LCR_REWARD_DENSE) return fail(LCR_ERR_INVALID, "invalid reward_type");
     int k = lcr_action_dim(cfg);
@@ -274,7 +283,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     // a cube, 36 floats per lane of every (64-lane) workgroup
     size_t o_scr = off; off += al(sizeof(float) * 48 * (((N + 63) / 64) * 64));
     const bool carry_warm = !(cfg->compat & LCR_COMPAT_COLD_SOLVE_EACH_STEP);
-    size_t o_warm = off; off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps (without carry_warm: between the substeps of a step, LcrDev::warm_mem)
+    size_t o_warm = off; if (carry_warm) off += al(sizeof(float) * LCR_NWARM * N);   // constraint forces carried between control steps
     size_t o_act = off; off += al(sizeof(float) * 6 * N);
     size_t o_mask = off; off += al(N);
     size_t o_seeds = off; off += al(sizeof(unsigned long long) * N);
@@ -371,7 +380,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             D.newton = cfg->solver == LCR_SOLVER_NEWTON ? 1 : 0;
             D.newton_iters = cfg->newton_iters; D.ls_iters = cfg->ls_iters;
             D.newton_tol = (float)cfg->newton_tol; D.ls_tol = (float)cfg->ls_tol;
-            D.coop_max = 3;   // coupled envs a wave of the one-cube Newton kernels solves one by one (lcr_newton_coop.h); measurement override: LCR_COOP_MAX (0: never)
+            D.coop_max = 4;   // coupled envs a wave of the one-cube Newton kernels solves one by one (lcr_newton_coop.h); measurement override: LCR_COOP_MAX (0: never)
             if (const char *cm_ov = getenv("LCR_COOP_MAX")) D.coop_max = atoi(cm_ov) < 0 ? 0 : (atoi(cm_ov) > 64 ? 64 : atoi(cm_ov));
             if (D.newton) { D.coop = 0; D.roll = 1; D.big_lds = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots, every g row in LDS (cc8: slots 4-7 of their eight cube<->cube records)
         }
@@ -417,7 +426,6 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     D.ctrl_out = cfg->diagnostics ? (float *)(base + o_diag + 4 * al(sizeof(unsigned) * N)) : nullptr;
     D.scratch = (float *)(base + o_scr);
     D.warm = carry_warm ? (float *)(base + o_warm) : nullptr;
-    D.warm_mem = (float *)(base + o_warm);
     D.img_front = s->has_images ? (unsigned char *)(base + o_img0) : nullptr;
     D.img_top = s->has_images ? (unsigned char *)(base + o_img1) : nullptr;
     D.img_bg = s->has_images ? (unsigned char *)(base + o_bg) : nullptr;

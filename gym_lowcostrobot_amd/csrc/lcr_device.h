@@ -71,8 +71,7 @@ struct LcrDev {
     int newton;                      // 1: lcr_config.solver = LCR_SOLVER_NEWTON
     int newton_iters, ls_iters;      // most Newton iterations per substep / most evaluations of phi' per line search
     float newton_tol, ls_tol;
-    int coop_max;                    // one-cube Newton kernels: a wave solves up to this many coupled (arm on cube) envs one by one with all its lanes (lcr_newton_coop.h); more: the 12-dimensional SIMT solve
-    float *warm_mem;                 // [LCR_NWARM][n], never null: where the one-cube Newton kernels keep the carried forces DURING a step (== warm when forces are carried between steps)
+    int coop_max;                    // Newton kernels: a wave solves up to this many coupled (arm on cube, cube on cube) envs one by one with all its lanes (lcr_newton_coop.h); more: the 12-dimensional SIMT solve
 };
 
 // pinhole camera: position, world axes (camera looks along -Z), s = 2 tan(fovy/2) / height

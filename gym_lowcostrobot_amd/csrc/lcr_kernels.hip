@@ -37,17 +37,16 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // NEWTON (the faithful preset): every finger contact has MuJoCo's six rows -- against the floor too (follower.xml:15 condim="6") -- and the constraint problem is solved
 // by Newton's method on the primal (lcr_newton.h) instead of sweeps on the dual
-// CPL (one-cube Newton kernels): the substep exists in two copies so that the coupled arm + cube problem (12 unknowns, 78-entry Hessian) does not set the register
-// allocation of the substeps that do not need it.  CPL_FAST: arm and cube are separate 6-dimensional problems; the copy returns false -- the env state untouched -- as
-// soon as some lane of the wave has a finger or a gripper-body proxy on its cube.  CPL_SLOW: the coupled solve; returns whether some lane was coupled (the caller
-// goes back to the fast copy when none was).  CPL_BOTH: one copy with both (Stack, PushCubeLoop).
+// CPL (Newton kernels): the substep exists in two copies so that the coupled problems (arm + cube: 12 unknowns, 78-entry Hessian; Stack's three bodies: 18 unknowns,
+// 171 entries) do not set the register allocation of the substeps that do not need them.  CPL_FAST: every body is its own 6-dimensional SIMT problem; the envs of
+// the wave in which bodies touch (a finger or a gripper-body proxy on a cube, cube on cube) are solved one by one by the whole wave (lcr_newton_coop.h).  With more
+// than LcrDev::coop_max such envs the copy returns false -- the env state untouched -- and the substep is run by CPL_SLOW: the wave-uniform coupled SIMT solves of
+// round 5; it returns whether the wave still has that many (the caller goes back to the fast copy when not).  CPL_BOTH: one copy with both (PushCubeLoop).
 constexpr int CPL_BOTH = 0, CPL_FAST = 1, CPL_SLOW = 2;
-template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false, int CPL = CPL_BOTH, class WT = Warm<NC, ROLL ? 6 : 4>>
-DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], WT &W, Diag &DGtot, int sub_index) {
-    constexpr bool WMEM = std::is_same<WT, WarmMem>::value;
-    static_assert(!WMEM || NC == 1, "carried forces in memory: one-cube kernels");
+template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false, int CPL = CPL_BOTH>
+DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
     static_assert(!NEWTON || (ROLL && !ADAPT && (NC == 1 || BIG)), "the Newton kernels carry six-row finger slots and keep every g row in LDS");
-    static_assert(CPL == CPL_BOTH || (NEWTON && NC == 1), "two copies of the substep: one-cube Newton kernels only");
+    static_assert(CPL == CPL_BOTH || NEWTON, "two copies of the substep: the Newton kernels");
     constexpr int NCC = NEWTON ? 8 : 4;   // cube<->cube manifold points (Stack): the Newton kernels carry eight slots, 4-7 in use with lcr_config.cc_points = 8
     constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();   // first LDS row of the cube<->cube records
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
@@ -248,7 +247,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
             // warm start: forces of the previous substep if this slot was active then (inactive slots were zeroed)
 #pragma unroll
-            for (int k = 0; k < 4; k++) { T.f[k] = T.act ? w_floor(W, c, s, k) : 0.f; }
+            for (int k = 0; k < 4; k++) { T.f[k] = T.act ? W.floor[c][s][k] : 0.f; }
             const f3 r = T.r;
             ca[c].z = fmaf(minv, T.f[0], ca[c].z);
             ca[c].y = fmaf(minv, T.f[1], ca[c].y);
@@ -266,6 +265,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
     for (int s = 0; s < NCC; s++) cc_act[s] = false;
     bool cc_any = false;
+    bool coupled = false;   // (NEWTON) bodies of this lane's env touch -- its arm a cube, cube on cube --: they are ONE problem
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
     float *ccl = lds + CCB * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
     const size_t CS = 64;
@@ -383,6 +383,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
         }
         cc_any = __any(cnt > 0) != 0;
+        coupled = cnt > 0;
         if (cc_any) {
             make_frame(ccn, cct1, cct2);
 #pragma unroll
@@ -437,7 +438,6 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     int link_nj = 3;             // slot 4: number of joints that move the contact point (proxy on link_3: 3 ... link_6: 6)
     int link_bi = 0;             // slot 4: which proxy
     int slot_cube[3] = {0, 0, 0};  // which cube the cube slots 0, 1 and 4 refer to (Stack)
-    bool coupled = false;          // (NEWTON) this lane's arm touches its cube: arm and cube are ONE problem
     {
     const f3 sph[2] = {local_point(F, 4, SPH0x, SPH0y, SPH0z), local_point(F, 5, SPH1x, SPH1y, SPH1z)};
     const float srad[2] = {SPH0r, SPH1r};
@@ -687,7 +687,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     if (r == 0) Ln = KF * arr;
                     else Lt = fmaf(row_on ? KF * m2r : 0.f, arr, Lt);
                 }
-                const float fw = row_on ? w_arm(W, s, r) : 0.f;
+                const float fw = row_on ? W.arm[s][r] : 0.f;
                 T.f[r] = fw;
                 if (body_row) tau = axpy(fw, d, tau);
                 else {
@@ -724,7 +724,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     for (int j = 0; j < 6; j++) {
         lim_act[j] = (S.q[j] < JLO[j]) || (S.q[j] > JHI[j]);
         if (P.diag) diag_choice(DG, lim_act[j], 18 + j, S.q[j] < JLO[j] ? 0 : 1);
-        flim[j] = lim_act[j] ? w_lim(W, j) : 0.f;
+        flim[j] = lim_act[j] ? W.lim[j] : 0.f;
         lim_wave |= __any(lim_act[j]) ? (1u << j) : 0u;
     }
     const bool wave_lim = lim_wave != 0u;
@@ -761,6 +761,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                                          ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
         const long long tn0 = P.diag == 2 ? clock64() : 0;   // (profiling aid: cycles of the solves, of the coupled ones, iterations -- tools/newton_phases.py)
         bool prof_coupled = false;
+        unsigned prof_coop = 0u;   // (one cube) cycles of the cooperative solves of this substep, number of envs solved that way
+        int prof_patients = 0;
         if constexpr (NC == 1) {
             const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
             prof_coupled = arm_on_cube;
@@ -776,11 +778,14 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 sweeps_done = max(ia, ic);
                 if constexpr (CPL == CPL_FAST) {
                     float *stage = lds + NEWTON_G_ROWS * LDS_ROW;
+                    const long long tc0 = P.diag == 2 ? clock64() : 0;
+                    prof_patients = __popcll(cmask);
                     for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
                         const int L = __builtin_ctzll(m);
                         const int ip = coop_solve<NC, NRW, NCC>(C, stage, lane, L, y, ca, cal);
                         sweeps_done = lane == L ? ip : sweeps_done;
                     }
+                    if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);
                 }
             }
         } else {
@@ -792,6 +797,23 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             on0 = on0 || (AS[4].act && link_on_cube && slot_cube[2] == 0); on1 = on1 || (AS[4].act && link_on_cube && slot_cube[2] == 1);
             const bool eA0 = __any(on0) != 0, eA1 = __any(on1) != 0, e01 = cc_any;
             int i1 = 0, i2 = 0, i3 = 0;
+            const unsigned long long cmask = __ballot(coupled);
+            coupled_any = __popcll(cmask) > P.coop_max;
+            if constexpr (CPL == CPL_FAST) {
+                // the envs with touching bodies sit out the three small solves and are then solved one by one by the whole wave (lcr_newton_coop.h: all 18 unknowns)
+                C.enable = !coupled;
+                i1 = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
+                i3 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal);
+                float *stage = lds + NEWTON_G_ROWS * LDS_ROW + 8 * CC_REC * 64;
+                const long long tc0 = P.diag == 2 ? clock64() : 0;
+                prof_patients = __popcll(cmask);
+                for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
+                    const int L = __builtin_ctzll(m);
+                    const int ip = coop_solve<NC, NRW, NCC>(C, stage, lane, L, y, ca, cal);
+                    i1 = lane == L ? ip : i1;
+                }
+                if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);
+            } else
             if ((eA0 && eA1) || (e01 && (eA0 || eA1))) i1 = newton_solve<NC, NRW, false, NCC, 7>(C, y, ca, cal);
             else if (eA0) { i1 = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal); }
             else if (eA1) { i1 = newton_solve<NC, NRW, false, NCC, 5>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal); }
@@ -805,7 +827,11 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         }
         if (P.diag == 2) {
             const unsigned dt = (unsigned)(clock64() - tn0);
-            DGtot.mask += dt; DGtot.count += prof_coupled ? dt : 0u; DGtot.choice += (prof_coupled ? 65536u : 0u) + (unsigned)C.wave_its;
+            // mask: cycles of the solves; count: of the coupled ones (the cooperative solves, or the whole solve of a substep in the coupled SIMT copy);
+            // choice: iterations + 65536 envs solved cooperatively + 2^24 substeps in the coupled SIMT copy
+            DGtot.mask += dt; DGtot.count += CPL == CPL_SLOW ? dt : prof_coop;
+            DGtot.choice += (CPL == CPL_SLOW ? (1u << 24) : 0u) + 65536u * (unsigned)prof_patients + (unsigned)C.wave_its;
+            (void)prof_coupled;
         }
     }
     for (int it = 0; it < max_it; it++) {
@@ -1061,15 +1087,13 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) w_set_floor(W, c, s, k, FS[c][s].f[k]);
+            for (int k = 0; k < 4; k++) W.floor[c][s][k] = FS[c][s].f[k];
 #pragma unroll
     for (int s = 0; s < NAS; s++)
 #pragma unroll
-        for (int k = 0; k < NRW; k++) w_set_arm(W, s, k, AS[s].f[k]);
-    if constexpr (!WMEM) {
+        for (int k = 0; k < NRW; k++) W.arm[s][k] = AS[s].f[k];
 #pragma unroll
-        for (int s = 0; s < NCC; s++) W.cc_prev[s] = cc_act[s];
-    }
+    for (int s = 0; s < NCC; s++) W.cc_prev[s] = cc_act[s];
     if (P.diag == 1 || (P.diag == 2 && !NEWTON)) {   // wave-uniform (diagnostics = 2 on the Newton kernels: the same fields carry cycle counts instead, see the solve above)
         unsigned m = 0u;
 #pragma unroll
@@ -1091,7 +1115,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         DGtot.choice += DG.choice * (unsigned)(2 * sub_index + 1);   // odd weight: the same choice in another substep hashes differently
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) w_set_lim(W, j, flim[j]);
+    for (int j = 0; j < 6; j++) W.lim[j] = flim[j];
 
     // ---- implicitfast: (M + h (damping + kv) I) qacc = qfrc_smooth + J^T f = L y -------------------
     float rhs[6];
@@ -1145,7 +1169,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CC_REC * 64 : COOP_FLOATS) : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records = 74 KiB)
+    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CC_REC * 64 : 0) + coop_floats<NC>() : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records = 74 KiB)
     constexpr int NCC = NEWTON ? 8 : 4;
     constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();
     const int lane = threadIdx.x;
@@ -1238,17 +1262,9 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     // Constraint forces for the warm start of the first substep: carried from the previous control step (P.warm: [LCR_NWARM][N],
     // zero after reset / set_state), as MuJoCo carries mjData.qacc_warmstart from one mj_step to the next -- the reference never
     // resets it between env.step calls.  With LCR_COMPAT_COLD_SOLVE_EACH_STEP (P.warm == nullptr) every control step starts from zero.
-#ifdef LCR_EXP_WMEM
-    constexpr bool WMEM = NEWTON && NC == 1;
-#else
-    constexpr bool WMEM = false;
-#endif
-    // the carried forces stay in memory (WarmMem, lcr_step_common.h)
     Warm<NC, ROLL ? 6 : 4> W;
-    WarmMem WM{__builtin_amdgcn_make_buffer_rsrc(P.warm_mem, 0, (int)(4u * (unsigned)LCR_DEV_NWARM * (unsigned)N), 0x00020000), 4 * e, 4u * (unsigned)N, P.warm == nullptr, valid};
     const bool carry = P.warm != nullptr;   // wave-uniform
     auto wld = [&](int idx) -> float { return (carry && valid) ? P.warm[(size_t)idx * N + e] : 0.f; };
-    if constexpr (!WMEM) {
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -1272,40 +1288,14 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
             for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r);
         }
     }
-    }
     Diag DG = {0u, 0u, 0u, 0u};
-    if constexpr (NEWTON && NC == 1) {
-        // two copies of the substep (see CPL above): the wave runs the fast one until some lane's arm touches its cube, then the coupled one until no lane's does
+    if constexpr (NEWTON) {
+        // two copies of the substep (see CPL above): the wave runs the fast one while at most coop_max of its lanes are coupled, else the SIMT one
         bool slow = false;   // wave-uniform
-        auto pick_w = [&]() -> auto & { if constexpr (WMEM) return WM; else return W; };
-        auto &WW = pick_w();
-#if defined(LCR_EXP_ONLY) && LCR_EXP_ONLY == 1
-        for (int s = 0; s < P.n_substeps; s++) { substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_FAST>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s); WM.zero = false; }
-#elif defined(LCR_EXP_ONLY) && LCR_EXP_ONLY == 2
-        for (int s = 0; s < P.n_substeps; s++) { substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_SLOW>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s); WM.zero = false; }
-#else
         for (int s = 0; s < P.n_substeps; s++) {
-            if (!slow) {
-#ifdef LCR_EXP_MARK
-                asm volatile("; MARK_FAST_BEGIN");
-#endif
-                slow = !substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_FAST>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s);
-#ifdef LCR_EXP_MARK
-                asm volatile("; MARK_FAST_END");
-#endif
-            }
-            if (slow) {
-#ifdef LCR_EXP_MARK
-                asm volatile("; MARK_SLOW_BEGIN");
-#endif
-                slow = substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_SLOW>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, WW, DG, s);
-#ifdef LCR_EXP_MARK
-                asm volatile("; MARK_SLOW_END");
-#endif
-            }
-            WM.zero = false;   // from the second substep on the forces of the previous one are there
+            if (!slow) slow = !substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_FAST>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+            if (slow) slow = substep<NC, ADAPT, ROLL, BIG, NEWTON, CPL_SLOW>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
         }
-#endif
     } else {
         for (int s = 0; s < P.n_substeps; s++) substep<NC, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
     }
@@ -1391,12 +1381,6 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         P.ee_lag[e] = lag_ee.x; P.ee_lag[N + e] = lag_ee.y; P.ee_lag[2 * N + e] = lag_ee.z;
         if (P.sim_time) P.sim_time[e] = __dadd_rn(P.sim_time[e], (double)P.n_substeps * 0.002);  // data.time advances in mj_step only
     }
-    if constexpr (WMEM) {   // the forces are in place; an env that was just reset starts from zero
-        if (carry && valid && do_reset) {
-#pragma unroll
-            for (int i = 0; i < 68; i++) { if (i < 16 || i >= 32) P.warm[(size_t)i * N + e] = 0.f; }   // WARM_FLOOR 0-15, WARM_ARM 32-61, WARM_LIM 62-67
-        }
-    } else
     if (carry && valid) {   // forces for the next control step's first substep; an env that was just reset starts from zero
         auto wst = [&](int idx, float v) { P.warm[(size_t)idx * N + e] = do_reset ? 0.f : v; };
 #pragma unroll

@@ -197,7 +197,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     // residual rows: joint limits, arm slots (6 rows each, slot 4: 4), floor slots per cube, rails, cube<->cube
     constexpr int Z_LIM = 0, Z_ARM = 6, Z_FLOOR = 34, Z_WALL = Z_FLOOR + 16 * NC, Z_CC = Z_WALL + (WALLS ? 16 : 0), NZ = Z_CC + (NC == 2 ? 4 * NCC : 0);
     const NewtonParams &P = C.P;
-    int ln = C.lane;   // the lane's LDS column; re-defined (an empty asm) at the top of every iteration: see the loop
+    const int ln = C.lane;   // the lane's LDS column
     const float cm = P.cube_mass, ci = rcp(P.cube_iinv);
     auto mdiag = [&](int i) -> float { return (HAS_A && i < 6) ? 1.f : (((i - (HAS_A ? 6 : 0)) % 6) < 3 ? cm : ci); };
     const bool wave_lim = HAS_A && C.lim_wave != 0u;
@@ -692,12 +692,6 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
     int lane_its = 0;   // iterations in which THIS env still moved (what the oracle counts per env)
     float dprev = 3.0e38f;
     for (int it = 0; it < P.newton_iters; it++) {
-#ifndef LCR_EXP_NOPIN
-        // The constraint rows are constants of the solve and every one of them is rebuilt from LDS where it is used (twice per iteration).  Left alone, the compiler
-        // hoists those loads -- and what is computed from them -- out of the loop and then has to SPILL them (hundreds of values: an LDS load turned into a scratch load).
-        // Re-defining the lane's LDS column per iteration keeps the loads where they are.
-        asm volatile("" : "+v"(ln));
-#endif
         float dx[NX], d0 = 0.f;
         {
             float Hm[NH], g[NX], hid[NX];

@@ -6,14 +6,16 @@
 // (LcrDev::coop_max, default 3) the others keep their two small solves (newton_solve<.., 1> / <.., 2> with the coupled lanes disabled) and each coupled env -- the
 // "patient", lane L -- is solved here by all 64 lanes: the same algorithm (lcr_newton.h; oracle: newton_product), laid out the other way round:
 //
-//   lane b < 15 owns ONE constraint block of the patient: b = 0..4 the arm slots (finger<->cube 0 1, finger<->floor 2 3, link proxy 4), 5..8 the cube's floor
-//   slots, 9..14 the joint limits (a limit is a block of one row: blk_eval with no friction rows is max(0, -z / R)).  It keeps its block's rows as dense vectors
-//   in the 12 unknowns (6 x 12 registers), evaluates its cone zone, its share of the gradient J'f and of the Hessian J'WJ (the SIMT code of ONE slot: blk_eval,
-//   h_block), and its share of phi'(al) / phi''(al) in the line search;
-//   the shares are summed through LDS (gradient + Hessian: 90 numbers per block, [block][90] written, summed column-wise by lanes 0..63 / 0..25, the totals read
-//   back by every lane) or by DPP (the two sums of a line-search evaluation);
-//   every lane then holds the whole 12 x 12 system and factorises / solves it redundantly (chol_packed<12>), so the iteration logic -- tolerances, the bracketing
+//   lane b < NB owns ONE constraint block of the patient: b = 0..4 the arm slots (finger<->cube 0 1, finger<->floor 2 3, link proxy 4), then the floor slots of
+//   the cube(s), the eight cube<->cube slots (Stack), last the six joint limits (a limit is a block of one row: blk_eval with no friction rows is max(0, -z / R)):
+//   15 blocks with one cube, 27 with two.  It has its block's rows as dense vectors in the NX = 12 / 18 unknowns, evaluates its cone zone, its share of the gradient
+//   J'f and of the Hessian J'WJ (the SIMT code of ONE slot: blk_eval, h_block), and its share of phi'(al) / phi''(al) in the line search;
+//   the shares are summed through LDS in chunks of 64 numbers ([block][64] written, column e summed by lane e, the totals read back by every lane) or by DPP (the
+//   two sums of a line-search evaluation);
+//   every lane then holds the whole NX x NX system and factorises / solves it redundantly (chol_packed<NX>), so the iteration logic -- tolerances, the bracketing
 //   line search, the exits -- is the SIMT code with wave-uniform values.
+//   Two cubes: a patient is an env with ANY coupling (arm on a cube, cube on cube) and all three bodies are solved as one 18-dimensional problem; the rows are
+//   rebuilt where they are used (twice per iteration) instead of being kept next to the 171-entry Hessian.
 //
 // The patient's data reach the other lanes through an LDS staging area it writes itself (block records, x, a0, the Cholesky factor of M for the limit rows); its
 // results (accelerations, the force of every row) go back the same way.  ~2 k instructions per iteration and patient instead of ~7 k for all lanes.
@@ -24,13 +26,17 @@
 
 namespace {
 
-constexpr int COOP_NB = 15;                      // blocks of one patient (one cube, no rails)
-constexpr int COOP_NX = 12;
-constexpr int COOP_NH = COOP_NX * (COOP_NX + 1) / 2;
-constexpr int COOP_RED = COOP_NX + COOP_NH;      // numbers a block contributes to one Newton step: gradient + packed Hessian
-constexpr int COOP_REC = 28;                     // floats of a block record in the staging area
-constexpr int COOP_FLOATS = COOP_NB * COOP_RED + COOP_RED + 6;   // LDS floats of the cooperative solve: [15][90] shares + [90] totals (the staging area overlays them) -> 5.8 KiB
-static_assert(COOP_NB * COOP_REC + 21 + 12 + 6 + 4 <= COOP_NB * COOP_RED, "staging area fits under the shares");
+template <int NC> constexpr int coop_nb() { return 5 + 4 * NC + (NC == 2 ? 8 : 0) + 6; }   // blocks of one patient: 15 / 27
+template <int NC> constexpr int coop_nx() { return 6 + 6 * NC; }
+constexpr int COOP_REC = 32;                     // floats of a block record in the staging area
+constexpr int COOP_CH = 64;                      // numbers per chunk of the LDS reduction
+// LDS floats of the cooperative solve: [NB][64] shares of one chunk + the totals (gradient + packed Hessian, padded to whole chunks); the staging area overlays the shares
+template <int NC> constexpr int coop_red() { return coop_nx<NC>() + coop_nx<NC>() * (coop_nx<NC>() + 1) / 2; }          // 90 / 189
+template <int NC> constexpr int coop_chunks() { return (coop_red<NC>() + COOP_CH - 1) / COOP_CH; }                        // 2 / 3
+template <int NC> constexpr int coop_stage_floats() { return coop_nb<NC>() * COOP_REC + 21 + coop_nx<NC>() + 6 + 2; }
+template <int NC> constexpr int coop_floats() {
+    return (coop_nb<NC>() * COOP_CH > coop_stage_floats<NC>() ? coop_nb<NC>() * COOP_CH : coop_stage_floats<NC>()) + coop_chunks<NC>() * COOP_CH;
+}
 
 // sum over the 64 lanes, the same value in every lane (DPP row reductions, then the two row broadcasts of GFX9; the total arrives in lane 63)
 DEV float wave_sum(float v) {
@@ -47,31 +53,66 @@ DEV float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// The patient (lane L) writes its problem into the staging area.  Record of block b at stage[b * COOP_REC]: n t1 t2 (0-8), rc (9-11), aref (12-17), Rn (18), Rt (19),
-// m2 of the tangential / torsional / rolling rows (20-22), coef of the cube part (23: -1 arm on the cube, +1 cube on the floor, 0 none), act (24), sign of a limit row (25)
+// H += w v v' restricted to the packed entries [E0, E1)  (the Hessian share of a block is produced chunk by chunk)
+template <int NX, int E0, int E1>
+DEV void h_rank1_part(float (&H)[E1 - E0], const float (&v)[NX], float w) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const float t = w * v[i];
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            if (tri(i, j) >= E0 && tri(i, j) < E1) H[tri(i, j) - E0] = fmaf(t, v[j], H[tri(i, j) - E0]);
+        }
+    }
+}
+
+// The patient (lane L) writes its problem into the staging area.  Record of block b at stage[b * COOP_REC]: n t1 t2 (0-8), lever from the centre of cube 0 / cube 1
+// (9-11 / 12-14), aref (15-20), Rn (21), Rt (22), m2 of the tangential / torsional / rolling rows (23-25), coefficient of the share of cube 0 / cube 1 (26 / 27:
+// -1 arm on that cube, +1 that cube on the floor, -1 / +1 cube 0 / cube 1 of a cube<->cube contact, 0 none), act (28), sign of a limit row (29)
 template <int NC, int NRW, int NCC>
 DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const float (&y)[6], const f3 (&ca)[NC], const f3 (&cal)[NC]) {
+    constexpr int NB = coop_nb<NC>();
     const NewtonParams &P = C.P;
-    auto rec = [&](int b, f3 n, f3 t1, f3 t2, f3 rc, const float *aref, int naref, float Rn, float Rt, float m2t, float m2s, float m2r, float coef, bool act, float sign) {
+    const f3 zero3 = mk(0.f, 0.f, 0.f);
+    auto rec = [&](int b, f3 n, f3 t1, f3 t2, f3 rc0, f3 rc1, const float *aref, int naref, float Rn, float Rt, float m2t, float m2s, float m2r, float c0, float c1, bool act, float sign) {
         float *r = stage + b * COOP_REC;
-        r[0] = n.x; r[1] = n.y; r[2] = n.z; r[3] = t1.x; r[4] = t1.y; r[5] = t1.z; r[6] = t2.x; r[7] = t2.y; r[8] = t2.z; r[9] = rc.x; r[10] = rc.y; r[11] = rc.z;
+        r[0] = n.x; r[1] = n.y; r[2] = n.z; r[3] = t1.x; r[4] = t1.y; r[5] = t1.z; r[6] = t2.x; r[7] = t2.y; r[8] = t2.z;
+        r[9] = rc0.x; r[10] = rc0.y; r[11] = rc0.z; r[12] = rc1.x; r[13] = rc1.y; r[14] = rc1.z;
 #pragma unroll
-        for (int k = 0; k < 6; k++) r[12 + k] = k < naref ? aref[k] : 0.f;
-        r[18] = Rn; r[19] = Rt; r[20] = m2t; r[21] = m2s; r[22] = m2r; r[23] = coef; r[24] = act ? 1.f : 0.f; r[25] = sign;
+        for (int k = 0; k < 6; k++) r[15 + k] = k < naref ? aref[k] : 0.f;
+        r[21] = act ? Rn : 1.f; r[22] = act ? Rt : 1.f; r[23] = m2t; r[24] = m2s; r[25] = m2r; r[26] = c0; r[27] = c1; r[28] = act ? 1.f : 0.f; r[29] = sign;
     };
 #pragma unroll
     for (int s = 0; s < NAS; s++) {
         const ArmSlot<NRW> &T = C.AS[s];
         const bool oncube = s < 2 || (s == 4 && C.link_on_cube);
+        const bool second = NC == 2 && C.slot_cube[s == 4 ? 2 : (s & 1)] == 1;   // which cube the slot talks to (Stack)
         const float m2t = s < 2 ? P.mu_fc2 : (s < 4 ? MU_FINGER * MU_FINGER : (oncube ? P.mu_c2 : 1.f));
         const float m2s = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : (oncube ? P.mu_ct2 : 0.f));
         const float m2r = s < 2 ? P.mu_fcr2 : (s < 4 ? MU_ROLL * MU_ROLL : 0.f);
-        rec(s, T.n, T.t1, T.t2, T.rc, T.aref, NRW, T.Rn, T.Rn * P.inv_impratio * m2t, m2t, m2s, m2r, oncube ? -1.f : 0.f, T.act, 0.f);
+        const bool may_cube = s < 2 || s == 4;
+        rec(s, T.n, T.t1, T.t2, T.rc, T.rc, T.aref, NRW, T.Rn, T.Rn * P.inv_impratio * m2t, m2t, m2s, m2r,
+            (may_cube && oncube && !second) ? -1.f : 0.f, (may_cube && oncube && second) ? -1.f : 0.f, T.act, 0.f);
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const FloorSlot &T = C.FS[0][s];
-        rec(5 + s, mk(0.f, 0.f, 1.f), mk(0.f, 1.f, 0.f), mk(-1.f, 0.f, 0.f), T.r, T.aref, 4, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f, 1.f, T.act, 0.f);
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const FloorSlot &T = C.FS[c][s];
+            rec(5 + 4 * c + s, mk(0.f, 0.f, 1.f), mk(0.f, 1.f, 0.f), mk(-1.f, 0.f, 0.f), T.r, T.r, T.aref, 4, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f,
+                c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, T.act, 0.f);
+        }
+    if constexpr (NC == 2) {   // cube<->cube: the force acts at the contact point on cube 1 and, negated, on cube 0 (records of the patient's own LDS column)
+#pragma unroll
+        for (int s = 0; s < NCC; s++) {
+            const bool act = C.cc_any && C.cc_act[s];
+            const f3 pos = act ? mk(C.ccl[(size_t)(s * CC_REC + 0) * 64], C.ccl[(size_t)(s * CC_REC + 1) * 64], C.ccl[(size_t)(s * CC_REC + 2) * 64]) : zero3;
+            float aref[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) aref[q] = act ? C.ccl[(size_t)(s * CC_REC + 7 + q) * 64] : 0.f;
+            const float Rn = act ? C.ccl[(size_t)(s * CC_REC + 15) * 64] : 1.f;
+            rec(13 + s, C.ccn, C.cct1, C.cct2, pos - C.cp[0], pos - C.cp[NC - 1], aref, 4, Rn, Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f, -1.f, 1.f, act, 0.f);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) {   // joint limits: regulariser and reference acceleration as newton_solve computes them
@@ -80,9 +121,9 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const
         const float imp = impedance(pos, D0_DEF, DW_DEF, 1.0f / W_DEF);
         const float Rn = fmaxf((1.f - imp) * rcp(imp) * INVW_DOF[j], 1e-15f);
         const float aref = -B_DEF * (lower ? 1.f : -1.f) * C.qd[j] - K_DEF * imp * pos;
-        rec(9 + j, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 0.f), &aref, 1, Rn, 1.f, 0.f, 0.f, 0.f, 0.f, C.lim_act[j], lower ? 1.f : -1.f);
+        rec(NB - 6 + j, zero3, zero3, zero3, zero3, zero3, &aref, 1, Rn, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, C.lim_act[j], lower ? 1.f : -1.f);
     }
-    float *g = stage + COOP_NB * COOP_REC;   // the factor of M (strictly lower part row by row, then 1 / L_ii), x, a0 of the arm
+    float *g = stage + NB * COOP_REC;   // the factor of M (strictly lower part row by row, then 1 / L_ii), a0 of the arm, x
     int o = 0;
 #pragma unroll
     for (int i = 1; i < 6; i++)
@@ -91,41 +132,62 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const
 #pragma unroll
     for (int i = 0; i < 6; i++) g[15 + i] = C.CL.id[i];
 #pragma unroll
-    for (int j = 0; j < 6; j++) { g[21 + j] = y[j]; g[33 + j] = C.y0s[j]; }
-    g[27] = ca[0].x; g[28] = ca[0].y; g[29] = ca[0].z; g[30] = cal[0].x; g[31] = cal[0].y; g[32] = cal[0].z;
+    for (int j = 0; j < 6; j++) { g[21 + j] = C.y0s[j]; g[27 + j] = y[j]; }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float *xc = g + 33 + 6 * c;
+        xc[0] = ca[c].x; xc[1] = ca[c].y; xc[2] = ca[c].z; xc[3] = cal[c].x; xc[4] = cal[c].y; xc[5] = cal[c].z;
+    }
 }
 
 // the solve; `lane` = this lane, L = the patient's lane (wave-uniform).  Returns the Newton iterations it took; the patient's y / ca / cal and the forces of its slots are updated.
 template <int NC, int NRW, int NCC>
 DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, int L, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC]) {
-    static_assert(NC == 1, "one cube");
-    constexpr int NX = COOP_NX, NH = COOP_NH;
+    constexpr int NX = coop_nx<NC>(), NH = NX * (NX + 1) / 2, NB = coop_nb<NC>(), RED = coop_red<NC>(), NCH = coop_chunks<NC>();
+    constexpr bool REBUILD = NC == 2;   // the rows are rebuilt where they are used instead of living next to the 171-entry Hessian
     const NewtonParams &P = C.P;
     if (lane == L) coop_stage<NC, NRW, NCC>(C, stage, y, ca, cal);
     // ---- every lane: its block's record, the shared vectors ----
-    const int b = lane < COOP_NB ? lane : COOP_NB - 1;   // (lanes 15..63 shadow the last block with act = false)
+    const int b = lane < NB ? lane : NB - 1;   // (the other lanes shadow the last block with act = false)
     const float *r = stage + b * COOP_REC;
-    const f3 dn = mk(r[0], r[1], r[2]), dt1 = mk(r[3], r[4], r[5]), dt2 = mk(r[6], r[7], r[8]), rc = mk(r[9], r[10], r[11]);
+    const f3 dn = mk(r[0], r[1], r[2]), dt1 = mk(r[3], r[4], r[5]), dt2 = mk(r[6], r[7], r[8]);
+    const f3 rcs[2] = {mk(r[9], r[10], r[11]), mk(r[12], r[13], r[14])};
     float aref[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) aref[k] = r[12 + k];
-    const float Rn = r[18], Rt = r[19], coef = r[23], lsign = r[25];
-    const float m2[6] = {1.f, r[20], r[20], r[21], r[22], r[22]};
-    const bool act = lane < COOP_NB && r[24] != 0.f;
-    const float *gs = stage + COOP_NB * COOP_REC;
+    for (int k = 0; k < 6; k++) aref[k] = r[15 + k];
+    const float Rn = r[21], Rt = r[22], lsign = r[29];
+    const float coefs[2] = {r[26], r[27]};
+    const float m2[6] = {1.f, r[23], r[23], r[24], r[25], r[25]};
+    const bool act = lane < NB && r[28] != 0.f;
+    const float *gs = stage + NB * COOP_REC;
     float x[NX], x0[NX];
 #pragma unroll
-    for (int i = 0; i < NX; i++) x[i] = gs[21 + i];
+    for (int i = 0; i < 6; i++) x0[i] = gs[21 + i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { x0[i] = gs[33 + i]; x0[6 + i] = i == 2 ? -GRAV : 0.f; }
+    for (int i = 6; i < NX; i++) x0[i] = (i - 6) % 6 == 2 ? -GRAV : 0.f;
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = gs[27 + i];
+    float lrow6[6];   // a joint limit's row L^-1 (+-e_j): kept (the factor of M lives in the staging area, which the reduction overwrites)
+#pragma unroll
+    for (int k = 0; k < 6; k++) lrow6[k] = 0.f;
+    if (act && b >= NB - 6) {
+        const int j = b - (NB - 6);
+        float Ls[15], id[6];
+#pragma unroll
+        for (int k = 0; k < 15; k++) Ls[k] = gs[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { id[k] = gs[15 + k]; lrow6[k] = k == j ? lsign : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {   // forward substitution (fsub)
+            float s = lrow6[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) s = fmaf(-Ls[i * (i - 1) / 2 + k], lrow6[k], s);
+            lrow6[i] = s * id[i];
+        }
+    }
     const float cm = P.cube_mass, ci = rcp(P.cube_iinv);
-    auto mdiag = [&](int i) -> float { return i < 6 ? 1.f : (i < 9 ? cm : ci); };
-    // ---- the rows of this lane's block, dense in the 12 unknowns ----
-    float J[6][NX];
-#pragma unroll
-    for (int q = 0; q < 6; q++)
-#pragma unroll
-        for (int i = 0; i < NX; i++) J[q][i] = 0.f;
+    auto mdiag = [&](int i) -> float { return i < 6 ? 1.f : ((i - 6) % 6 < 3 ? cm : ci); };
+    // ---- the rows of this lane's block, dense in the NX unknowns ----
     auto ldrow = [&](int lrow, float (&o6)[6]) {   // g row `lrow` of the patient's LDS column
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -133,101 +195,133 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
             o6[2 * k] = gp.x; o6[2 * k + 1] = gp.y;
         }
     };
-    if (act) {   // (a block that is off keeps zero rows: the g rows of a slot no lane of the wave touches were never written)
-        if (b < 4) {   // a finger slot: three linear rows, then torsion / rolling = d . B of the finger body's three angular rows
-            float bx[6], by[6], bz[6];
-            const int b0 = NEWTON_BODY_ROW0 + 3 * (b & 1);
-            ldrow(b0, bx); ldrow(b0 + 1, by); ldrow(b0 + 2, bz);
+    auto build_rows = [&](float (&J)[6][NX]) {
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                float g6[6];
-                ldrow(3 * b + q, g6);
-                const f3 dd = q == 0 ? dn : (q == 1 ? dt1 : dt2);
+        for (int q = 0; q < 6; q++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) { J[q][k] = g6[k]; J[3 + q][k] = fmaf(dd.x, bx[k], fmaf(dd.y, by[k], dd.z * bz[k])); }
+            for (int i = 0; i < NX; i++) J[q][i] = 0.f;
+        if (act) {   // (a block that is off keeps zero rows: the g rows of a slot no lane of the wave touches were never written)
+            if (b < 4) {   // a finger slot: three linear rows, then torsion / rolling = d . B of the finger body's three angular rows
+                float bx[6], by[6], bz[6];
+                const int b0 = NEWTON_BODY_ROW0 + 3 * (b & 1);
+                ldrow(b0, bx); ldrow(b0 + 1, by); ldrow(b0 + 2, bz);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    float g6[6];
+                    ldrow(3 * b + q, g6);
+                    const f3 dd = q == 0 ? dn : (q == 1 ? dt1 : dt2);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { J[q][k] = g6[k]; J[3 + q][k] = fmaf(dd.x, bx[k], fmaf(dd.y, by[k], dd.z * bz[k])); }
+                }
+            } else if (b == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float g6[6];
+                    ldrow(18 + q, g6);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) J[q][k] = g6[k];
+                }
+            } else if (b >= NB - 6) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) J[0][k] = lrow6[k];
             }
-        } else if (b == 4) {
+            // a cube's share: its contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float g6[6];
-                ldrow(18 + q, g6);
+            for (int c = 0; c < NC; c++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) J[q][k] = g6[k];
-            }
-        } else if (b >= 9) {   // a joint limit: row L^-1 (+-e_j)
-            const int j = b - 9;
-            float g6[6], Ls[15], id[6];
-#pragma unroll
-            for (int k = 0; k < 15; k++) Ls[k] = gs[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { id[k] = gs[15 + k]; g6[k] = k == j ? lsign : 0.f; }
-#pragma unroll
-            for (int i = 0; i < 6; i++) {   // forward substitution (fsub)
-                float s = g6[i];
-#pragma unroll
-                for (int k = 0; k < i; k++) s = fmaf(-Ls[i * (i - 1) / 2 + k], g6[k], s);
-                g6[i] = s * id[i];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++) J[0][k] = g6[k];
+                for (int q = 0; q < 6; q++) {
+                    const f3 d = (q % 3) == 0 ? dn : ((q % 3) == 1 ? dt1 : dt2);
+                    const f3 lin = q < 3 ? coefs[c] * d : mk(0.f, 0.f, 0.f), ang = q < 3 ? coefs[c] * cross(rcs[c], d) : coefs[c] * d;
+                    J[q][6 + 6 * c + 0] = lin.x; J[q][6 + 6 * c + 1] = lin.y; J[q][6 + 6 * c + 2] = lin.z;
+                    J[q][6 + 6 * c + 3] = ang.x; J[q][6 + 6 * c + 4] = ang.y; J[q][6 + 6 * c + 5] = ang.z;
+                }
         }
-        // the cube's share: its contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const f3 d = (q % 3) == 0 ? dn : ((q % 3) == 1 ? dt1 : dt2);
-            const f3 lin = q < 3 ? coef * d : mk(0.f, 0.f, 0.f), ang = q < 3 ? coef * cross(rc, d) : coef * d;
-            J[q][6] = lin.x; J[q][7] = lin.y; J[q][8] = lin.z; J[q][9] = ang.x; J[q][10] = ang.y; J[q][11] = ang.z;
-        }
-    }
+    };
+    float Jk[REBUILD ? 1 : 6][REBUILD ? 1 : NX];   // (one cube: the rows stay in registers)
+    auto with_rows = [&](auto &&fn) {
+        if constexpr (REBUILD) {
+            float J[6][NX];
+            build_rows(J);
+            fn(J);
+        } else fn(Jk);
+    };
+    if constexpr (!REBUILD) build_rows(Jk);
     float scale = fmaf((float)NC * cm, GRAV * GRAV, 1.f);
 #pragma unroll
     for (int j = 0; j < 6; j++) scale = fmaf(x0[j], x0[j], scale);
     const float tol2 = P.newton_tol * P.newton_tol * scale;
     float zs[6], jd[6];
+    with_rows([&](const float (&J)[6][NX]) {
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        float a = -aref[q];
+        for (int q = 0; q < 6; q++) {
+            float a = -aref[q];
 #pragma unroll
-        for (int i = 0; i < NX; i++) a = fmaf(J[q][i], x[i], a);
-        zs[q] = act ? a : 0.f;
-        jd[q] = 0.f;
-    }
-    float *shares = stage, *totals = stage + COOP_NB * COOP_RED;
+            for (int i = 0; i < NX; i++) a = fmaf(J[q][i], x[i], a);
+            zs[q] = act ? a : 0.f;
+            jd[q] = 0.f;
+        }
+    });
+    float *shares = stage, *totals = stage + (NB * COOP_CH > coop_stage_floats<NC>() ? NB * COOP_CH : coop_stage_floats<NC>());
     int its = 0;
     float dprev = 3.0e38f;
     for (int it = 0; it < P.newton_iters; it++) {
         float dx[NX], d0 = 0.f;
         {
-            // this block's share of the gradient and of the Hessian
+            // this block's share of the gradient and of the Hessian, chunk by chunk of 64 numbers: the shares [block][64] are written, column e is summed by lane e,
+            // the totals [RED] collect
             BlkEval<6> B;
             blk_eval<6>(zs, Rn, Rt, m2, act, B);
-            float Hl[NH], gl[NX];
+            with_rows([&](const float (&J)[6][NX]) {
+                float wv[NX], v[NX];   // J'WJ = av v v' - gam w w' + sum_t kap m2[t] row_t row_t',  w = sum_t c[t] row_t,  v = row_n - w
 #pragma unroll
-            for (int i = 0; i < NH; i++) Hl[i] = 0.f;
+                for (int i = 0; i < NX; i++) {
+                    float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < NX; i++) {
-                float a = 0.f;
+                    for (int q = 1; q < 6; q++) a = fmaf(B.c[q], J[q][i], a);
+                    wv[i] = a;
+                    v[i] = J[0][i] - a;
+                }
+                auto chunk = [&](auto ch_tag) {
+                    constexpr int CHI = decltype(ch_tag)::value;
+                    constexpr int V0 = CHI * COOP_CH, V1 = (CHI + 1) * COOP_CH < RED ? (CHI + 1) * COOP_CH : RED;     // values [V0, V1) of (gradient | packed Hessian)
+                    constexpr int E0 = V0 > NX ? V0 - NX : 0, E1 = V1 > NX ? V1 - NX : 0;                           // ... packed Hessian entries [E0, E1)
+                    float vals[COOP_CH];
 #pragma unroll
-                for (int q = 0; q < 6; q++) a = fmaf(-B.f[q], J[q][i], a);
-                gl[i] = a;
-            }
-            h_block<0, NX, NX, 6>(Hl, J, B, m2);
-            if (lane < COOP_NB) {
-                float *w = shares + lane * COOP_RED;
+                    for (int i = 0; i < COOP_CH; i++) vals[i] = 0.f;
+                    if constexpr (V0 < NX) {
 #pragma unroll
-                for (int i = 0; i < NX; i++) w[i] = gl[i];
+                        for (int i = V0; i < (V1 < NX ? V1 : NX); i++) {
+                            float a = 0.f;
 #pragma unroll
-                for (int i = 0; i < NH; i++) w[NX + i] = Hl[i];
-            }
-            // column sums: lane e sums entry e (and entry 64 + e) over the blocks
-            float t0 = 0.f, t1 = 0.f;
+                            for (int q = 0; q < 6; q++) a = fmaf(-B.f[q], J[q][i], a);
+                            vals[i - V0] = a;
+                        }
+                    }
+                    if constexpr (E1 > E0) {
+                        float Hl[E1 - E0];
 #pragma unroll
-            for (int k = 0; k < COOP_NB; k++) {
-                t0 += shares[k * COOP_RED + lane];
-                t1 += lane < COOP_RED - 64 ? shares[k * COOP_RED + 64 + lane] : 0.f;
-            }
-            totals[lane] = t0;
-            if (lane < COOP_RED - 64) totals[64 + lane] = t1;
+                        for (int i = 0; i < E1 - E0; i++) Hl[i] = 0.f;
+                        h_rank1_part<NX, E0, E1>(Hl, v, B.av);
+                        h_rank1_part<NX, E0, E1>(Hl, wv, -B.gam);
+#pragma unroll
+                        for (int q = 1; q < 6; q++) h_rank1_part<NX, E0, E1>(Hl, J[q], B.kap * m2[q]);
+#pragma unroll
+                        for (int i = 0; i < E1 - E0; i++) vals[E0 + NX - V0 + i] = Hl[i];
+                    }
+                    if (lane < NB) {
+                        float4v *w = reinterpret_cast<float4v *>(shares + lane * COOP_CH);
+#pragma unroll
+                        for (int i = 0; i < COOP_CH / 4; i++) w[i] = float4v{vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]};
+                    }
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NB; k++) t += shares[k * COOP_CH + lane];
+                    totals[CHI * COOP_CH + lane] = t;
+                };
+                chunk(std::integral_constant<int, 0>{});
+                chunk(std::integral_constant<int, 1>{});
+                if constexpr (NCH > 2) chunk(std::integral_constant<int, 2>{});
+            });
             float Hm[NH], g[NX], hid[NX];
 #pragma unroll
             for (int i = 0; i < NX; i++) g[i] = fmaf(mdiag(i), x[i] - x0[i], totals[i]);
@@ -249,13 +343,15 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
         dprev = -d0;
         if (!live) break;
         its++;
+        with_rows([&](const float (&J)[6][NX]) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            float a = 0.f;
+            for (int q = 0; q < 6; q++) {
+                float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < NX; i++) a = fmaf(J[q][i], dx[i], a);
-            jd[q] = act ? a : 0.f;
-        }
+                for (int i = 0; i < NX; i++) a = fmaf(J[q][i], dx[i], a);
+                jd[q] = act ? a : 0.f;
+            }
+        });
         // the line search of newton_solve with this block's share of phi' / phi'' summed over the wave
         float q1 = 0.f, q0 = 0.f;
 #pragma unroll
@@ -286,10 +382,10 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
             const float iqa = rcp(fmaxf(qa, 1e-30f));
             const float am = -qb * iqa;
             const float n2 = fmaxf(fmaf(-qb * qb, iqa, qc), 0.f), wn = fmaf(am, jd[0], zs[0]);
-            const bool ok = act && lane < 9 && qa > 0.f && am > lo && am < hi && wn < 0.f && !(n2 * Rn * Rn > wn * wn * Rt * Rt);
+            const bool ok = act && lane < NB - 6 && qa > 0.f && am > lo && am < hi && wn < 0.f && !(n2 * Rn * Rn > wn * wn * Rt * Rt);
             const float dist = fabsf(am - sec);
             float best = sec, bestd = -1.f;
-            for (int k = 0; k < 9; k++) {
+            for (int k = 0; k < NB - 6; k++) {
                 const bool okk = __builtin_amdgcn_readlane((int)ok, k) != 0;
                 const float amk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(am), k)), dk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dist), k));
                 const bool take = okk && (bestd < 0.f || dk < bestd);
@@ -344,7 +440,7 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
     {
         BlkEval<6> B;
         blk_eval<6>(zs, Rn, Rt, m2, act, B);
-        if (lane < COOP_NB) {
+        if (lane < NB) {
 #pragma unroll
             for (int q = 0; q < 6; q++) stage[lane * 8 + q] = B.f[q];
         }
@@ -354,14 +450,25 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
 #pragma unroll
                 for (int q = 0; q < (s < 4 ? 6 : 4); q++) C.AS[s].f[q] = stage[s * 8 + q];
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int c = 0; c < NC; c++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) C.FS[0][s].f[q] = stage[(5 + s) * 8 + q];
+                for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) C.flim[j] = stage[(9 + j) * 8];
+                    for (int q = 0; q < 4; q++) C.FS[c][s].f[q] = stage[(5 + 4 * c + s) * 8 + q];
+            if constexpr (NC == 2) {
+                if (C.cc_any) {
+#pragma unroll
+                    for (int s = 0; s < NCC; s++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC + 3 + q) * 64] = stage[(13 + s) * 8 + q];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) C.flim[j] = stage[(NB - 6 + j) * 8];
 #pragma unroll
             for (int j = 0; j < 6; j++) y[j] = x[j];
-            ca[0] = mk(x[6], x[7], x[8]); cal[0] = mk(x[9], x[10], x[11]);
+#pragma unroll
+            for (int c = 0; c < NC; c++) { ca[c] = mk(x[6 + 6 * c], x[7 + 6 * c], x[8 + 6 * c]); cal[c] = mk(x[9 + 6 * c], x[10 + 6 * c], x[11 + 6 * c]); }
         }
     }
     C.wave_its += its;

@@ -336,35 +336,6 @@ struct Warm {
     bool cc_prev[8];   // (slots 4-7: the eight-point manifold of the Newton kernels)
 };
 
-// The same record kept in MEMORY (one-cube Newton kernels): the 52 carried forces are read where a substep's set-up needs them and written back at its end
-// ([WARM_*][N] floats, L2-resident, coalesced) instead of occupying 52 registers through every solve.  `mem` = LcrDev::warm_mem + env; `zero`: nothing is carried into
-// this substep (first substep of a control step under LCR_COMPAT_COLD_SOLVE_EACH_STEP); tail lanes (`valid` false) shadow the last env and do not write.
-// (buffer instructions: the row offset idx * N travels in an SGPR and the lane's 4 * env in ONE VGPR -- plain global loads made the compiler hold a 64-bit address per row)
-struct WarmMem {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int voff;     // 4 * env
-    unsigned row;  // 4 * N
-    bool zero, valid;
-    DEV float ld(int idx) const {
-        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(row * (unsigned)idx), 0));
-        return zero ? 0.f : v;
-    }
-    DEV void st(int idx, float v) const { if (valid) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, voff, (int)(row * (unsigned)idx), 0); }
-};
-// accessors shared by both representations
-template <int NC, int NRW> DEV float w_floor(const Warm<NC, NRW> &W, int c, int s, int k) { return W.floor[c][s][k]; }
-template <int NC, int NRW> DEV float w_arm(const Warm<NC, NRW> &W, int s, int r) { return W.arm[s][r]; }
-template <int NC, int NRW> DEV float w_lim(const Warm<NC, NRW> &W, int j) { return W.lim[j]; }
-template <int NC, int NRW> DEV void w_set_floor(Warm<NC, NRW> &W, int c, int s, int k, float v) { W.floor[c][s][k] = v; }
-template <int NC, int NRW> DEV void w_set_arm(Warm<NC, NRW> &W, int s, int r, float v) { W.arm[s][r] = v; }
-template <int NC, int NRW> DEV void w_set_lim(Warm<NC, NRW> &W, int j, float v) { W.lim[j] = v; }
-DEV float w_floor(const WarmMem &W, int c, int s, int k) { return W.ld(16 * c + 4 * s + k); }      // WARM_FLOOR = 0
-DEV float w_arm(const WarmMem &W, int s, int r) { return W.ld(32 + 6 * s + r); }                 // WARM_ARM = 32
-DEV float w_lim(const WarmMem &W, int j) { return W.ld(62 + j); }                                // WARM_LIM = 62
-DEV void w_set_floor(WarmMem &W, int c, int s, int k, float v) { W.st(16 * c + 4 * s + k, v); }
-DEV void w_set_arm(WarmMem &W, int s, int r, float v) { W.st(32 + 6 * s + r, v); }
-DEV void w_set_lim(WarmMem &W, int j, float v) { W.st(62 + j, v); }
-
 constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
 constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 20 rows -> 30 KiB per wave (4 waves per CU: 120 of 160 KiB)
 // Stack only: cube<->cube contact records, 4 slots x 16 floats per lane: pos3 f4 aref4 inv4 Rn (LDS, see LdsSize)

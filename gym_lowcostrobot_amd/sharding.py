@@ -62,6 +62,8 @@ class ShardedVecSim:
             raise ValueError("n_envs_total must be divisible by the number of shards")
         self.per = n_envs_total // len(devices)
         self.n = n_envs_total
+        # every shard declares the whole job (lcr_config.global_envs): the same kernel family on every shard, and lcr_create checks that the cut is at wave boundaries
+        kw.setdefault("global_envs", n_envs_total)
         self.shards = [VecSim(task, self.per, device=d, env_id_offset=shard_offset(self.per, i), **kw) for i, d in enumerate(devices)]
         self.action_dim = self.shards[0].action_dim
         self._act = [s.alloc_actions() for s in self.shards]

@@ -95,10 +95,11 @@ typedef struct lcr_config {
                                   which it also selects; 3: phases of the two-wave kernels).  Anything else: LCR_ERR_INVALID */
     int32_t finger_cube_condim; /* rows of a finger<->cube contact.  6 = MuJoCo's: normal, two tangents, torsion, two rolling (follower.xml:15
                                   condim="6" wins the max rule over the cube's 4; rolling coefficient = max of both geoms).  4 = without the
-                                  rolling rows (8-12 % faster).  lcr_config_default: 6 for PushCubeLoop (coefficient 1.5 m) and
-                                  StackTwoCubes (light cubes), 4 for the other tasks (effect below the parity tolerance: deviation D4,
-                                  DESIGN.md).  0 = the task's default */
-    int32_t step_kernel;       /* which step-kernel family runs lcr_step: 0 = by task and JOB size (global_envs below, never the shard size n_envs): two
+                                  rolling rows (sweep kernels only, 8-12 % faster there).  lcr_config_default (= LCR_PRESET_FAITHFUL): 6 on every task,
+                                  4 is LCR_ERR_UNSUPPORTED under LCR_SOLVER_NEWTON.  LCR_PRESET_FAST: 6 for PushCubeLoop (coefficient 1.5 m) and
+                                  StackTwoCubes (light cubes), 4 for the other tasks (deviation D4).  0 = the preset's default */
+    int32_t step_kernel;       /* LCR_SOLVER_PGS (LCR_PRESET_FAST) only -- the Newton kernels of the default preset are ONE family (one wave per 64 envs; 2 is
+                                  LCR_ERR_UNSUPPORTED with them).  Which step-kernel family runs lcr_step: 0 = by task and JOB size (global_envs below, never the shard size n_envs): two
                                   cooperating waves per 64 envs for ReachCube / LiftCube / PushCube / PickPlaceCube at every size and for StackTwoCubes
                                   jobs of <= 32 envs per SIMD of the device (MI355X: 32 768 envs), one wave per 64 envs for larger Stack jobs -- the faster family when the job runs as ONE shard
                                   on an MI355X; 1 = one wave per 64 envs always; 2 = two cooperating waves always (the faster family on shards of
@@ -108,15 +109,20 @@ typedef struct lcr_config {
                                   results are bit-identical for every sharding.  Because 0 looks at the job and not at the shard, every sharding of a
                                   job whose shards declare the same global_envs runs the same family and gives identical bits; which
                                   build of the family a shard runs (one / two waves per SIMD, rows in LDS / global scratch) does follow its size and
-                                  does not change a bit. */
+                                  does not change a bit.  The Stack family boundary is counted in SIMDs of the device the handle lives on: a job replayed on
+                                  another part may pick the other family (fp32 rounding apart, not bit for bit). */
     int32_t cc_points;         /* StackTwoCubes: cube<->cube manifold points kept per substep.  4 (default, 0 = default): the extremes along the diagonals
                                   of the reference face; 8: also the extremes along its two axes -- as many points as MuJoCo's box-box
                                   collider may return (stack_two_cubes.xml:25-35; narrows deviation D5).  8 runs on the
                                   two-cooperating-waves kernels (step_kernel = 1 with it: LCR_ERR_UNSUPPORTED); other tasks: LCR_ERR_INVALID */
     int64_t global_envs;       /* ABI v4: number of envs of the whole JOB this handle is one shard of (all GPUs together); 0 = n_envs (the handle is
-                                  the job).  Must be >= env_id_offset + n_envs.  Only the step_kernel = 0 dispatch reads it (see there): the reference
-                                  has one independent MjData per env (reach_cube_env.py:89-90), so how a batch is cut into shards must not show in
-                                  the results */
+                                  the job).  Must be >= env_id_offset + n_envs.  The reference has one independent MjData per env
+                                  (reach_cube_env.py:89-90), so how a batch is cut into shards must not show in the results: every sharding of a job
+                                  gives identical bits PROVIDED the shards are cut at wave boundaries -- a wave (64 consecutive env ids) skips work no
+                                  lane needs, solves its coupled envs cooperatively and leaves the solver loops for all its lanes at once, so an env's
+                                  low-order bits depend on its 63 wave-mates.  lcr_create therefore refuses (LCR_ERR_INVALID) a handle whose
+                                  env_id_offset is not a multiple of 64 and a shard that, not being the job's last (env_id_offset + n_envs <
+                                  global_envs), does not hold a multiple of 64 envs.  The step_kernel = 0 dispatch reads global_envs as well (see there) */
     /* ABI v5 (round 5): the solver of the constraint problem and the rows of a finger<->floor contact.  See lcr_config_preset. */
     int32_t solver;            /* lcr_solver.  LCR_SOLVER_NEWTON: Newton's method on the primal problem, all accelerations at once, warm-started from the carried
                                   constraint forces -- MuJoCo's default solver (follower.xml:3 names none); reaches the optimum of MuJoCo's convex constraint problem to
@@ -133,8 +139,12 @@ typedef struct lcr_config {
 typedef enum lcr_solver { LCR_SOLVER_PGS = 0, LCR_SOLVER_NEWTON = 1 } lcr_solver;
 /* LCR_PRESET_FAITHFUL (what lcr_config_default fills in): the reference's contact model as its MJCF states it -- six-row finger contacts against cube AND floor
  * (follower.xml:15), up to eight box-box points (stack_two_cubes.xml:25-35), elliptic cones -- solved by Newton's method (follower.xml:3).
+ * What remains approximate under it: finger pads are boxes fitted to the hull tips and the other arm hulls five sphere proxies (deviation D3), each finger has one
+ * world contact (floor or rail), Newton is capped at newton_iters = 30 iterations per substep, fp32 arithmetic.
  * LCR_PRESET_FAST: the rounds 1-4 configuration -- four block projected-gradient sweeps, rolling rows only where they change a step by more than the fp32
- * parity tolerance, four box-box points -- about 4 x the throughput at p90 2e-4 / p99 1e-2 rad per control step from the optimum. */
+ * parity tolerance, four box-box points -- 8 x (ReachCube) to 35 x (StackTwoCubes) the throughput of the default (measured per task: profiles/r06_quick_times.txt)
+ * at p90 2e-4 / p99 1e-2 rad per control step from the optimum.  Options of the sweep kernels (step_kernel = 2, pgs_iters < 0,
+ * diagnostics = 3, finger_cube_condim = 4) are refused under LCR_SOLVER_NEWTON: set them on a config filled by lcr_config_preset(.., LCR_PRESET_FAST). */
 typedef enum lcr_preset { LCR_PRESET_FAITHFUL = 0, LCR_PRESET_FAST = 1 } lcr_preset;
 
 typedef struct lcr_sim lcr_sim;

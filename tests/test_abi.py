@@ -99,6 +99,10 @@ def test_invalid_arguments_are_reported_not_thrown(hip_lib):
         ("push", dict(diagnostics=-1), _capi.LCR_ERR_INVALID, b"diagnostics must be"),
         ("push", dict(global_envs=-5), _capi.LCR_ERR_INVALID, b"global_envs"),
         ("push", dict(n_envs=64, env_id_offset=100, global_envs=128), _capi.LCR_ERR_INVALID, b"does not lie inside the job"),
+        # shards are cut at wave boundaries (64 consecutive env ids): a wave's shortcuts are taken for all its lanes at once, so an env's bits depend on its wave-mates
+        ("push", dict(n_envs=64, env_id_offset=32, global_envs=128), _capi.LCR_ERR_INVALID, b"wave boundaries"),
+        ("push", dict(n_envs=64, env_id_offset=100), _capi.LCR_ERR_INVALID, b"wave boundaries"),
+        ("push", dict(n_envs=100, env_id_offset=0, global_envs=256), _capi.LCR_ERR_INVALID, b"wave boundaries"),
         # the Newton kernels (faithful preset) carry six-row finger contacts and are one-wave kernels; six-row finger<->floor contacts exist only there
         ("push", dict(solver=1, finger_cube_condim=4), _capi.LCR_ERR_UNSUPPORTED, b"six-row finger contacts"),
         ("push", dict(solver=1, finger_cube_condim=6, finger_floor_condim=6, step_kernel=2), _capi.LCR_ERR_UNSUPPORTED, b"one-wave kernels"),
