@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcr_hip.so")
 SOURCES = ["lcr_capi.hip", "lcr_kernels.hip", "lcr_kernels2.hip", "lcr_render.hip"]   # (bench.kernel_sha16 and the tools hash / compile these)
-HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", "lcr_step_common.h", "lcr_newton.h", os.path.join("..", "..", "include", "lcr.h")]
+HEADERS = ["lcr_device.h", "lcr_arm.h", "lcr_model_gen.h", "lcr_step_common.h", "lcr_newton.h", "lcr_newton_coop.h", os.path.join("..", "..", "include", "lcr.h")]
 # -ffast-math: the kernels carry no NaN/inf/signed-zero semantics (the -0.0 sparse reward is built from its bit pattern,
 # the fp64 reset sampling uses explicitly rounded __dmul_rn/__dadd_rn); -fno-slp-vectorize: packed-f32 formation by the
 # SLP vectoriser costs more moves than it saves here (measured on MI355X: 0.340 ms -> 0.286 ms per 65 536-env step).

@@ -38,6 +38,11 @@ template <int NC> constexpr int coop_floats() {
     return (coop_nb<NC>() * COOP_CH > coop_stage_floats<NC>() ? coop_nb<NC>() * COOP_CH : coop_stage_floats<NC>()) + coop_chunks<NC>() * COOP_CH;
 }
 
+// LDS stores complete before the loads that follow.  Needed, not belt and braces: the column sums of a chunk are ds_read2st64 loads issued right behind the sixteen
+// ds_write_b128 of the shares, and the compiler lets them return into the registers those stores send (profiles/r06_lds_store_hazard.txt: lanes 15-25 of the second
+// chunk read wrong sums on the MI355X until the stores were waited for -- the solve then diverged by radians)
+DEV void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // sum over the 64 lanes, the same value in every lane (DPP row reductions, then the two row broadcasts of GFX9; the total arrives in lane 63)
 DEV float wave_sum(float v) {
     auto dpp = [](float x, auto ctrl_tag, auto rmask_tag) -> float {
@@ -144,9 +149,11 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const
 template <int NC, int NRW, int NCC>
 DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, int L, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC]) {
     constexpr int NX = coop_nx<NC>(), NH = NX * (NX + 1) / 2, NB = coop_nb<NC>(), RED = coop_red<NC>(), NCH = coop_chunks<NC>();
-    constexpr bool REBUILD = NC == 2;   // the rows are rebuilt where they are used instead of living next to the 171-entry Hessian
+    constexpr bool REBUILD = NC == 2;
+    // the rows are rebuilt where they are used instead of living next to the 171-entry Hessian
     const NewtonParams &P = C.P;
     if (lane == L) coop_stage<NC, NRW, NCC>(C, stage, y, ca, cal);
+    lds_fence();
     // ---- every lane: its block's record, the shared vectors ----
     const int b = lane < NB ? lane : NB - 1;   // (the other lanes shadow the last block with act = false)
     const float *r = stage + b * COOP_REC;
@@ -309,14 +316,18 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
                         for (int i = 0; i < E1 - E0; i++) vals[E0 + NX - V0 + i] = Hl[i];
                     }
                     if (lane < NB) {
-                        float4v *w = reinterpret_cast<float4v *>(shares + lane * COOP_CH);
+                        // (plain float stores, which the compiler merges into wide LDS writes itself: stores through a float4 lvalue are, to its alias analysis, unrelated
+                        //  to the float loads of the staging records and of the column sums -- it moved those loads across them, and the solve read clobbered records)
+                        float *w = shares + lane * COOP_CH;
 #pragma unroll
-                        for (int i = 0; i < COOP_CH / 4; i++) w[i] = float4v{vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]};
+                        for (int i = 0; i < COOP_CH; i++) w[i] = vals[i];
                     }
+                    lds_fence();
                     float t = 0.f;
 #pragma unroll
                     for (int k = 0; k < NB; k++) t += shares[k * COOP_CH + lane];
                     totals[CHI * COOP_CH + lane] = t;
+                    lds_fence();
                 };
                 chunk(std::integral_constant<int, 0>{});
                 chunk(std::integral_constant<int, 1>{});
@@ -444,6 +455,7 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
 #pragma unroll
             for (int q = 0; q < 6; q++) stage[lane * 8 + q] = B.f[q];
         }
+        lds_fence();
         if (lane == L) {
 #pragma unroll
             for (int s = 0; s < NAS; s++)
