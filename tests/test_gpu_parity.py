@@ -1032,8 +1032,8 @@ def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, mo
     import torch
     from gym_lowcostrobot_amd import VecSim
 
-    if kernel_family != "auto":
-        pytest.skip("the default dispatch is what is tested")
+    if kernel_family == "single":
+        pytest.skip("the default dispatch is what is tested")   # (faithful: the shipped default -- one family, the Newton kernels; auto: preset fast's dispatch by job size)
     monkeypatch.delenv("LCR_STEP_KERNEL", raising=False)
     simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     fit = simds // 2 * 64                                  # largest shard with one wave per SIMD
@@ -1069,7 +1069,9 @@ def test_default_dispatch_of_the_step_kernel_families(hip_lib, kernel_family, mo
 def test_shard_invariance_under_the_default_dispatch(hip_lib, kernel_family, monkeypatch, task, mode, shards, M, steps):
     """SURVEY.md 8(e) with lcr_config.step_kernel left at 0: one sim of shards x M envs == `shards` sims of M envs that declare the job size
     (global_envs), bit for bit -- PickPlace 131 072 vs 4 x 32 768 (BASELINE config 4's shape), Stack 65 536 vs 2 x 32 768 (across auto-resets),
-    Reach 65 536 vs 2 x 32 768 (two-wave family: the builds for two / one wave per SIMD), and a small job (two-wave family on every shard)."""
+    Reach 65 536 vs 2 x 32 768 (two-wave family: the builds for two / one wave per SIMD), and a small job (two-wave family on every shard).  Under the faithful
+    preset (what lcr_config_default ships) the same shapes run the Newton kernels: a wave's cooperative solves and exits depend only on its own 64 envs, and shards
+    are cut at wave boundaries (lcr_create refuses others: tests/test_abi.py)."""
     from gym_lowcostrobot_amd import VecSim
 
     if kernel_family != "auto":
@@ -1093,6 +1095,33 @@ def test_shard_invariance_under_the_default_dispatch(hip_lib, kernel_family, mon
     np.testing.assert_array_equal(whole.reward.numpy(), np.concatenate([p.reward.numpy() for p in parts]))
     assert np.isfinite(sw["qpos"]).all()
     for s_ in [whole] + parts:
+        s_.close()
+
+
+@pytest.mark.parametrize("task,mode", [("reach", "joint"), ("push", "joint"), ("pick_place", "ee"), ("stack", "joint"), ("push_loop", "joint")])
+def test_newton_kernels_are_deterministic(hip_lib, kernel_family, task, mode):
+    """The kernels of the shipped default (Newton on the primal; the coupled envs of a wave solved cooperatively, sums through LDS and DPP -- no atomics anywhere): two
+    runs of the same job are bit-identical across auto-resets, state, carried forces and outputs (the determinism tests above cover the sweep kernels only)."""
+    from gym_lowcostrobot_amd import VecSim
+
+    if kernel_family != "faithful":
+        pytest.skip("the Newton kernels are the faithful preset's")
+    n, steps = 4096, 60
+    sims = [VecSim(task, n, observation_mode="state", action_mode=mode, base_seed=5) for _ in range(2)]
+    acts = [s_.alloc_actions() for s_ in sims]
+    rewards = [[], []]
+    for t in range(steps):
+        for i, (s_, a) in enumerate(zip(sims, acts)):
+            s_.fill_random_actions(a, 3, t); s_.step_device(a.ptr)
+            if t % 20 == 19:
+                rewards[i].append(s_.reward.numpy().copy())
+    st = [s_.get_state() for s_ in sims]
+    for k in ("qpos", "qvel", "elapsed", "rng", "ee_lag", "warm"):
+        np.testing.assert_array_equal(st[0][k], st[1][k], err_msg=k)
+    for a, b in zip(*rewards):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(st[0]["qpos"]).all()
+    for s_ in sims:
         s_.close()
 
 
