@@ -265,6 +265,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 #pragma unroll
     for (int s = 0; s < NCC; s++) cc_act[s] = false;
     bool cc_any = false;
+    const bool real_lane = (int)(blockIdx.x * 64 + lane) < P.n;   // (the tail lanes of a ragged batch shadow the last env and store nothing: they are nobody's patient)
+    int cc_count = 0;       // (Stack) cube<->cube points of this lane
     bool coupled = false;   // (NEWTON) bodies of this lane's env touch -- its arm a cube, cube on cube --: they are ONE problem
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
     float *ccl = lds + CCB * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
@@ -383,7 +385,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             }
         }
         cc_any = __any(cnt > 0) != 0;
-        coupled = cnt > 0;
+        coupled = cnt > 0 && real_lane;
+        cc_count = cnt;
         if (cc_any) {
             make_frame(ccn, cct1, cct2);
 #pragma unroll
@@ -533,7 +536,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             invw_link = bi < 2 ? INVW_TRAN_L3 : (bi == 2 ? INVW_TRAN_L4 : (bi == 3 ? INVW_TRAN_L5 : INVW_TRAN_L6));
         }
         T.act = dist < 0.f;
-        if (may_cube) coupled = coupled || (T.act && (s < 2 || oncube));
+        if (may_cube) coupled = coupled || (T.act && (s < 2 || oncube) && real_lane);
         if constexpr (CPL == CPL_FAST) {   // more lanes with a finger or a gripper-body proxy on their cube than are solved one by one: this substep belongs to the other copy
             if (may_cube && __popcll(__ballot(coupled)) > P.coop_max) {
 #pragma unroll
@@ -772,7 +775,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             else if (CPL == CPL_BOTH && arm_on_cube) sweeps_done = newton_solve<NC, NRW, false, NCC, 3>(C, y, ca, cal);
             else {
                 // the lanes whose arm touches their cube sit out the two small solves and are then solved one by one by the whole wave (lcr_newton_coop.h)
-                C.enable = CPL == CPL_BOTH || !coupled;
+                C.enable = (CPL == CPL_BOTH || !coupled) ? 7 : 0;
                 const int ia = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal);
                 const int ic = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
                 sweeps_done = max(ia, ic);
@@ -800,17 +803,23 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             const unsigned long long cmask = __ballot(coupled);
             coupled_any = __popcll(cmask) > P.coop_max;
             if constexpr (CPL == CPL_FAST) {
-                // the envs with touching bodies sit out the three small solves and are then solved one by one by the whole wave (lcr_newton_coop.h: all 18 unknowns)
-                C.enable = !coupled;
+                // the bodies of an env that touch sit out the three small solves and are then solved by the whole wave (lcr_newton_coop.h), one env after the other: the
+                // arm and ONE cube (12 unknowns; the other cube keeps its small solve) where the arm on that cube is the env's only coupling -- nine patients of ten under
+                // random actions --, all three bodies (18 unknowns) otherwise
+                const bool pair0 = on0 && !on1 && !(cc_any && cc_count > 0), pair1 = on1 && !on0 && !(cc_any && cc_count > 0);
+                C.enable = !coupled ? 7 : (pair0 ? 4 : (pair1 ? 2 : 0));
                 i1 = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
                 i3 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal);
                 float *stage = lds + NEWTON_G_ROWS * LDS_ROW + 8 * CC_REC * 64;
                 const long long tc0 = P.diag == 2 ? clock64() : 0;
                 prof_patients = __popcll(cmask);
+                const unsigned long long m0 = __ballot(pair0), m1 = __ballot(pair1);
                 for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
                     const int L = __builtin_ctzll(m);
-                    const int ip = coop_solve<NC, NRW, NCC>(C, stage, lane, L, y, ca, cal);
-                    i1 = lane == L ? ip : i1;
+                    int ip;
+                    if ((m0 | m1) >> L & 1ull) ip = coop_solve<NC, NRW, NCC, 1>(C, stage, lane, L, y, ca, cal, (int)(m1 >> L & 1ull));
+                    else ip = coop_solve<NC, NRW, NCC, 2>(C, stage, lane, L, y, ca, cal);
+                    i1 = lane == L ? max(ip, i1) : i1;
                 }
                 if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);
             } else

@@ -21,6 +21,7 @@
 //   reset                     envs/push_cube_loop_env.py:299-317
 #include "lcr_step_common.h"
 #include "lcr_newton.h"
+#include "lcr_newton_coop.h"
 
 namespace {
 
@@ -28,16 +29,26 @@ namespace {
 // one physics substep (== mujoco.mj_step, reach_cube_env.py:277)
 // ------------------------------------------------------------------------------------------------
 // NEWTON (the faithful preset): six-row finger contacts against cube AND floor, the constraint problem solved by Newton's method on the primal (lcr_newton.h)
-template <int NC, bool WALLS, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
-DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
+// CPL: the two copies of the Newton substep, as in lcr_kernels.hip -- CPL_FAST: arm and cube as two 6-dimensional SIMT problems, the envs whose arm touches the cube solved
+// one by one by the whole wave (lcr_newton_coop.h); with more than LcrDev::coop_max of them it returns false, the state untouched, and CPL_SLOW runs the substep with
+// the coupled 12-dimensional SIMT solve (it returns whether the wave still has that many).  CPL_BOTH: the sweep kernels.
+constexpr int CPL_BOTH = 0, CPL_FAST = 1, CPL_SLOW = 2;
+template <int NC, bool WALLS, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false, int CPL = CPL_BOTH>
+DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
     static_assert(!NEWTON || (ROLL && NC == 1 && !ADAPT), "the Newton kernels carry six-row finger slots");
+    static_assert(CPL == CPL_BOTH || NEWTON, "two copies of the substep: the Newton kernels");
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
     // ---- position stage -------------------------------------------------------------------------
     CubeRot CR[NC];
+    float cq_in[NC][4];   // (CPL_FAST) the quaternion as it came in: a bail-out leaves the state as it found it
+    const bool real_lane = (int)(blockIdx.x * 64 + lane) < P.n;   // (the tail lanes of a ragged batch shadow the last env and store nothing: they are nobody's patient)
+    bool coupled = false;   // (NEWTON) this lane's arm touches its cube: arm and cube are ONE problem
 #pragma unroll
     for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cq_in[c][k] = S.cq[c][k];
         float n2 = S.cq[c][0] * S.cq[c][0] + S.cq[c][1] * S.cq[c][1] + S.cq[c][2] * S.cq[c][2] + S.cq[c][3] * S.cq[c][3];
         float in = rsq(n2);
 #pragma unroll
@@ -598,6 +609,16 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             invw_link = bi < 2 ? INVW_TRAN_L3 : (bi == 2 ? INVW_TRAN_L4 : (bi == 3 ? INVW_TRAN_L5 : INVW_TRAN_L6));
         }
         T.act = dist < 0.f;
+        if (may_cube) coupled = coupled || (T.act && (s < 2 || oncube) && real_lane);
+        if constexpr (CPL == CPL_FAST) {
+            if (may_cube && __popcll(__ballot(coupled)) > P.coop_max) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) S.cq[c][k] = cq_in[c][k];
+                return false;
+            }
+        }
         if (P.diag) {
             if (may_cube && (s < 2 || oncube)) sel += (n.y < 0.5f && n.y > -0.5f) ? 0 : ((NEWTON && s < 2) ? 2 : 16);   // branch of make_frame (pad boxes: sel = cube + 2 branch + 4 code)
             diag_choice(DG, T.act, 12 + s, sel);
@@ -787,6 +808,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     //      of the wave, at most 50 sweeps ----
     const int max_it = NEWTON ? 0 : (ADAPT ? 50 : P.pgs_iters);
     int sweeps_done = 0;
+    bool coupled_many = false;   // (NEWTON) more lanes of the wave have the arm on the cube than are solved cooperatively
     if constexpr (NEWTON) {
         // ---- Newton on the primal (lcr_newton.h; oracle: newton_product); the cube's problem carries the rails' rows ----
         const int row0[NAS] = {arm_row0_of<ROLL, NC, BIG, NEWTON>(0), arm_row0_of<ROLL, NC, BIG, NEWTON>(1), arm_row0_of<ROLL, NC, BIG, NEWTON>(2),
@@ -794,12 +816,21 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         const NewtonParams NP = newton_params(P);
         NewtonCtx<NC, NRW, WALLS, 4> C{NP, lds, lane, row0, AS, slot_any, link_on_cube, slot_cube, FS, WS, wsg, wall_any,
                                        ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
-        const bool arm_on_cube = slot_any[0] || slot_any[1] || (__any(AS[4].act && link_on_cube) != 0);
-        if (arm_on_cube) sweeps_done = newton_solve<NC, NRW, WALLS, 4, 3>(C, y, ca, cal);
+        const unsigned long long cmask = __ballot(coupled);
+        coupled_many = __popcll(cmask) > P.coop_max;
+        if constexpr (CPL == CPL_SLOW) sweeps_done = newton_solve<NC, NRW, WALLS, 4, 3>(C, y, ca, cal);   // (uncoupled lanes: the same optimum, block-diagonal Hessian)
         else {
+            // the lanes whose arm touches their cube sit out the two small solves and are then solved one by one by the whole wave (lcr_newton_coop.h)
+            C.enable = coupled ? 0 : 7;
             const int ia = newton_solve<NC, NRW, WALLS, 4, 1>(C, y, ca, cal);
             const int ic = newton_solve<NC, NRW, WALLS, 4, 2>(C, y, ca, cal);
             sweeps_done = max(ia, ic);
+            float *stage = lds + NEWTON_G_ROWS * LDS_ROW;
+            for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
+                const int L = __builtin_ctzll(m);
+                const int ip = coop_solve<NC, NRW, 4, NC, WALLS>(C, stage, lane, L, y, ca, cal);
+                sweeps_done = lane == L ? ip : sweeps_done;
+            }
         }
     }
     for (int it = 0; it < max_it; it++) {
@@ -1207,6 +1238,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             S.cq[c][0] = r0 * in; S.cq[c][1] = r1 * in; S.cq[c][2] = r2 * in; S.cq[c][3] = r3 * in;
         }
     }
+    return CPL == CPL_SLOW ? coupled_many : true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1214,7 +1246,7 @@ DEV void substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool WALLS, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW : LdsSize<NC, WALLS, ROLL, BIG>::value];
+    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + coop_floats<NC, WALLS>() : LdsSize<NC, WALLS, ROLL, BIG>::value];
     const int lane = threadIdx.x;
     const int e_raw = blockIdx.x * 64 + lane;
     const bool valid = e_raw < P.n;
@@ -1337,7 +1369,15 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         }
     }
     Diag DG = {0u, 0u, 0u, 0u};
-    for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    if constexpr (NEWTON) {
+        bool slow = false;   // wave-uniform: the substep's two copies (CPL above)
+        for (int s = 0; s < P.n_substeps; s++) {
+            if (!slow) slow = !substep<NC, WALLS, ADAPT, ROLL, BIG, NEWTON, CPL_FAST>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+            if (slow) slow = substep<NC, WALLS, ADAPT, ROLL, BIG, NEWTON, CPL_SLOW>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+        }
+    } else {
+        for (int s = 0; s < P.n_substeps; s++) substep<NC, WALLS, ADAPT, ROLL, BIG, NEWTON>(P, S, ctrl, lds, lane, e, lag_ee, lag_cube, W, DG, s);
+    }
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
         P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;

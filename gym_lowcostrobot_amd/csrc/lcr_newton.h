@@ -176,7 +176,8 @@ struct NewtonCtx {
     float (&flim)[6];
     const float (&y0s)[6];
     int wave_its = 0;            // iterations this wave has executed in its solves of the substep (profiling aid, lcr_config.diagnostics = 2)
-    bool enable = true;          // false: this lane's env is solved elsewhere (lcr_newton_coop.h) -- it never counts as live here and its accelerations stay as they are
+    int enable = 7;              // bit b clear: body b (0 arm, 1 cube 0, 2 cube 1) of this lane's env is solved elsewhere (lcr_newton_coop.h) -- a solve over bodies that are not all enabled
+                                 // never counts the lane as live and leaves its accelerations as they are
 };
 
 template <int MASK> constexpr int nw_off(int body) {   // first compact index of a body of MASK
@@ -709,7 +710,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         float dist2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++) dist2 = fmaf(mdiag(i) * (x[i] - x0[i]), x[i] - x0[i], dist2);
-        const bool live = C.enable && -d0 > tol2 && !(-d0 <= DEC_FLOOR * dist2 && -d0 >= 0.25f * dprev);
+        const bool live = (C.enable & MASK) == MASK && -d0 > tol2 && !(-d0 <= DEC_FLOOR * dist2 && -d0 >= 0.25f * dprev);
         dprev = -d0;
         if (!__any(live)) break;
         lane_its += live ? 1 : 0;

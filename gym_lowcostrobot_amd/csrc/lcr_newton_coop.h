@@ -26,16 +26,16 @@
 
 namespace {
 
-template <int NC> constexpr int coop_nb() { return 5 + 4 * NC + (NC == 2 ? 8 : 0) + 6; }   // blocks of one patient: 15 / 27
+template <int NC, bool WALLS = false> constexpr int coop_nb() { return 5 + 4 * NC + (NC == 2 ? 8 : 0) + (WALLS ? 4 : 0) + 6; }   // blocks of one patient: 15 / 27 (PushCubeLoop, its four rails: 19)
 template <int NC> constexpr int coop_nx() { return 6 + 6 * NC; }
 constexpr int COOP_REC = 32;                     // floats of a block record in the staging area
 constexpr int COOP_CH = 64;                      // numbers per chunk of the LDS reduction
 // LDS floats of the cooperative solve: [NB][64] shares of one chunk + the totals (gradient + packed Hessian, padded to whole chunks); the staging area overlays the shares
 template <int NC> constexpr int coop_red() { return coop_nx<NC>() + coop_nx<NC>() * (coop_nx<NC>() + 1) / 2; }          // 90 / 189
 template <int NC> constexpr int coop_chunks() { return (coop_red<NC>() + COOP_CH - 1) / COOP_CH; }                        // 2 / 3
-template <int NC> constexpr int coop_stage_floats() { return coop_nb<NC>() * COOP_REC + 21 + coop_nx<NC>() + 6 + 2; }
-template <int NC> constexpr int coop_floats() {
-    return (coop_nb<NC>() * COOP_CH > coop_stage_floats<NC>() ? coop_nb<NC>() * COOP_CH : coop_stage_floats<NC>()) + coop_chunks<NC>() * COOP_CH;
+template <int NC, bool WALLS = false> constexpr int coop_stage_floats() { return coop_nb<NC, WALLS>() * COOP_REC + 21 + coop_nx<NC>() + 6 + 2; }
+template <int NC, bool WALLS = false> constexpr int coop_floats() {
+    return (coop_nb<NC, WALLS>() * COOP_CH > coop_stage_floats<NC, WALLS>() ? coop_nb<NC, WALLS>() * COOP_CH : coop_stage_floats<NC, WALLS>()) + coop_chunks<NC>() * COOP_CH;
 }
 
 // LDS stores complete before the loads that follow.  Needed, not belt and braces: the column sums of a chunk are ds_read2st64 loads issued right behind the sixteen
@@ -74,9 +74,12 @@ DEV void h_rank1_part(float (&H)[E1 - E0], const float (&v)[NX], float w) {
 // The patient (lane L) writes its problem into the staging area.  Record of block b at stage[b * COOP_REC]: n t1 t2 (0-8), lever from the centre of cube 0 / cube 1
 // (9-11 / 12-14), aref (15-20), Rn (21), Rt (22), m2 of the tangential / torsional / rolling rows (23-25), coefficient of the share of cube 0 / cube 1 (26 / 27:
 // -1 arm on that cube, +1 that cube on the floor, -1 / +1 cube 0 / cube 1 of a cube<->cube contact, 0 none), act (28), sign of a limit row (29)
-template <int NC, int NRW, int NCC>
-DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const float (&y)[6], const f3 (&ca)[NC], const f3 (&cal)[NC]) {
-    constexpr int NB = coop_nb<NC>();
+// NCS = cubes of the problem solved here: all NC of the env, or (Stack) ONE -- cube `cs` -- when the patient's only coupling is its arm on that cube (the other cube
+// stays with its own 6-dimensional SIMT solve: 12 unknowns instead of 18)
+template <int NC, int NRW, int NCC, int NCS, bool WALLS>
+DEV void coop_stage(const NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, const float (&y)[6], const f3 (&ca)[NC], const f3 (&cal)[NC], int cs) {
+    constexpr int NB = coop_nb<NCS, WALLS>();
+    auto cube_of = [&](int ci) -> int { return NCS == NC ? ci : cs; };   // env cube behind the problem's cube ci
     const NewtonParams &P = C.P;
     const f3 zero3 = mk(0.f, 0.f, 0.f);
     auto rec = [&](int b, f3 n, f3 t1, f3 t2, f3 rc0, f3 rc1, const float *aref, int naref, float Rn, float Rt, float m2t, float m2s, float m2r, float c0, float c1, bool act, float sign) {
@@ -96,18 +99,19 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const
         const float m2s = s < 2 ? P.mu_fct2 : (s < 4 ? MU_TORS * MU_TORS : (oncube ? P.mu_ct2 : 0.f));
         const float m2r = s < 2 ? P.mu_fcr2 : (s < 4 ? MU_ROLL * MU_ROLL : 0.f);
         const bool may_cube = s < 2 || s == 4;
-        rec(s, T.n, T.t1, T.t2, T.rc, T.rc, T.aref, NRW, T.Rn, T.Rn * P.inv_impratio * m2t, m2t, m2s, m2r,
-            (may_cube && oncube && !second) ? -1.f : 0.f, (may_cube && oncube && second) ? -1.f : 0.f, T.act, 0.f);
+        const int sc = second ? 1 : 0;                                   // the env's cube the slot is on, and which of the problem's cubes that is (-1: none)
+        const int sci = (may_cube && oncube) ? (NCS == NC ? sc : (sc == cs ? 0 : -1)) : -1;
+        rec(s, T.n, T.t1, T.t2, T.rc, T.rc, T.aref, NRW, T.Rn, T.Rn * P.inv_impratio * m2t, m2t, m2s, m2r, sci == 0 ? -1.f : 0.f, sci == 1 ? -1.f : 0.f, T.act, 0.f);
     }
 #pragma unroll
-    for (int c = 0; c < NC; c++)
+    for (int ci = 0; ci < NCS; ci++)
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const FloorSlot &T = C.FS[c][s];
-            rec(5 + 4 * c + s, mk(0.f, 0.f, 1.f), mk(0.f, 1.f, 0.f), mk(-1.f, 0.f, 0.f), T.r, T.r, T.aref, 4, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f,
-                c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, T.act, 0.f);
+            const FloorSlot T = cube_of(ci) == 0 ? C.FS[0][s] : C.FS[NC - 1][s];
+            rec(5 + 4 * ci + s, mk(0.f, 0.f, 1.f), mk(0.f, 1.f, 0.f), mk(-1.f, 0.f, 0.f), T.r, T.r, T.aref, 4, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f,
+                ci == 0 ? 1.f : 0.f, ci == 1 ? 1.f : 0.f, T.act, 0.f);
         }
-    if constexpr (NC == 2) {   // cube<->cube: the force acts at the contact point on cube 1 and, negated, on cube 0 (records of the patient's own LDS column)
+    if constexpr (NCS == 2) {   // cube<->cube: the force acts at the contact point on cube 1 and, negated, on cube 0 (records of the patient's own LDS column)
 #pragma unroll
         for (int s = 0; s < NCC; s++) {
             const bool act = C.cc_any && C.cc_act[s];
@@ -117,6 +121,17 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const
             for (int q = 0; q < 4; q++) aref[q] = act ? C.ccl[(size_t)(s * CC_REC + 7 + q) * 64] : 0.f;
             const float Rn = act ? C.ccl[(size_t)(s * CC_REC + 15) * 64] : 1.f;
             rec(13 + s, C.ccn, C.cct1, C.cct2, pos - C.cp[0], pos - C.cp[NC - 1], aref, 4, Rn, Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f, -1.f, 1.f, act, 0.f);
+        }
+    }
+    if constexpr (WALLS) {   // PushCubeLoop's rails: pair coordinates (a, b, c) = (x, y, z) for the x pair, (y, z, x) for the y pair; n = sg a, t1 = b, t2 = sg c (newton_solve: wall_frame)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const FloorSlot &T = C.WS[s];
+            const float sg = C.wsg[s >> 1];
+            const bool xp = (s >> 1) == 0;
+            const f3 n = xp ? mk(sg, 0.f, 0.f) : mk(0.f, sg, 0.f), t1 = xp ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f), t2 = xp ? mk(0.f, 0.f, sg) : mk(sg, 0.f, 0.f);
+            const f3 r = xp ? T.r : mk(T.r.z, T.r.x, T.r.y);
+            rec(5 + 4 * NCS + s, n, t1, t2, r, r, T.aref, 4, T.Rn, T.Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f, 1.f, 0.f, T.act && C.wall_any, 0.f);
         }
     }
 #pragma unroll
@@ -139,20 +154,21 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, false, NCC> &C, float *stage, const
 #pragma unroll
     for (int j = 0; j < 6; j++) { g[21 + j] = C.y0s[j]; g[27 + j] = y[j]; }
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        float *xc = g + 33 + 6 * c;
-        xc[0] = ca[c].x; xc[1] = ca[c].y; xc[2] = ca[c].z; xc[3] = cal[c].x; xc[4] = cal[c].y; xc[5] = cal[c].z;
+    for (int ci = 0; ci < NCS; ci++) {
+        float *xc = g + 33 + 6 * ci;
+        const f3 a = cube_of(ci) == 0 ? ca[0] : ca[NC - 1], al = cube_of(ci) == 0 ? cal[0] : cal[NC - 1];
+        xc[0] = a.x; xc[1] = a.y; xc[2] = a.z; xc[3] = al.x; xc[4] = al.y; xc[5] = al.z;
     }
 }
 
 // the solve; `lane` = this lane, L = the patient's lane (wave-uniform).  Returns the Newton iterations it took; the patient's y / ca / cal and the forces of its slots are updated.
-template <int NC, int NRW, int NCC>
-DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, int L, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC]) {
-    constexpr int NX = coop_nx<NC>(), NH = NX * (NX + 1) / 2, NB = coop_nb<NC>(), RED = coop_red<NC>(), NCH = coop_chunks<NC>();
-    constexpr bool REBUILD = NC == 2;
+template <int NC, int NRW, int NCC, int NCS = NC, bool WALLS = false>
+DEV int coop_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, int lane, int L, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int cs = 0) {
+    constexpr int NX = coop_nx<NCS>(), NH = NX * (NX + 1) / 2, NB = coop_nb<NCS, WALLS>(), RED = coop_red<NCS>(), NCH = coop_chunks<NCS>();
+    constexpr bool REBUILD = NCS == 2;
     // the rows are rebuilt where they are used instead of living next to the 171-entry Hessian
     const NewtonParams &P = C.P;
-    if (lane == L) coop_stage<NC, NRW, NCC>(C, stage, y, ca, cal);
+    if (lane == L) coop_stage<NC, NRW, NCC, NCS, WALLS>(C, stage, y, ca, cal, cs);
     lds_fence();
     // ---- every lane: its block's record, the shared vectors ----
     const int b = lane < NB ? lane : NB - 1;   // (the other lanes shadow the last block with act = false)
@@ -234,7 +250,7 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
             }
             // a cube's share: its contact point moves with ca + cal x rc (rows 0-2); rows 3-5 see cal
 #pragma unroll
-            for (int c = 0; c < NC; c++)
+            for (int c = 0; c < NCS; c++)
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
                     const f3 d = (q % 3) == 0 ? dn : ((q % 3) == 1 ? dt1 : dt2);
@@ -268,7 +284,7 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
             jd[q] = 0.f;
         }
     });
-    float *shares = stage, *totals = stage + (NB * COOP_CH > coop_stage_floats<NC>() ? NB * COOP_CH : coop_stage_floats<NC>());
+    float *shares = stage, *totals = stage + (NB * COOP_CH > coop_stage_floats<NCS, WALLS>() ? NB * COOP_CH : coop_stage_floats<NCS, WALLS>());
     int its = 0;
     float dprev = 3.0e38f;
     for (int it = 0; it < P.newton_iters; it++) {
@@ -462,12 +478,15 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
 #pragma unroll
                 for (int q = 0; q < (s < 4 ? 6 : 4); q++) C.AS[s].f[q] = stage[s * 8 + q];
 #pragma unroll
-            for (int c = 0; c < NC; c++)
+            for (int ci = 0; ci < NCS; ci++)
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) C.FS[c][s].f[q] = stage[(5 + 4 * c + s) * 8 + q];
-            if constexpr (NC == 2) {
+                    for (int q = 0; q < 4; q++) {
+                        const float fv = stage[(5 + 4 * ci + s) * 8 + q];
+                        if ((NCS == NC ? ci : cs) == 0) C.FS[0][s].f[q] = fv; else C.FS[NC - 1][s].f[q] = fv;
+                    }
+            if constexpr (NCS == 2) {
                 if (C.cc_any) {
 #pragma unroll
                     for (int s = 0; s < NCC; s++)
@@ -475,12 +494,21 @@ DEV int coop_solve(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, in
                         for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC + 3 + q) * 64] = stage[(13 + s) * 8 + q];
                 }
             }
+            if constexpr (WALLS) {
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) C.WS[s].f[q] = stage[(5 + 4 * NCS + s) * 8 + q];
+            }
 #pragma unroll
             for (int j = 0; j < 6; j++) C.flim[j] = stage[(NB - 6 + j) * 8];
 #pragma unroll
             for (int j = 0; j < 6; j++) y[j] = x[j];
 #pragma unroll
-            for (int c = 0; c < NC; c++) { ca[c] = mk(x[6 + 6 * c], x[7 + 6 * c], x[8 + 6 * c]); cal[c] = mk(x[9 + 6 * c], x[10 + 6 * c], x[11 + 6 * c]); }
+            for (int ci = 0; ci < NCS; ci++) {
+                const f3 a = mk(x[6 + 6 * ci], x[7 + 6 * ci], x[8 + 6 * ci]), al = mk(x[9 + 6 * ci], x[10 + 6 * ci], x[11 + 6 * ci]);
+                if ((NCS == NC ? ci : cs) == 0) { ca[0] = a; cal[0] = al; } else { ca[NC - 1] = a; cal[NC - 1] = al; }
+            }
         }
     }
     C.wave_its += its;
