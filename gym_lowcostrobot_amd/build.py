@@ -33,10 +33,14 @@ def _newer(target, deps):
 NO_POST_RA = ["-mllvm", "-enable-post-misched=0"]
 ITER_ILP = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 UNITS = [("lcr_capi.hip", "lcr_capi.o", []), ("lcr_render.hip", "lcr_render.o", []),
-         ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels_loop.hip", "lcr_kernels_loop.o", []),
+         ("lcr_kernels.hip", "lcr_kernels.o", ["-DLCR_PART=0"]), ("lcr_kernels_loop.hip", "lcr_kernels_loop.o", ["-DLCR_LOOP_PART=0"]),
+         ("lcr_kernels_loop.hip", "lcr_kernels_loop_newton.o", ["-DLCR_LOOP_PART=1"] + ITER_ILP),   # (PushCubeLoop's Newton kernels: 6.60 -> 5.98 ms with it, its sweep kernels 0.652 -> 0.730: two units)
          ("lcr_kernels.hip", "lcr_kernels_stack.o", ["-DLCR_PART=2"]), ("lcr_kernels.hip", "lcr_kernels_stack_big.o", ["-DLCR_PART=3"]),
-         ("lcr_kernels.hip", "lcr_kernels_newton.o", ["-DLCR_PART=4"]),   # the Newton kernels of the faithful preset (one cube)
-         ("lcr_kernels.hip", "lcr_kernels_newton_stack.o", ["-DLCR_PART=5"]),   # ... StackTwoCubes (eight cube<->cube slots)
+         # the Newton kernels of the faithful preset: one cube / StackTwoCubes (eight cube<->cube slots).  Iterative-ILP scheduling, measured in round 6 against the default
+         # (same box, tools/quick_times.py): ReachCube 65 536 envs 2.209 -> 2.082 ms, PushCube 3.499 -> 3.312, Stack 32 768 envs 7.06 -> 6.88, PushCubeLoop 6.60 -> 5.98;
+         # no post-RA scheduler 2.362 (worse), both 2.230, max-ilp 2.179, max-memory-clause 2.188
+         ("lcr_kernels.hip", "lcr_kernels_newton.o", ["-DLCR_PART=4"] + ITER_ILP),
+         ("lcr_kernels.hip", "lcr_kernels_newton_stack.o", ["-DLCR_PART=5"] + ITER_ILP),
          # the two-cooperating-waves family (lcr_kernels2.hip): 10 / 14 one cube built for one / two waves per SIMD, 12 StackTwoCubes, 13 StackTwoCubes with the eight-point
          # manifold.  Instruction-scheduling flags per unit, each measured on the MI355X against the default (tools/quick_times.py; results are bit-identical, the flags only
          # reorder instructions): no post-RA scheduler for the 256-register build (Reach 65 536 envs 0.2578 -> 0.2554 ms, Push 0.3128 -> 0.3064, PickPlace-ee 0.3106 -> 0.3068);

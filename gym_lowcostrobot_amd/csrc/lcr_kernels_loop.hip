@@ -1509,19 +1509,34 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
 // ------------------------------------------------------------------------------------------------
 // launcher: solver mode (fixed sweeps | converged) x finger<->cube rows (4 | 6) x action mode
 // ------------------------------------------------------------------------------------------------
+#if LCR_LOOP_PART == -1 || LCR_LOOP_PART == 0
 template <bool ADAPT, bool ROLL>
 static void launch_loop_t(const LcrDev &P, const float *action_dev, int ee_mode, hipStream_t st) {
     const int blocks = (P.n + 63) / 64;
     if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
     else hipLaunchKernelGGL((lcr_step_kernel<1, true, true, ADAPT, ROLL, false>), dim3(blocks), dim3(64), 0, st, P, action_dev);
 }
+#endif
+// (two translation units, -DLCR_LOOP_PART=0: the sweep kernels + this dispatcher, 1: the Newton kernels -- they take different scheduling flags, gym_lowcostrobot_amd/build.py)
+#ifndef LCR_LOOP_PART
+#define LCR_LOOP_PART (-1)
+#endif
+int lcr_launch_step_loop_newton(const LcrDev &P, const float *action_dev, int ee_mode, void *stream);
+#if LCR_LOOP_PART == -1 || LCR_LOOP_PART == 1
+int lcr_launch_step_loop_newton(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {   // the faithful preset: Newton on the primal, six-row finger contacts everywhere
+    const hipStream_t st = (hipStream_t)stream;
+    const int blocks = (P.n + 63) / 64;
+    if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    else hipLaunchKernelGGL((lcr_step_kernel<1, true, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : (int)err;
+}
+#endif
+#if LCR_LOOP_PART == -1 || LCR_LOOP_PART == 0
 int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, void *stream) {
     const hipStream_t st = (hipStream_t)stream;
-    if (P.newton) {   // the faithful preset: Newton on the primal, six-row finger contacts everywhere
-        const int blocks = (P.n + 63) / 64;
-        if (!ee_mode) hipLaunchKernelGGL((lcr_step_kernel<1, false, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-        else hipLaunchKernelGGL((lcr_step_kernel<1, true, true, false, true, false, true>), dim3(blocks), dim3(64), 0, st, P, action_dev);
-    } else if (P.pgs_iters < 0) {   // converged mode
+    if (P.newton) return lcr_launch_step_loop_newton(P, action_dev, ee_mode, stream);
+    if (P.pgs_iters < 0) {   // converged mode
         if (P.roll) launch_loop_t<true, true>(P, action_dev, ee_mode, st);
         else launch_loop_t<true, false>(P, action_dev, ee_mode, st);
     } else {
@@ -1531,3 +1546,4 @@ int lcr_launch_step_loop(const LcrDev &P, const float *action_dev, int ee_mode, 
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : (int)err;
 }
+#endif

@@ -30,3 +30,7 @@ cp = ((res["4"][1] >> 12) & 3) != 0
 print("lanes with finger on cube:", np.nonzero(cp)[0][:40].tolist())
 for e in (93, 175, 105, 22, 30):
     print("patient", e, "sweeps", res["0"][2][e], hex(int(res["4"][2][e])), "dq", d[e])
+big = np.nonzero(d > 1e-5)[0]
+print("all envs differing > 1e-5:", [(int(e), int(e) // 64, int(e) % 64, float(f"{d[e]:.2e}"), hex(int(res["4"][2][e]))) for e in big])
+c4 = np.nonzero(res["4"][2] >= 30)[0]
+print("envs with sweeps >= 30 under coop:", c4.tolist())
