@@ -113,13 +113,18 @@ def main():
     ap.add_argument("asm", nargs="?")
     ap.add_argument("--kernel", default="lcr_step2_kernelILi1ELb0ELb0ELi2ELb0E", help="substring of the mangled name (default: the bench kernel: two-wave family, one cube, joint, four-row contacts, two waves per SIMD)")
     ap.add_argument("--out")
+    ap.add_argument("--newton", action="store_true", help="the headline kernel of the default preset: lcr_step_kernel<1, false, false, true, false, true> (merged into --out if that file exists)")
     a = ap.parse_args()
     path = a.asm
     if not path:
         sys.path.insert(0, ROOT)
         from gym_lowcostrobot_amd import build as B
 
-        src, part = ("lcr_kernels2.hip", ["-DLCR_PART=14"] + B.NO_POST_RA) if "step2" in a.kernel else ("lcr_kernels.hip", ["-DLCR_PART=0"])   # (as build.py builds the unit)
+        if a.newton:   # the one-cube Newton kernel of the default preset (unit LCR_PART = 4, iterative-ILP scheduling: as build.py builds it)
+            src, part = "lcr_kernels.hip", ["-DLCR_PART=4"] + B.ITER_ILP
+            a.kernel = "lcr_step_kernelILi1ELb0ELb0ELb1ELb0ELb1E"
+        else:
+            src, part = ("lcr_kernels2.hip", ["-DLCR_PART=14"] + B.NO_POST_RA) if "step2" in a.kernel else ("lcr_kernels.hip", ["-DLCR_PART=0"])   # (as build.py builds the unit)
         path = os.path.join(tempfile.gettempdir(), src.replace(".hip", ".s"))
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + part + ["-S", "--cuda-device-only", "-o", path, os.path.join(B.CSRC, src)],
                               stderr=subprocess.DEVNULL)
@@ -134,6 +139,8 @@ def main():
             print("    %-11s %5.1f %%  (%d)" % (k, 100 * v, r["weighted"].get(k, 0)))
         print("    lds %d  vmem %d  salu %d  wait/nop %d" % tuple(r["weighted"].get(k, 0) for k in ("lds", "vmem", "salu", "wait_nop")))
     if a.out:
+        if a.newton and os.path.exists(a.out):
+            res = dict(json.load(open(a.out)), **res)
         json.dump(res, open(a.out, "w"), indent=1)
 
 
