@@ -14,6 +14,12 @@ TASKS = {"reach": 0, "lift": 1, "push": 2, "pick_place": 3, "stack": 4, "push_lo
 NQ_MAX, NV_MAX = 20, 18
 
 
+# orc_params.solver.  The oracle knows one solver more than the product's ABI (include/lcr.h: lcr_solver {LCR_SOLVER_PGS = 0, LCR_SOLVER_NEWTON = 1}): the yard-stick
+# "Newton to machine precision" of tools/kkt_distance.py sits at 1 here, the product's Newton (same budget, tolerances and line search as the kernels) at 2.
+ORC_SOLVER_PGS, ORC_SOLVER_EXACT, ORC_SOLVER_NEWTON = 0, 1, 2
+LCR_TO_ORC_SOLVER = {0: ORC_SOLVER_PGS, 1: ORC_SOLVER_NEWTON}   # lcr_solver -> orc_params.solver
+
+
 class OrcParams(ctypes.Structure):
     _fields_ = [
         ("task", ctypes.c_int32),

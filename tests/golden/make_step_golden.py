@@ -10,8 +10,8 @@ What runs unmodified: the env classes' `__init__` (constructor defaults, action 
   * `mujoco.MjModel.from_xml_path` / `MjData`: objects holding qpos / qvel / ctrl / time, joint ranges (follower.xml:58-95 via
     tests/golden/model_golden.json), the goal-region geoms of push_cube_loop.xml:38,41 (same file), `body(name).id`, `site(name).id`,
     `data.body(id).xpos`, `data.site(id).xpos`;
-  * `mujoco.mj_forward`: body xpos := qpos slices of the free joints, site xpos := this repo's forward kinematics (oracle FK, pinned to the
-    SURVEY.md 8(c) known answers) -- i.e. the kinematics of the PLACED state;
+  * `mujoco.mj_forward`: body xpos := qpos slices of the free joints, site xpos := plain-numpy forward kinematics (tests/golden/kin_numpy.py: no oracle
+    involved -- tests/test_kin_golden.py asserts that; pinned to the SURVEY.md 8(c) known answers) -- i.e. the kinematics of the PLACED state;
   * `mujoco.mj_step`: advances `data.time` by the model's timestep (0.002, follower.xml:3) and leaves the state alone: the physics is
     exactly what cannot run here ("parity unpinned").  With the state frozen, body / site xpos are those of the placed
     state -- which is also what the reference's reward sees in real MuJoCo up to one substep (xpos lag) -- so the fixtures pin

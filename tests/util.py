@@ -96,7 +96,7 @@ def make_pair(task, n, **kw):
     if kw.get("finger_floor_condim") == 6:
         okw["condim6"] = 2                                             # ... and on the finger<->floor contacts (the Newton kernels)
     if kw.get("solver") is not None:
-        okw["solver"] = {"pgs": 0, "newton": 2}[kw["solver"]]
+        okw["solver"] = {"pgs": orc.ORC_SOLVER_PGS, "newton": orc.ORC_SOLVER_NEWTON}[kw["solver"]]   # (the oracle's numbering: orc.py)
     for k in ("newton_iters", "ls_iters", "newton_tol", "ls_tol"):
         if k in kw:
             okw[k] = kw[k]
@@ -274,7 +274,7 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
                 print(f"[parity] {where}: excused as sensitive to two-ulp input noise: envs {np.nonzero(exc)[0][:16].tolist()}, |dq| {dq[exc][:4]}")
                 STATS.setdefault("out_sens_by_task", {})[sim.task_name] = STATS.get("out_sens_by_task", {}).get(sim.task_name, 0) + int(exc.sum())
             ill = ill | sens
-        if o.params.solver == 2:
+        if o.params.solver == orc.ORC_SOLVER_NEWTON:
             # Newton kernels: an env whose solve ran into the iteration budget on either side has not converged -- where it stops depends on the path (the analogue
             # of a decision flip; counted separately, and bounded like every explained outlier)
             cap = (o.max_sweeps >= o.params.newton_iters) | (sim.max_sweeps.numpy() >= o.params.newton_iters)
@@ -282,7 +282,7 @@ def parity_step(sim, o, a, atol_q=2e-5, atol_v=2e-3, max_dq=MAX_DQ, max_dv=MAX_D
             ill = ill | cap
         STATS["out"] += int((~ok).sum()); STATS["out_carry"] += int((~ok).sum()) if carry else 0; STATS["out_flip"] += int((~ok & flip).sum()); STATS["out_illcond"] += int((~ok & ~flip & ill).sum())
         illc = ~ok & ~flip & ill
-        if illc.any() and getattr(sim, "_pair_kw", None) is not None and o.params.pgs_iters >= 0 and o.params.solver == 0:
+        if illc.any() and getattr(sim, "_pair_kw", None) is not None and o.params.pgs_iters >= 0 and o.params.solver == orc.ORC_SOLVER_PGS:
             # evidence (reported, not a gate): envs excused as "ill-conditioned for fp32" re-run from the same state with the CONVERGED solver on
             # both sides -- if the disagreement came from rounding amplified by a non-converged PGS, kernel and oracle agree again there
             cv = getattr(sim, "_conv_pair", None)

@@ -14,7 +14,7 @@ mode = "ee" if task.endswith("_ee") else "joint"
 task = task.replace("_ee", "")
 from gym_lowcostrobot_amd import VecSim  # noqa: E402
 
-sim = VecSim(task, n, action_mode=mode, profile="phase_cycles", step_kernel="coop")
+sim = VecSim(task, n, action_mode=mode, profile="phase_cycles", step_kernel="coop", preset="fast")   # (the two-wave kernels are preset fast's)
 bufs = [sim.alloc_actions() for _ in range(16)]
 for i, b in enumerate(bufs):
     sim.fill_random_actions(b, 0, i)

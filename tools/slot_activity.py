@@ -13,7 +13,7 @@ from gym_lowcostrobot_amd import VecSim  # noqa: E402
 task = sys.argv[1] if len(sys.argv) > 1 else "reach"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 60
-sim = VecSim(task, n, diagnostics=1, step_kernel="single")
+sim = VecSim(task, n, diagnostics=1, step_kernel="single", preset="fast")   # (step_kernel pins a family of the sweep kernels: preset fast)
 act = sim.alloc_actions()
 names = {12: "finger 0 <-> cube", 13: "finger 1 <-> cube", 14: "finger 0 <-> floor", 15: "finger 1 <-> floor", 16: "link proxy"}
 names.update({18 + j: f"joint limit {j}" for j in range(6)})
