@@ -208,7 +208,6 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
         if (cfg->step_kernel == 2) return fail(LCR_ERR_UNSUPPORTED, "the Newton kernels are one-wave kernels (step_kernel = 2 pins the two-wave family)");
         if (cfg->pgs_iters < 0) return fail(LCR_ERR_INVALID, "pgs_iters < 0 (converged sweeps) belongs to LCR_SOLVER_PGS");
         if (cfg->diagnostics == 3) return fail(LCR_ERR_UNSUPPORTED, "the per-phase cycle read-back (diagnostics = 3) belongs to the two-wave sweep kernels");
-        if (cfg->diagnostics == 2 && cfg->task == LCR_TASK_PUSH_LOOP) return fail(LCR_ERR_UNSUPPORTED, "the per-wave cycle read-back of the Newton kernels is implemented in lcr_kernels.hip (five tasks), not for PushCubeLoop");
     } else if (cfg->finger_floor_condim == 6) return fail(LCR_ERR_UNSUPPORTED, "six-row finger<->floor contacts are implemented by the Newton kernels (solver = LCR_SOLVER_NEWTON)");
     if (cfg->global_envs < 0) return fail(LCR_ERR_INVALID, "global_envs must be >= 0 (0 = n_envs)");
     if (cfg->global_envs > 0 && (cfg->env_id_offset < 0 || cfg->env_id_offset + (int64_t)cfg->n_envs > cfg->global_envs))

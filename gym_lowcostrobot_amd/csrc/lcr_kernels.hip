@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     }
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
-        P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
+        P.choice[e] = DG.choice + (P.diag == 2 ? 0u : (unsigned)ik_iters * 0x9E3779B1u);   // (diagnostics = 2: the field carries counters, not the decision hash)
         if (P.diag == 2) P.max_sweeps[e] = (unsigned)(clock64() - t_begin);   // profiling aid: cycles of this wave up to here
 #pragma unroll
         for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];   // data.ctrl as apply_action left it (reach_cube_env.py:273)

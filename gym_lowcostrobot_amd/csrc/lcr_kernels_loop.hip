@@ -818,6 +818,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                                        ccl, cc_act, cc_any, ccn, cct1, cct2, S.cp, lim_act, lim_wave, S.q, S.qd, CL, flim, y0s};
         const unsigned long long cmask = __ballot(coupled);
         coupled_many = __popcll(cmask) > P.coop_max;
+        const long long tn0 = P.diag == 2 ? clock64() : 0;   // (profiling aid, as in lcr_kernels.hip: cycles of the solves / of the cooperative ones, patients, iterations -- tools/newton_phases.py)
+        unsigned prof_coop = 0u;
         if constexpr (CPL == CPL_SLOW) sweeps_done = newton_solve<NC, NRW, WALLS, 4, 3>(C, y, ca, cal);   // (uncoupled lanes: the same optimum, block-diagonal Hessian)
         else {
             // the lanes whose arm touches their cube sit out the two small solves and are then solved one by one by the whole wave (lcr_newton_coop.h)
@@ -826,11 +828,18 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             const int ic = newton_solve<NC, NRW, WALLS, 4, 2>(C, y, ca, cal);
             sweeps_done = max(ia, ic);
             float *stage = lds + NEWTON_G_ROWS * LDS_ROW;
+            const long long tc0 = P.diag == 2 ? clock64() : 0;
             for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
                 const int L = __builtin_ctzll(m);
                 const int ip = coop_solve<NC, NRW, 4, NC, WALLS>(C, stage, lane, L, y, ca, cal);
                 sweeps_done = lane == L ? ip : sweeps_done;
             }
+            if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);
+        }
+        if (P.diag == 2) {
+            const unsigned dt = (unsigned)(clock64() - tn0);
+            DGtot.mask += dt; DGtot.count += CPL == CPL_SLOW ? dt : prof_coop;
+            DGtot.choice += (CPL == CPL_SLOW ? (1u << 24) : 0u) + 65536u * (CPL == CPL_SLOW ? 0u : (unsigned)__popcll(cmask)) + (unsigned)C.wave_its;
         }
     }
     for (int it = 0; it < max_it; it++) {
@@ -1164,7 +1173,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
         for (int k = 0; k < NRW; k++) W.arm[s][k] = AS[s].f[k];
 #pragma unroll
     for (int s = 0; s < 4; s++) W.cc_prev[s] = cc_act[s];
-    if (P.diag) {   // wave-uniform
+    if (P.diag == 1 || (P.diag == 2 && !NEWTON)) {   // wave-uniform (diagnostics = 2 on the Newton kernels: the same fields carry cycle counts instead, see the solve above)
         unsigned m = 0u;
 #pragma unroll
         for (int c = 0; c < NC; c++)
@@ -1380,7 +1389,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
     }
     if (P.diag && valid) {
         P.active_mask[e] = DG.mask; P.active_count[e] = DG.count; P.max_sweeps[e] = DG.sweeps;
-        P.choice[e] = DG.choice + (unsigned)ik_iters * 0x9E3779B1u;
+        P.choice[e] = DG.choice + (P.diag == 2 ? 0u : (unsigned)ik_iters * 0x9E3779B1u);   // (diagnostics = 2: the field carries counters, not the decision hash)
         if (P.diag == 2) P.max_sweeps[e] = (unsigned)(clock64() - t_begin);   // profiling aid: cycles of this wave up to here
 #pragma unroll
         for (int j = 0; j < 6; j++) P.ctrl_out[(size_t)j * N + e] = ctrl[j];   // data.ctrl as apply_action left it (reach_cube_env.py:273)

@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 from gym_lowcostrobot_amd import VecSim  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("tasks", nargs="*", default=["reach", "push", "lift", "pick_place_ee", "stack"])
+ap.add_argument("tasks", nargs="*", default=["reach", "push", "lift", "pick_place_ee", "stack", "push_loop"])
 ap.add_argument("--n", type=int, default=65536)
 a = ap.parse_args()
 for name in a.tasks:
