@@ -381,7 +381,7 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             D.newton_tol = (float)cfg->newton_tol; D.ls_tol = (float)cfg->ls_tol;
             // coupled envs a wave of the Newton kernels solves one by one (lcr_newton_coop.h) before it falls back to the coupled SIMT solves: 4 with one cube (a 12-dim SIMT
             // iteration costs ~4 cooperative ones), 16 for Stack (its 18-dim SIMT iteration spills 3 KB per lane: profiles/r06_coop_sweep.txt); measurement override: LCR_COOP_MAX (0: never)
-            D.coop_max = cfg->task == LCR_TASK_STACK ? 16 : 4;
+            D.coop_max = cfg->task == LCR_TASK_STACK ? 16 : (loop ? 4 : 8);   // (one cube without rails: four patients per pass, two passes)
             if (const char *cm_ov = getenv("LCR_COOP_MAX")) D.coop_max = atoi(cm_ov) < 0 ? 0 : (atoi(cm_ov) > 64 ? 64 : atoi(cm_ov));
             if (D.newton) { D.coop = 0; D.roll = 1; D.big_lds = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots, every g row in LDS (cc8: slots 4-7 of their eight cube<->cube records)
         }

@@ -43,6 +43,9 @@ namespace {
 // than LcrDev::coop_max such envs the copy returns false -- the env state untouched -- and the substep is run by CPL_SLOW: the wave-uniform coupled SIMT solves of
 // round 5; it returns whether the wave still has that many (the caller goes back to the fast copy when not).  CPL_BOTH: one copy with both (PushCubeLoop).
 constexpr int CPL_BOTH = 0, CPL_FAST = 1, CPL_SLOW = 2;
+#ifndef LCR_COOP_ROWS
+#define LCR_COOP_ROWS 4   // one cube: patients per pass of the cooperative solve, one per 16-lane row (0: one at a time through the LDS reduction, as Stack and PushCubeLoop do)
+#endif
 template <int NC, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false, int CPL = CPL_BOTH>
 DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float *lds, int lane, int env, f3 &lag_ee, f3 (&lag_cube)[NC], Warm<NC, ROLL ? 6 : 4> &W, Diag &DGtot, int sub_index) {
     static_assert(!NEWTON || (ROLL && !ADAPT && (NC == 1 || BIG)), "the Newton kernels carry six-row finger slots and keep every g row in LDS");
@@ -783,11 +786,19 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     float *stage = lds + NEWTON_G_ROWS * LDS_ROW;
                     const long long tc0 = P.diag == 2 ? clock64() : 0;
                     prof_patients = __popcll(cmask);
+#if LCR_COOP_ROWS > 0
+                    for (unsigned long long m = cmask; m != 0ull;) {   // LCR_COOP_ROWS patients per pass, one per 16-lane row (lcr_newton_coop.h: coop_solve_rows)
+                        unsigned long long pm = 0ull;
+                        for (int k = 0; k < LCR_COOP_ROWS && m != 0ull; k++) { pm |= m & (0ull - m); m &= m - 1ull; }
+                        coop_solve_rows<NC, NRW, NCC>(C, stage, lane, pm, y, ca, cal, sweeps_done);
+                    }
+#else
                     for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
                         const int L = __builtin_ctzll(m);
                         const int ip = coop_solve<NC, NRW, NCC>(C, stage, lane, L, y, ca, cal);
                         sweeps_done = lane == L ? ip : sweeps_done;
                     }
+#endif
                     if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);
                 }
             }

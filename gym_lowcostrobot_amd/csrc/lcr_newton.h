@@ -147,7 +147,8 @@ struct NewtonParams {
     int ls_iters, newton_iters;
 };
 DEV NewtonParams newton_params(const LcrDev &P) {
-    return NewtonParams{P.cube_iinv, P.cube_mass, P.inv_impratio, P.ls_tol, P.mu_c2, P.mu_ct2, P.mu_fc2, P.mu_fcr2, P.mu_fct2, P.newton_tol, P.ls_iters, P.newton_iters};
+    return NewtonParams{P.cube_iinv, P.cube_mass, P.inv_impratio, P.ls_tol, P.mu_c2, P.mu_ct2, P.mu_fc2, P.mu_fcr2, P.mu_fct2, P.newton_tol, P.ls_iters, P.newton_iters
+    };
 }
 template <int NC, int NRW, bool WALLS, int NCC>
 struct NewtonCtx {

@@ -515,4 +515,327 @@ DEV int coop_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, int lane, in
     return its;
 }
 
+// ================================================================================================
+// One cube (15 blocks): up to FOUR patients at a time, one per 16-lane row of the wave.  Lane 16 p + b owns block b of patient p; the shares of a row are summed
+// inside the row by DPP (no LDS, no waits), so each row is its own little solve and the rows run the iteration loop together like the lanes of the SIMT solver do: a
+// row that has converged idles (step 0) until the last one has.  The launch time of PushCube / LiftCube / PickPlaceCube was the wave with the most coupled envs (three
+// per substep, 61 cooperative solves per control step): four per pass turn its k solves into ceil(k / 4) -- PushCube 3.31 -> 2.64 ms, PickPlace-ee 3.32 -> 2.53.
+// ================================================================================================
+// sum over the 16 lanes of a row, THE SAME BITS in every lane of the row: every step adds a lane and its partner under an involution (i ^ 1, i ^ 2, mirror of the half
+// row, mirror of the row), so both compute a + b = b + a.  (With rotations -- row_ror:4, row_ror:8 -- the quads are added in a different order in each quad; the
+// lanes of a row then factorise Hessians that differ in the last bit and their copies of the iterate drift apart.)
+DEV float row_sum(float v) {
+    auto dpp = [](float x, auto ctrl_tag) -> float {
+        constexpr int ctrl = decltype(ctrl_tag)::value;
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xb1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4e>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+// pmask: the patients of this pass (at most four lanes of the wave, ascending: the p-th set bit is row p's patient)
+template <int NC, int NRW, int NCC>
+DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, unsigned long long pmask, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int &sweeps_done) {
+    static_assert(NC == 1, "one cube: 15 blocks fit a 16-lane row");
+    constexpr int NX = coop_nx<1>(), NH = NX * (NX + 1) / 2, NB = coop_nb<1>();
+    const NewtonParams &P = C.P;
+    const int row = lane >> 4, b = (lane & 15) < NB ? (lane & 15) : NB - 1;
+    int Lp = 0;           // this row's patient lane
+    bool has = false;     // this row has a patient
+    f3 dn = mk(0.f, 0.f, 1.f), dt1 = mk(0.f, 1.f, 0.f), dt2 = mk(-1.f, 0.f, 0.f), rc = mk(0.f, 0.f, 0.f);
+    float aref[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Rn = 1.f, Rt = 1.f, coef = 0.f, lsign = 0.f, m2t = 0.f, m2s = 0.f, m2r = 0.f;
+    bool act = false;
+    float x[NX], x0[NX], lrow6[6];
+#pragma unroll
+    for (int i = 0; i < NX; i++) { x[i] = 0.f; x0[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) lrow6[k] = 0.f;
+    {
+        int p = 0;
+        for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull, p++) {
+            const int L = __builtin_ctzll(m);
+            if (lane == L) coop_stage<NC, NRW, NCC, 1, false>(C, stage, y, ca, cal, 0);
+            lds_fence();
+            if (row == p) {
+                const float *r = stage + b * COOP_REC;
+                const float *gs = stage + NB * COOP_REC;
+                Lp = L; has = true;
+                dn = mk(r[0], r[1], r[2]); dt1 = mk(r[3], r[4], r[5]); dt2 = mk(r[6], r[7], r[8]); rc = mk(r[9], r[10], r[11]);
+#pragma unroll
+                for (int k = 0; k < 6; k++) aref[k] = r[15 + k];
+                Rn = r[21]; Rt = r[22]; m2t = r[23]; m2s = r[24]; m2r = r[25]; coef = r[26]; lsign = r[29];
+                act = (lane & 15) < NB && r[28] != 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; i++) x0[i] = gs[21 + i];
+#pragma unroll
+                for (int i = 0; i < NX; i++) x[i] = gs[27 + i];
+                if (act && b >= NB - 6) {   // a joint limit's row L^-1 (+-e_j)
+                    const int j = b - (NB - 6);
+                    float Ls[15], id[6];
+#pragma unroll
+                    for (int k = 0; k < 15; k++) Ls[k] = gs[k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { id[k] = gs[15 + k]; lrow6[k] = k == j ? lsign : 0.f; }
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        float sacc = lrow6[i];
+#pragma unroll
+                        for (int k = 0; k < i; k++) sacc = fmaf(-Ls[i * (i - 1) / 2 + k], lrow6[k], sacc);
+                        lrow6[i] = sacc * id[i];
+                    }
+                }
+            }
+            lds_fence();   // (the record is in registers before the next patient overwrites it)
+        }
+    }
+#pragma unroll
+    for (int i = 6; i < NX; i++) x0[i] = i == 8 ? -GRAV : 0.f;
+    const float m2[6] = {1.f, m2t, m2t, m2s, m2r, m2r};
+    const float cm = P.cube_mass, ci = rcp(P.cube_iinv);
+    auto mdiag = [&](int i) -> float { return i < 6 ? 1.f : (i < 9 ? cm : ci); };
+    float J[6][NX];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int i = 0; i < NX; i++) J[q][i] = 0.f;
+    auto ldrow = [&](int lrow, float (&o6)[6]) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float2v gp = *reinterpret_cast<const float2v *>(&C.lds[lrow * LDS_ROW + k * 128 + Lp * 2]);
+            o6[2 * k] = gp.x; o6[2 * k + 1] = gp.y;
+        }
+    };
+    if (act) {
+        if (b < 4) {
+            float bx[6], by[6], bz[6];
+            const int b0 = NEWTON_BODY_ROW0 + 3 * (b & 1);
+            ldrow(b0, bx); ldrow(b0 + 1, by); ldrow(b0 + 2, bz);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                float g6[6];
+                ldrow(3 * b + q, g6);
+                const f3 dd = q == 0 ? dn : (q == 1 ? dt1 : dt2);
+#pragma unroll
+                for (int k = 0; k < 6; k++) { J[q][k] = g6[k]; J[3 + q][k] = fmaf(dd.x, bx[k], fmaf(dd.y, by[k], dd.z * bz[k])); }
+            }
+        } else if (b == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float g6[6];
+                ldrow(18 + q, g6);
+#pragma unroll
+                for (int k = 0; k < 6; k++) J[q][k] = g6[k];
+            }
+        } else if (b >= NB - 6) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) J[0][k] = lrow6[k];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const f3 d = (q % 3) == 0 ? dn : ((q % 3) == 1 ? dt1 : dt2);
+            const f3 lin = q < 3 ? coef * d : mk(0.f, 0.f, 0.f), ang = q < 3 ? coef * cross(rc, d) : coef * d;
+            J[q][6] = lin.x; J[q][7] = lin.y; J[q][8] = lin.z; J[q][9] = ang.x; J[q][10] = ang.y; J[q][11] = ang.z;
+        }
+    }
+    float scale = fmaf((float)NC * cm, GRAV * GRAV, 1.f);
+#pragma unroll
+    for (int j = 0; j < 6; j++) scale = fmaf(x0[j], x0[j], scale);
+    const float tol2 = P.newton_tol * P.newton_tol * scale;
+    float zs[6], jd[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        float a = -aref[q];
+#pragma unroll
+        for (int i = 0; i < NX; i++) a = fmaf(J[q][i], x[i], a);
+        zs[q] = act ? a : 0.f;
+        jd[q] = 0.f;
+    }
+    int its = 0, n_floor = 0;
+    float dprev = 3.0e38f;
+    for (int it = 0; it < P.newton_iters; it++) {
+        float dx[NX], d0 = 0.f;
+        {
+            BlkEval<6> B;
+            blk_eval<6>(zs, Rn, Rt, m2, act, B);
+            float Hm[NH], g[NX], hid[NX];
+#pragma unroll
+            for (int i = 0; i < NH; i++) Hm[i] = 0.f;
+            h_block<0, NX, NX, 6>(Hm, J, B, m2);
+#pragma unroll
+            for (int i = 0; i < NH; i++) Hm[i] = row_sum(Hm[i]);
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 6; q++) a = fmaf(-B.f[q], J[q][i], a);
+                g[i] = fmaf(mdiag(i), x[i] - x0[i], row_sum(a));
+            }
+#pragma unroll
+            for (int i = 0; i < NX; i++) Hm[tri(i, i)] += mdiag(i);
+            chol_packed<NX>(Hm, hid);
+#pragma unroll
+            for (int i = 0; i < NX; i++) dx[i] = -g[i];
+            solve_packed<NX>(Hm, hid, dx);
+#pragma unroll
+            for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
+            // The row's lanes take the step and the decrement of the row's FIRST lane (ds_bpermute).  What each computed itself from the bit-identical sums above is meant to
+            // be the same -- and was not: traced on the MI355X, the lanes' copies of dx, x, the decrement and the line-search step spread within a row (a row stuck at a
+            // decrement of 5.9e-4 with phi'(0) = +9.4e-5 for 30 iterations: every lane's rows multiplied ITS OWN dx).  Which operation of the replicated factorisation differs
+            // between lanes was not isolated; with the step shared the rows converge like the single-patient solve (tools/ubench/row_sum_check.hip holds the sums).
+            const int src0 = (lane & 48) << 2;
+#pragma unroll
+            for (int i = 0; i < NX; i++) dx[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(dx[i])));
+            d0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(d0)));
+        }
+        float dist2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) dist2 = fmaf(mdiag(i) * (x[i] - x0[i]), x[i] - x0[i], dist2);
+        // (the exits of newton_solve, and one more: a decrement at rounding level for the THIRD time ends the solve even if the ones between were larger -- a step taken
+        //  from a converged iterate on line-search values that are noise can bounce the decrement between 1e-11 and 1e-6 without ever "not shrinking": seen, 30 iterations)
+        const bool at_floor = -d0 <= DEC_FLOOR * dist2;
+        n_floor += at_floor ? 1 : 0;
+        const bool live = has && -d0 > tol2 && !(at_floor && (-d0 >= 0.25f * dprev || n_floor >= 3));   // (the same in every lane of a row)
+        dprev = -d0;
+        if (!__any(live)) break;
+        its += live ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < NX; i++) a = fmaf(J[q][i], dx[i], a);
+            jd[q] = act ? a : 0.f;
+        }
+        float q1 = 0.f, q0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) { q1 = fmaf(mdiag(i) * dx[i], dx[i], q1); q0 = fmaf(mdiag(i) * (x[i] - x0[i]), dx[i], q0); }
+        auto ls_eval = [&](float al, float &ef, float &eh) {
+            float z[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) z[q] = fmaf(al, jd[q], zs[q]);
+            BlkEval<6> B;
+            blk_eval<6>(z, Rn, Rt, m2, act, B);
+            float acc = 0.f, u = 0.f, tt = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc = fmaf(B.f[q], jd[q], acc);
+#pragma unroll
+            for (int q = 1; q < 6; q++) { u = fmaf(B.c[q], jd[q], u); tt = fmaf(m2[q] * jd[q], jd[q], tt); }
+            const float sn = jd[0] - u;
+            ef = row_sum(acc);
+            eh = row_sum(fmaf(B.av * sn, sn, fmaf(-B.gam * u, u, B.kap * tt)));
+        };
+        auto kink_cand = [&](float lo, float hi, float sec) -> float {   // (rare)
+            float qa = 0.f, qb = 0.f, qc = 0.f;
+#pragma unroll
+            for (int q = 1; q < 6; q++) {
+                const float mj = m2[q] * jd[q];
+                qa = fmaf(mj, jd[q], qa); qb = fmaf(mj, zs[q], qb); qc = fmaf(m2[q] * zs[q], zs[q], qc);
+            }
+            const float iqa = rcp(fmaxf(qa, 1e-30f));
+            const float am = -qb * iqa;
+            const float n2 = fmaxf(fmaf(-qb * qb, iqa, qc), 0.f), wn = fmaf(am, jd[0], zs[0]);
+            const bool ok = act && (lane & 15) < NB - 6 && qa > 0.f && am > lo && am < hi && wn < 0.f && !(n2 * Rn * Rn > wn * wn * Rt * Rt);
+            const float dist = fabsf(am - sec), okf = ok ? 1.f : 0.f;
+            float best = sec;
+            for (int rr = 0; rr < 4; rr++) {   // (v_readlane with wave-uniform lane numbers; the row that is meant keeps the result)
+                float bst = sec, bd = -1.f;
+                for (int k = 0; k < NB - 6; k++) {
+                    const bool okk = __builtin_amdgcn_readlane(__float_as_int(okf), 16 * rr + k) != 0;
+                    const float amk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(am), 16 * rr + k)), dk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dist), 16 * rr + k));
+                    const bool take = okk && (bd < 0.f || dk < bd);
+                    bst = take ? amk : bst;
+                    bd = take ? dk : bd;
+                }
+                best = row == rr ? bst : best;
+            }
+            return best;
+        };
+        float al = 1.f, lo_a = 0.f, hi_a = -1.f, dlo = d0, dhi = 0.f, hlo = -d0, hhi = 0.f, dlo_m = d0, dhi_m = 0.f;
+        int last_side = 0, same = 0;
+        bool done = !live, conv = !live;
+        for (int ls = 0; ls < P.ls_iters; ls++) {
+            float ef, eh;
+            ls_eval(al, ef, eh);
+            const float mpart = fmaf(al, q1, q0);
+            const float dphi = mpart - ef, ddphi = q1 + eh;
+            float an = al, sec = al;
+            bool need = false;
+            if (!done) {
+                const bool fin = fabsf(dphi) <= fmaf(P.ls_tol, fabsf(d0), LS_NOISE * (fabsf(mpart) + fabsf(ef)));
+                const int side = dphi < 0.f ? -1 : 1;
+                if (dphi < 0.f) { if (last_side < 0) dhi_m *= 0.5f; lo_a = al; dlo = dphi; hlo = ddphi; dlo_m = dphi; }
+                else { if (last_side > 0) dlo_m *= 0.5f; hi_a = al; dhi = dphi; hhi = ddphi; dhi_m = dphi; }
+                same = side == last_side ? same + 1 : 0;
+                last_side = side;
+                if (hi_a < 0.f) an = lo_a - dlo * rcp(hlo);
+                else {
+                    const float cl = lo_a - dlo * rcp(hlo), ch = hi_a - dhi * rcp(hhi);
+                    const float mg = 1e-4f * (hi_a - lo_a), blo = lo_a + mg, bhi = hi_a - mg;
+                    const bool vl = cl > blo && cl < bhi, vh = ch > blo && ch < bhi;
+                    bool from_lo = fabsf(dlo) <= fabsf(dhi);
+                    if (same >= 2) from_lo = side > 0;
+                    sec = lo_a - dlo_m * (hi_a - lo_a) * rcp(dhi_m - dlo_m);
+                    if (!(sec > lo_a && sec < hi_a)) sec = 0.5f * (lo_a + hi_a);
+                    an = from_lo ? (vl ? cl : ch) : (vh ? ch : cl);
+                    need = !fin && !vl && !vh;
+                }
+                conv = fin;
+                done = fin;
+            }
+            if (__any(need)) {
+                const float mg = 1e-4f * (hi_a - lo_a);
+                const float kc = kink_cand(lo_a + mg, hi_a - mg, sec);
+                an = need ? kc : an;
+            }
+            al = done ? al : an;
+            if (__all(done)) break;
+        }
+        if (!conv) al = lo_a > 0.f ? lo_a : hi_a;
+        const float step = live ? al : 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) x[i] = fmaf(step, dx[i], x[i]);
+#pragma unroll
+        for (int q = 0; q < 6; q++) zs[q] = fmaf(step, jd[q], zs[q]);
+    }
+    // ---- forces and accelerations back to the patients: [lane][8] forces, then [row][12] x ----
+    {
+        BlkEval<6> B;
+        blk_eval<6>(zs, Rn, Rt, m2, act, B);
+#pragma unroll
+        for (int q = 0; q < 6; q++) stage[lane * 8 + q] = B.f[q];
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) stage[512 + row * NX + i] = x[i];
+            stage[512 + 4 * NX + row] = (float)its;
+        }
+        lds_fence();
+        int p = 0;
+        for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull, p++) {
+            const int L = __builtin_ctzll(m);
+            if (lane == L) {
+                const float *fr = stage + p * 16 * 8;
+#pragma unroll
+                for (int s = 0; s < NAS; s++)
+#pragma unroll
+                    for (int q = 0; q < (s < 4 ? 6 : 4); q++) C.AS[s].f[q] = fr[s * 8 + q];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) C.FS[0][s].f[q] = fr[(5 + s) * 8 + q];
+#pragma unroll
+                for (int j = 0; j < 6; j++) C.flim[j] = fr[(NB - 6 + j) * 8];
+                const float *xr = stage + 512 + p * NX;
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = xr[j];
+                ca[0] = mk(xr[6], xr[7], xr[8]); cal[0] = mk(xr[9], xr[10], xr[11]);
+                sweeps_done = (int)stage[512 + 4 * NX + p];
+            }
+        }
+        lds_fence();
+        C.wave_its += its;
+    }
+}
+
 }  // namespace
