@@ -790,7 +790,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     for (unsigned long long m = cmask; m != 0ull;) {   // LCR_COOP_ROWS patients per pass, one per 16-lane row (lcr_newton_coop.h: coop_solve_rows)
                         unsigned long long pm = 0ull;
                         for (int k = 0; k < LCR_COOP_ROWS && m != 0ull; k++) { pm |= m & (0ull - m); m &= m - 1ull; }
-                        coop_solve_rows<NC, NRW, NCC>(C, stage, lane, pm, y, ca, cal, sweeps_done);
+                        coop_solve_rows<NC, NRW, NCC>(C, stage, lane, pm, 0ull, y, ca, cal, sweeps_done);
                     }
 #else
                     for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
@@ -825,11 +825,27 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const long long tc0 = P.diag == 2 ? clock64() : 0;
                 prof_patients = __popcll(cmask);
                 const unsigned long long m0 = __ballot(pair0), m1 = __ballot(pair1);
-                for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
+#ifndef LCR_STACK_ROWS
+                // (one at a time.  Four per pass, as the one-cube kernels solve them -- -DLCR_STACK_ROWS -- is 10 % faster (Stack, 32 768 envs: 6.88 -> 6.18 ms) and as close to the
+                //  oracle in the aggregate (tools/newton_dev_check.py: 99.90 % within 2e-5), but one env of tests/test_gpu_parity.py::test_step_rollout_vs_oracle -- a gripper-body
+                //  proxy on a cube -- took 23 iterations instead of 10 and ended 8e-4 rad off with every decision identical: not shipped until that solve is understood)
+                for (unsigned long long m = m0 | m1; m != 0ull; m &= m - 1ull) {
                     const int L = __builtin_ctzll(m);
-                    int ip;
-                    if ((m0 | m1) >> L & 1ull) ip = coop_solve<NC, NRW, NCC, 1>(C, stage, lane, L, y, ca, cal, (int)(m1 >> L & 1ull));
-                    else ip = coop_solve<NC, NRW, NCC, 2>(C, stage, lane, L, y, ca, cal);
+                    const int ip = coop_solve<NC, NRW, NCC, 1>(C, stage, lane, L, y, ca, cal, (int)(m1 >> L & 1ull));
+                    i1 = lane == L ? max(ip, i1) : i1;
+                }
+#else
+                for (unsigned long long m = m0 | m1; m != 0ull;) {   // arm + one cube: four patients per pass, one per 16-lane row (coop_solve_rows)
+                    unsigned long long pm = 0ull;
+                    for (int k = 0; k < 4 && m != 0ull; k++) { pm |= m & (0ull - m); m &= m - 1ull; }
+                    int ip = 0;
+                    coop_solve_rows<NC, NRW, NCC>(C, stage, lane, pm, m1, y, ca, cal, ip);
+                    i1 = max(ip, i1);
+                }
+#endif
+                for (unsigned long long m = cmask & ~(m0 | m1); m != 0ull; m &= m - 1ull) {   // all three bodies: one patient at a time
+                    const int L = __builtin_ctzll(m);
+                    const int ip = coop_solve<NC, NRW, NCC, 2>(C, stage, lane, L, y, ca, cal);
                     i1 = lane == L ? max(ip, i1) : i1;
                 }
                 if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);

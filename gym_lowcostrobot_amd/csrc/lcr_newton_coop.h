@@ -536,10 +536,10 @@ DEV float row_sum(float v) {
     return v;
 }
 
-// pmask: the patients of this pass (at most four lanes of the wave, ascending: the p-th set bit is row p's patient)
+// pmask: the patients of this pass (at most four lanes of the wave, ascending: the p-th set bit is row p's patient); c1mask (Stack): the patients whose cube is cube 1
+// (each is solved as arm + ITS cube, 12 unknowns, 15 blocks: the other cube keeps its SIMT solve)
 template <int NC, int NRW, int NCC>
-DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, unsigned long long pmask, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int &sweeps_done) {
-    static_assert(NC == 1, "one cube: 15 blocks fit a 16-lane row");
+DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, unsigned long long pmask, unsigned long long c1mask, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int &sweeps_done) {
     constexpr int NX = coop_nx<1>(), NH = NX * (NX + 1) / 2, NB = coop_nb<1>();
     const NewtonParams &P = C.P;
     const int row = lane >> 4, b = (lane & 15) < NB ? (lane & 15) : NB - 1;
@@ -557,7 +557,7 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
         int p = 0;
         for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull, p++) {
             const int L = __builtin_ctzll(m);
-            if (lane == L) coop_stage<NC, NRW, NCC, 1, false>(C, stage, y, ca, cal, 0);
+            if (lane == L) coop_stage<NC, NRW, NCC, 1, false>(C, stage, y, ca, cal, NC == 2 ? (int)(c1mask >> L & 1ull) : 0);
             lds_fence();
             if (row == p) {
                 const float *r = stage + b * COOP_REC;
@@ -653,7 +653,7 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
         zs[q] = act ? a : 0.f;
         jd[q] = 0.f;
     }
-    int its = 0, n_floor = 0;
+    int its = 0;
     float dprev = 3.0e38f;
     for (int it = 0; it < P.newton_iters; it++) {
         float dx[NX], d0 = 0.f;
@@ -693,11 +693,7 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
         float dist2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++) dist2 = fmaf(mdiag(i) * (x[i] - x0[i]), x[i] - x0[i], dist2);
-        // (the exits of newton_solve, and one more: a decrement at rounding level for the THIRD time ends the solve even if the ones between were larger -- a step taken
-        //  from a converged iterate on line-search values that are noise can bounce the decrement between 1e-11 and 1e-6 without ever "not shrinking": seen, 30 iterations)
-        const bool at_floor = -d0 <= DEC_FLOOR * dist2;
-        n_floor += at_floor ? 1 : 0;
-        const bool live = has && -d0 > tol2 && !(at_floor && (-d0 >= 0.25f * dprev || n_floor >= 3));   // (the same in every lane of a row)
+        const bool live = has && -d0 > tol2 && !(-d0 <= DEC_FLOOR * dist2 && -d0 >= 0.25f * dprev);   // (the same in every lane of a row)
         dprev = -d0;
         if (!__any(live)) break;
         its += live ? 1 : 0;
@@ -820,16 +816,18 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
                 for (int s = 0; s < NAS; s++)
 #pragma unroll
                     for (int q = 0; q < (s < 4 ? 6 : 4); q++) C.AS[s].f[q] = fr[s * 8 + q];
+                const bool second = NC == 2 && (c1mask >> L & 1ull) != 0ull;
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) C.FS[0][s].f[q] = fr[(5 + s) * 8 + q];
+                    for (int q = 0; q < 4; q++) { if (second) C.FS[NC - 1][s].f[q] = fr[(5 + s) * 8 + q]; else C.FS[0][s].f[q] = fr[(5 + s) * 8 + q]; }
 #pragma unroll
                 for (int j = 0; j < 6; j++) C.flim[j] = fr[(NB - 6 + j) * 8];
                 const float *xr = stage + 512 + p * NX;
 #pragma unroll
                 for (int j = 0; j < 6; j++) y[j] = xr[j];
-                ca[0] = mk(xr[6], xr[7], xr[8]); cal[0] = mk(xr[9], xr[10], xr[11]);
+                if (second) { ca[NC - 1] = mk(xr[6], xr[7], xr[8]); cal[NC - 1] = mk(xr[9], xr[10], xr[11]); }
+                else { ca[0] = mk(xr[6], xr[7], xr[8]); cal[0] = mk(xr[9], xr[10], xr[11]); }
                 sweeps_done = (int)stage[512 + 4 * NX + p];
             }
         }
