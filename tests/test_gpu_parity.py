@@ -699,14 +699,16 @@ def test_link_proxy_contacts(hip_lib, kernel_family, monkeypatch, task, bit, nea
         # (outliers: every one has to be explained inside parity_step -- a contact switching in another substep, an ill-conditioned state; with the ~64 selected
         #  states of a task one such env is 1.6 %.  Six-row finger contacts: a finger tip that starts or stops rolling in a different substep moves the arm by up
         #  to 2.2e-2 rad within the control step, PushCube seed 66)
-        # (faithful: 6e-5 -- three six-row arm contacts, up to 17 rows on 6 dofs, from a cold start with a finger 5 mm inside the floor: PushCubeLoop env 183 of seed 66
+        # (round 6: with the coupled envs solved as ONE problem by the cooperative solves the faithful preset is back at 4e-5 / 0.99 on five of the six tasks; StackTwoCubes
+        #  keeps round 5's 6e-5 / 0.975 -- 5 of its 256 selected states are outside 4e-5, profiles/r06_soak.txt)
+        # (faithful, round 5: 6e-5 -- three six-row arm contacts, up to 17 rows on 6 dofs, from a cold start with a finger 5 mm inside the floor: PushCubeLoop env 183 of seed 66
         #  ends 5.1e-5 rad from the fp64 oracle with identical decisions on both sides and the oracle's own fp32 build within 1e-5 -- the kernel solves the arm and
         #  the cube as separate problems and accumulates the row residuals incrementally, the oracle neither)
-        tq = 6e-5 if kernel_family == "faithful" else 4e-5
+        tq = 6e-5 if kernel_family == "faithful" and task == "stack" else 4e-5
         dq, dv, ok, st = util.parity_step(sim, o, a, tq, 4e-3, max_dq=3e-2 if kernel_family == "faithful" else util.MAX_DQ, where=("link", task, bit, t))
         # faithful preset: the selected states start a finger up to 5 mm inside the floor with zero carried forces -- a cold Newton start that runs into the
         # iteration budget in ~1.5 % of them on the fp64 side alone (explained as "cap"); 97.5 % within the tolerance there
-        assert ok.mean() >= (0.975 if kernel_family == "faithful" else min(0.99, 1.0 - 1.5 / n)), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
+        assert ok.mean() >= (0.975 if kernel_family == "faithful" and task == "stack" else min(0.99, 1.0 - 1.5 / n)), (t, ok.mean(), np.sort(dq)[-5:], np.sort(dv)[-5:])
         seen += int(((o.active_mask >> bit) & 1).sum())
         assert np.array_equal((sim.active_mask.numpy() >> bit) & 1, (o.active_mask >> bit) & 1) or ok.mean() < 1.0
     assert seen >= n        # the slot under test was really exercised
