@@ -825,10 +825,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 const long long tc0 = P.diag == 2 ? clock64() : 0;
                 prof_patients = __popcll(cmask);
                 const unsigned long long m0 = __ballot(pair0), m1 = __ballot(pair1);
-#ifndef LCR_STACK_ROWS
-                // (one at a time.  Four per pass, as the one-cube kernels solve them -- -DLCR_STACK_ROWS -- is 10 % faster (Stack, 32 768 envs: 6.88 -> 6.18 ms) and as close to the
-                //  oracle in the aggregate (tools/newton_dev_check.py: 99.90 % within 2e-5), but one env of tests/test_gpu_parity.py::test_step_rollout_vs_oracle -- a gripper-body
-                //  proxy on a cube -- took 23 iterations instead of 10 and ended 8e-4 rad off with every decision identical: not shipped until that solve is understood)
+#ifdef LCR_STACK_ONE_PER_PASS
+                // (A/B: one patient at a time with all 64 lanes -- Stack, 32 768 envs: 6.81 ms against 6.03 with four per pass)
                 for (unsigned long long m = m0 | m1; m != 0ull; m &= m - 1ull) {
                     const int L = __builtin_ctzll(m);
                     const int ip = coop_solve<NC, NRW, NCC, 1>(C, stage, lane, L, y, ca, cal, (int)(m1 >> L & 1ull));

@@ -519,7 +519,9 @@ DEV int coop_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, int lane, in
 // One cube (15 blocks): up to FOUR patients at a time, one per 16-lane row of the wave.  Lane 16 p + b owns block b of patient p; the shares of a row are summed
 // inside the row by DPP (no LDS, no waits), so each row is its own little solve and the rows run the iteration loop together like the lanes of the SIMT solver do: a
 // row that has converged idles (step 0) until the last one has.  The launch time of PushCube / LiftCube / PickPlaceCube was the wave with the most coupled envs (three
-// per substep, 61 cooperative solves per control step): four per pass turn its k solves into ceil(k / 4) -- PushCube 3.31 -> 2.64 ms, PickPlace-ee 3.32 -> 2.53.
+// per substep, 61 cooperative solves per control step): four per pass turn its k solves into ceil(k / 4) -- PushCube 3.31 -> 2.64 ms, PickPlace-ee 3.32 -> 2.53.  StackTwoCubes' arm + ONE cube patients
+// (12 unknowns, the same 15 blocks) are solved here too: 32 768 envs 6.81 -> 6.03 ms.  -DLCR_ROWS_TRACE: every replicated quantity of every iteration is compared with
+// the row's first lane and the first differences are printed (how the re-association in row_sum was found).
 // ================================================================================================
 // sum over the 16 lanes of a row, THE SAME BITS in every lane of the row: every step adds a lane and its partner under an involution (i ^ 1, i ^ 2, mirror of the half
 // row, mirror of the row), so both compute a + b = b + a.  (With rotations -- row_ror:4, row_ror:8 -- the quads are added in a different order in each quad; the
@@ -529,15 +531,33 @@ DEV float row_sum(float v) {
         constexpr int ctrl = decltype(ctrl_tag)::value;
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false));
     };
+    // (each partial sum is made opaque: under -ffast-math the compiler may otherwise re-associate a step with the next one or with the CALLER's arithmetic --
+    //  phi'(al) = mpart - (h0 + h1) became (mpart - h0) - h1 in one half of the row and (mpart - h1) - h0 in the other: profiles/r06_rows_trace.txt)
     v += dpp(v, std::integral_constant<int, 0xb1>{});    // quad_perm [1,0,3,2]
+    asm("" : "+v"(v));
     v += dpp(v, std::integral_constant<int, 0x4e>{});    // quad_perm [2,3,0,1]
+    asm("" : "+v"(v));
     v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    asm("" : "+v"(v));
     v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    asm("" : "+v"(v));
     return v;
 }
 
 // pmask: the patients of this pass (at most four lanes of the wave, ascending: the p-th set bit is row p's patient); c1mask (Stack): the patients whose cube is cube 1
 // (each is solved as arm + ITS cube, 12 unknowns, 15 blocks: the other cube keeps its SIMT solve)
+#ifdef LCR_ROWS_TRACE
+__device__ int lcr_rows_trace_n = 0;
+DEV void rows_chk(float v, int lane, bool has, int it, int tag, int idx) {
+    const float r = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 48) << 2, __float_as_int(v)));
+    if (has && __float_as_int(r) != __float_as_int(v)) {
+        if (atomicAdd(&lcr_rows_trace_n, 1) < 60) printf("ROWS it %d lane %d tag %d idx %d mine %a first %a\n", it, lane, tag, idx, (double)v, (double)r);
+    }
+}
+#define ROWS_CHK(v, tag, idx) rows_chk(v, lane, has, it, tag, idx)
+#else
+#define ROWS_CHK(v, tag, idx)
+#endif
 template <int NC, int NRW, int NCC>
 DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, unsigned long long pmask, unsigned long long c1mask, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int &sweeps_done) {
     constexpr int NX = coop_nx<1>(), NH = NX * (NX + 1) / 2, NB = coop_nb<1>();
@@ -667,6 +687,10 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
 #pragma unroll
             for (int i = 0; i < NH; i++) Hm[i] = row_sum(Hm[i]);
 #pragma unroll
+            for (int i = 0; i < NH; i++) ROWS_CHK(Hm[i], 0, i);
+#pragma unroll
+            for (int i = 0; i < NX; i++) ROWS_CHK(x[i], 6, i);
+#pragma unroll
             for (int i = 0; i < NX; i++) {
                 float a = 0.f;
 #pragma unroll
@@ -675,20 +699,25 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
             }
 #pragma unroll
             for (int i = 0; i < NX; i++) Hm[tri(i, i)] += mdiag(i);
+#pragma unroll
+            for (int i = 0; i < NX; i++) ROWS_CHK(g[i], 1, i);
+#pragma unroll
+            for (int i = 0; i < NH; i++) ROWS_CHK(Hm[i], 9, i);
             chol_packed<NX>(Hm, hid);
+#pragma unroll
+            for (int i = 0; i < NH; i++) ROWS_CHK(Hm[i], 2, i);
+#pragma unroll
+            for (int i = 0; i < NX; i++) ROWS_CHK(hid[i], 3, i);
 #pragma unroll
             for (int i = 0; i < NX; i++) dx[i] = -g[i];
             solve_packed<NX>(Hm, hid, dx);
 #pragma unroll
-            for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
-            // The row's lanes take the step and the decrement of the row's FIRST lane (ds_bpermute).  What each computed itself from the bit-identical sums above is meant to
-            // be the same -- and was not: traced on the MI355X, the lanes' copies of dx, x, the decrement and the line-search step spread within a row (a row stuck at a
-            // decrement of 5.9e-4 with phi'(0) = +9.4e-5 for 30 iterations: every lane's rows multiplied ITS OWN dx).  Which operation of the replicated factorisation differs
-            // between lanes was not isolated; with the step shared the rows converge like the single-patient solve (tools/ubench/row_sum_check.hip holds the sums).
-            const int src0 = (lane & 48) << 2;
+            for (int i = 0; i < NX; i++) ROWS_CHK(dx[i], 4, i);
 #pragma unroll
-            for (int i = 0; i < NX; i++) dx[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(dx[i])));
-            d0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(d0)));
+            for (int i = 0; i < NX; i++) d0 = fmaf(g[i], dx[i], d0);
+            ROWS_CHK(d0, 5, 0);
+            // (every lane of the row now holds the same dx and d0 to the bit: computed from the same sums by the same instructions.  Until row_sum made its partial sums
+            //  opaque the two halves of a row disagreed in the last bit of phi'(al) -- see there -- and the copies of x drifted apart)
         }
         float dist2 = 0.f;
 #pragma unroll
@@ -790,6 +819,7 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
         }
         if (!conv) al = lo_a > 0.f ? lo_a : hi_a;
         const float step = live ? al : 0.f;
+        ROWS_CHK(step, 7, 0);
 #pragma unroll
         for (int i = 0; i < NX; i++) x[i] = fmaf(step, dx[i], x[i]);
 #pragma unroll
