@@ -379,9 +379,10 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
             D.newton = cfg->solver == LCR_SOLVER_NEWTON ? 1 : 0;
             D.newton_iters = cfg->newton_iters; D.ls_iters = cfg->ls_iters;
             D.newton_tol = (float)cfg->newton_tol; D.ls_tol = (float)cfg->ls_tol;
-            // coupled envs a wave of the Newton kernels solves one by one (lcr_newton_coop.h) before it falls back to the coupled SIMT solves: 4 with one cube (a 12-dim SIMT
-            // iteration costs ~4 cooperative ones), 16 for Stack (its 18-dim SIMT iteration spills 3 KB per lane: profiles/r06_coop_sweep.txt); measurement override: LCR_COOP_MAX (0: never)
-            D.coop_max = cfg->task == LCR_TASK_STACK ? 16 : (loop ? 4 : 8);   // (one cube without rails: four patients per pass, two passes)
+            // coupled envs a wave of the Newton kernels solves cooperatively (lcr_newton_coop.h: four per pass, one per 16-lane row; StackTwoCubes' three-body patients one at a time)
+            // before it falls back to the coupled SIMT solves: 8 with one cube (two passes; flat beyond), 16 with rails and for Stack (PushCubeLoop 5.52 / 4.91 / 4.90 ms at 4 / 8 / 16: the
+            // fall-back's 12-dim SIMT iteration spills; Stack's 18-dim one 3 KB per lane: profiles/r06_coop_sweep.txt, r06_coop_sweep2.txt); measurement override: LCR_COOP_MAX (0: never)
+            D.coop_max = (cfg->task == LCR_TASK_STACK || loop) ? 16 : 8;
             if (const char *cm_ov = getenv("LCR_COOP_MAX")) D.coop_max = atoi(cm_ov) < 0 ? 0 : (atoi(cm_ov) > 64 ? 64 : atoi(cm_ov));
             if (D.newton) { D.coop = 0; D.roll = 1; D.big_lds = 1; }   // the Newton kernels: one wave per 64 envs, six-row finger slots, every g row in LDS (cc8: slots 4-7 of their eight cube<->cube records)
         }

@@ -829,11 +829,19 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             sweeps_done = max(ia, ic);
             float *stage = lds + NEWTON_G_ROWS * LDS_ROW;
             const long long tc0 = P.diag == 2 ? clock64() : 0;
-            for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {
+#ifdef LCR_LOOP_ONE_PER_PASS
+            for (unsigned long long m = cmask; m != 0ull; m &= m - 1ull) {   // (A/B: one patient at a time with all 64 lanes, 19 blocks)
                 const int L = __builtin_ctzll(m);
                 const int ip = coop_solve<NC, NRW, 4, NC, WALLS>(C, stage, lane, L, y, ca, cal);
                 sweeps_done = lane == L ? ip : sweeps_done;
             }
+#else
+            for (unsigned long long m = cmask; m != 0ull;) {   // four patients per pass, one per 16-lane row: 13 contact blocks + the six joint limits in one lane (coop_solve_rows)
+                unsigned long long pm = 0ull;
+                for (int k = 0; k < 4 && m != 0ull; k++) { pm |= m & (0ull - m); m &= m - 1ull; }
+                coop_solve_rows<NC, NRW, 4, WALLS>(C, stage, lane, pm, 0ull, y, ca, cal, sweeps_done);
+            }
+#endif
             if (P.diag == 2) prof_coop = (unsigned)(clock64() - tc0);
         }
         if (P.diag == 2) {

@@ -520,7 +520,8 @@ DEV int coop_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, int lane, in
 // inside the row by DPP (no LDS, no waits), so each row is its own little solve and the rows run the iteration loop together like the lanes of the SIMT solver do: a
 // row that has converged idles (step 0) until the last one has.  The launch time of PushCube / LiftCube / PickPlaceCube was the wave with the most coupled envs (three
 // per substep, 61 cooperative solves per control step): four per pass turn its k solves into ceil(k / 4) -- PushCube 3.31 -> 2.64 ms, PickPlace-ee 3.32 -> 2.53.  StackTwoCubes' arm + ONE cube patients
-// (12 unknowns, the same 15 blocks) are solved here too: 32 768 envs 6.81 -> 6.03 ms.  -DLCR_ROWS_TRACE: every replicated quantity of every iteration is compared with
+// (12 unknowns, the same 15 blocks) are solved here too: 32 768 envs 6.81 -> 6.03 ms.  PushCubeLoop (rails: 19 blocks) fits a row with its six joint limits in ONE lane
+// (LIM1 below): 5.88 -> 4.90 ms.  -DLCR_ROWS_TRACE: every replicated quantity of every iteration is compared with
 // the row's first lane and the first differences are printed (how the re-association in row_sum was found).
 // ================================================================================================
 // sum over the 16 lanes of a row, THE SAME BITS in every lane of the row: every step adds a lane and its partner under an involution (i ^ 1, i ^ 2, mirror of the half
@@ -558,17 +559,25 @@ DEV void rows_chk(float v, int lane, bool has, int it, int tag, int idx) {
 #else
 #define ROWS_CHK(v, tag, idx)
 #endif
-template <int NC, int NRW, int NCC>
-DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int lane, unsigned long long pmask, unsigned long long c1mask, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int &sweeps_done) {
-    constexpr int NX = coop_nx<1>(), NH = NX * (NX + 1) / 2, NB = coop_nb<1>();
+template <int NC, int NRW, int NCC, bool WALLS = false>
+DEV void coop_solve_rows(NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, int lane, unsigned long long pmask, unsigned long long c1mask, float (&y)[6], f3 (&ca)[NC], f3 (&cal)[NC], int &sweeps_done) {
+    // With rails (PushCubeLoop) the patient has 19 blocks: the six joint limits -- blocks of ONE row each -- then share ONE lane (LIM1), whose six rows are six blocks:
+    // 13 contact lanes + 1 limit lane per row.  Its evaluation is per row (f_j = max(0, -z_j / R_j)); its Hessian share has the form of a contact's with av = w_0, no
+    // cone terms and the weights w_1..5 in place of kap m2[r] (kw below), so everything after the evaluation is shared code.
+    constexpr bool LIM1 = WALLS;
+    constexpr int NX = coop_nx<1>(), NH = NX * (NX + 1) / 2, NBR = coop_nb<1, WALLS>(), NBC = NBR - 6, NB = LIM1 ? NBC + 1 : NBR;   // records, contact blocks, lanes in use
+    static_assert(NB <= 16, "a patient's blocks must fit a 16-lane row");
     const NewtonParams &P = C.P;
-    const int row = lane >> 4, b = (lane & 15) < NB ? (lane & 15) : NB - 1;
+    const int row = lane >> 4, li = lane & 15, b = LIM1 ? (li < NBC ? li : NBC - 1) : (li < NB ? li : NB - 1);
+    const bool islim = LIM1 && li == NBC;
     int Lp = 0;           // this row's patient lane
     bool has = false;     // this row has a patient
     f3 dn = mk(0.f, 0.f, 1.f), dt1 = mk(0.f, 1.f, 0.f), dt2 = mk(-1.f, 0.f, 0.f), rc = mk(0.f, 0.f, 0.f);
     float aref[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Rn = 1.f, Rt = 1.f, coef = 0.f, lsign = 0.f, m2t = 0.f, m2s = 0.f, m2r = 0.f;
     bool act = false;
     float x[NX], x0[NX], lrow6[6];
+    float limrow[LIM1 ? 6 : 1][6], lim_iR[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (LIM1, the limit lane: the rows L^-1 (+-e_j) of the active limits, 1 / R_j)
+    bool lim_on[6] = {false, false, false, false, false, false};
 #pragma unroll
     for (int i = 0; i < NX; i++) { x[i] = 0.f; x0[i] = 0.f; }
 #pragma unroll
@@ -577,22 +586,47 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
         int p = 0;
         for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull, p++) {
             const int L = __builtin_ctzll(m);
-            if (lane == L) coop_stage<NC, NRW, NCC, 1, false>(C, stage, y, ca, cal, NC == 2 ? (int)(c1mask >> L & 1ull) : 0);
+            if (lane == L) coop_stage<NC, NRW, NCC, 1, WALLS>(C, stage, y, ca, cal, NC == 2 ? (int)(c1mask >> L & 1ull) : 0);
             lds_fence();
             if (row == p) {
                 const float *r = stage + b * COOP_REC;
-                const float *gs = stage + NB * COOP_REC;
+                const float *gs = stage + NBR * COOP_REC;
                 Lp = L; has = true;
                 dn = mk(r[0], r[1], r[2]); dt1 = mk(r[3], r[4], r[5]); dt2 = mk(r[6], r[7], r[8]); rc = mk(r[9], r[10], r[11]);
 #pragma unroll
                 for (int k = 0; k < 6; k++) aref[k] = r[15 + k];
                 Rn = r[21]; Rt = r[22]; m2t = r[23]; m2s = r[24]; m2r = r[25]; coef = r[26]; lsign = r[29];
-                act = (lane & 15) < NB && r[28] != 0.f;
+                act = (LIM1 ? li < NBC : li < NB) && r[28] != 0.f;
 #pragma unroll
                 for (int i = 0; i < 6; i++) x0[i] = gs[21 + i];
 #pragma unroll
                 for (int i = 0; i < NX; i++) x[i] = gs[27 + i];
-                if (act && b >= NB - 6) {   // a joint limit's row L^-1 (+-e_j)
+                if constexpr (LIM1) {
+                    if (islim) {
+                        float Ls[15], id[6];
+#pragma unroll
+                        for (int k = 0; k < 15; k++) Ls[k] = gs[k];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) id[k] = gs[15 + k];
+                        coef = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            const float *rj = stage + (NBC + j) * COOP_REC;
+                            lim_on[j] = rj[28] != 0.f;
+                            act = act || lim_on[j];
+                            aref[j] = rj[15]; lim_iR[j] = rcp(rj[21]);
+                            const float sg = lim_on[j] ? rj[29] : 0.f;
+#pragma unroll
+                            for (int i = 0; i < 6; i++) {
+                                float sacc = i == j ? sg : 0.f;
+#pragma unroll
+                                for (int k = 0; k < i; k++) sacc = fmaf(-Ls[i * (i - 1) / 2 + k], limrow[j][k], sacc);
+                                limrow[j][i] = sacc * id[i];
+                            }
+                        }
+                    }
+                }
+                if (!LIM1 && act && b >= NB - 6) {   // a joint limit's row L^-1 (+-e_j)
                     const int j = b - (NB - 6);
                     float Ls[15], id[6];
 #pragma unroll
@@ -649,7 +683,7 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
 #pragma unroll
                 for (int k = 0; k < 6; k++) J[q][k] = g6[k];
             }
-        } else if (b >= NB - 6) {
+        } else if (!LIM1 && b >= NB - 6) {
 #pragma unroll
             for (int k = 0; k < 6; k++) J[0][k] = lrow6[k];
         }
@@ -659,7 +693,30 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
             const f3 lin = q < 3 ? coef * d : mk(0.f, 0.f, 0.f), ang = q < 3 ? coef * cross(rc, d) : coef * d;
             J[q][6] = lin.x; J[q][7] = lin.y; J[q][8] = lin.z; J[q][9] = ang.x; J[q][10] = ang.y; J[q][11] = ang.z;
         }
+        if constexpr (LIM1) {
+            if (islim) {
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) J[j][k] = limrow[j][k];
+            }
+        }
     }
+    // this lane's forces and curvature weights at the residuals z: a contact block's cone zone (blk_eval), or -- the limit lane -- six one-row blocks
+    auto eval = [&](const float (&z)[6], BlkEval<6> &B, float (&kw)[6]) {
+        if (!islim) {
+            blk_eval<6>(z, Rn, Rt, m2, act, B);
+#pragma unroll
+            for (int q = 0; q < 6; q++) kw[q] = B.kap * m2[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float w = (lim_on[q] && z[q] < 0.f) ? lim_iR[q] : 0.f;
+                B.f[q] = -z[q] * w; B.c[q] = 0.f; kw[q] = w;
+            }
+            B.av = kw[0]; B.gam = 0.f; B.kap = 0.f;
+        }
+    };
     float scale = fmaf((float)NC * cm, GRAV * GRAV, 1.f);
 #pragma unroll
     for (int j = 0; j < 6; j++) scale = fmaf(x0[j], x0[j], scale);
@@ -679,11 +736,25 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
         float dx[NX], d0 = 0.f;
         {
             BlkEval<6> B;
-            blk_eval<6>(zs, Rn, Rt, m2, act, B);
+            float kw[6];
+            if constexpr (LIM1) eval(zs, B, kw); else blk_eval<6>(zs, Rn, Rt, m2, act, B);
             float Hm[NH], g[NX], hid[NX];
 #pragma unroll
             for (int i = 0; i < NH; i++) Hm[i] = 0.f;
-            h_block<0, NX, NX, 6>(Hm, J, B, m2);
+            if constexpr (LIM1) {   // (h_block with the weights kw[r] in place of kap m2[r])
+                float wv[NX], v[NX];
+#pragma unroll
+                for (int i = 0; i < NX; i++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 1; r < 6; r++) acc = fmaf(B.c[r], J[r][i], acc);
+                    wv[i] = acc; v[i] = J[0][i] - acc;
+                }
+                h_rank1<0, NX, NX>(Hm, v, B.av);
+                h_rank1<0, NX, NX>(Hm, wv, -B.gam);
+#pragma unroll
+                for (int r = 1; r < 6; r++) h_rank1<0, NX, NX>(Hm, J[r], kw[r]);
+            } else h_block<0, NX, NX, 6>(Hm, J, B, m2);
 #pragma unroll
             for (int i = 0; i < NH; i++) Hm[i] = row_sum(Hm[i]);
 #pragma unroll
@@ -741,15 +812,16 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
 #pragma unroll
             for (int q = 0; q < 6; q++) z[q] = fmaf(al, jd[q], zs[q]);
             BlkEval<6> B;
-            blk_eval<6>(z, Rn, Rt, m2, act, B);
+            float kw[6];
+            if constexpr (LIM1) eval(z, B, kw); else blk_eval<6>(z, Rn, Rt, m2, act, B);
             float acc = 0.f, u = 0.f, tt = 0.f;
 #pragma unroll
             for (int q = 0; q < 6; q++) acc = fmaf(B.f[q], jd[q], acc);
 #pragma unroll
-            for (int q = 1; q < 6; q++) { u = fmaf(B.c[q], jd[q], u); tt = fmaf(m2[q] * jd[q], jd[q], tt); }
+            for (int q = 1; q < 6; q++) { u = fmaf(B.c[q], jd[q], u); tt = LIM1 ? fmaf(kw[q] * jd[q], jd[q], tt) : fmaf(m2[q] * jd[q], jd[q], tt); }
             const float sn = jd[0] - u;
             ef = row_sum(acc);
-            eh = row_sum(fmaf(B.av * sn, sn, fmaf(-B.gam * u, u, B.kap * tt)));
+            eh = row_sum(fmaf(B.av * sn, sn, fmaf(-B.gam * u, u, LIM1 ? tt : B.kap * tt)));
         };
         auto kink_cand = [&](float lo, float hi, float sec) -> float {   // (rare)
             float qa = 0.f, qb = 0.f, qc = 0.f;
@@ -761,12 +833,12 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
             const float iqa = rcp(fmaxf(qa, 1e-30f));
             const float am = -qb * iqa;
             const float n2 = fmaxf(fmaf(-qb * qb, iqa, qc), 0.f), wn = fmaf(am, jd[0], zs[0]);
-            const bool ok = act && (lane & 15) < NB - 6 && qa > 0.f && am > lo && am < hi && wn < 0.f && !(n2 * Rn * Rn > wn * wn * Rt * Rt);
+            const bool ok = act && li < NBC && qa > 0.f && am > lo && am < hi && wn < 0.f && !(n2 * Rn * Rn > wn * wn * Rt * Rt);
             const float dist = fabsf(am - sec), okf = ok ? 1.f : 0.f;
             float best = sec;
             for (int rr = 0; rr < 4; rr++) {   // (v_readlane with wave-uniform lane numbers; the row that is meant keeps the result)
                 float bst = sec, bd = -1.f;
-                for (int k = 0; k < NB - 6; k++) {
+                for (int k = 0; k < NBC; k++) {
                     const bool okk = __builtin_amdgcn_readlane(__float_as_int(okf), 16 * rr + k) != 0;
                     const float amk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(am), 16 * rr + k)), dk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dist), 16 * rr + k));
                     const bool take = okk && (bd < 0.f || dk < bd);
@@ -828,7 +900,8 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
     // ---- forces and accelerations back to the patients: [lane][8] forces, then [row][12] x ----
     {
         BlkEval<6> B;
-        blk_eval<6>(zs, Rn, Rt, m2, act, B);
+        float kw[6];
+        if constexpr (LIM1) eval(zs, B, kw); else blk_eval<6>(zs, Rn, Rt, m2, act, B);
 #pragma unroll
         for (int q = 0; q < 6; q++) stage[lane * 8 + q] = B.f[q];
         if ((lane & 15) == 0) {
@@ -852,7 +925,13 @@ DEV void coop_solve_rows(NewtonCtx<NC, NRW, false, NCC> &C, float *stage, int la
 #pragma unroll
                     for (int q = 0; q < 4; q++) { if (second) C.FS[NC - 1][s].f[q] = fr[(5 + s) * 8 + q]; else C.FS[0][s].f[q] = fr[(5 + s) * 8 + q]; }
 #pragma unroll
-                for (int j = 0; j < 6; j++) C.flim[j] = fr[(NB - 6 + j) * 8];
+                for (int j = 0; j < 6; j++) C.flim[j] = LIM1 ? fr[NBC * 8 + j] : fr[(NB - 6 + j) * 8];
+                if constexpr (WALLS) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) C.WS[s].f[q] = fr[(9 + s) * 8 + q];
+                }
                 const float *xr = stage + 512 + p * NX;
 #pragma unroll
                 for (int j = 0; j < 6; j++) y[j] = xr[j];
