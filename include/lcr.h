@@ -142,7 +142,7 @@ typedef enum lcr_solver { LCR_SOLVER_PGS = 0, LCR_SOLVER_NEWTON = 1 } lcr_solver
  * What remains approximate under it: finger pads are boxes fitted to the hull tips and the other arm hulls five sphere proxies (deviation D3), each finger has one
  * world contact (floor or rail), Newton is capped at newton_iters = 30 iterations per substep, fp32 arithmetic.
  * LCR_PRESET_FAST: the rounds 1-4 configuration -- four block projected-gradient sweeps, rolling rows only where they change a step by more than the fp32
- * parity tolerance, four box-box points -- 8 x (ReachCube) to 35 x (StackTwoCubes) the throughput of the default (measured per task: profiles/r06_quick_times.txt)
+ * parity tolerance, four box-box points -- 8 x (ReachCube, PushCubeLoop) to 13 x (StackTwoCubes) the throughput of the default (measured per task: profiles/r06_quick_times.txt)
  * at p90 2e-4 / p99 1e-2 rad per control step from the optimum.  Options of the sweep kernels (step_kernel = 2, pgs_iters < 0,
  * diagnostics = 3, finger_cube_condim = 4) are refused under LCR_SOLVER_NEWTON: set them on a config filled by lcr_config_preset(.., LCR_PRESET_FAST). */
 typedef enum lcr_preset { LCR_PRESET_FAITHFUL = 0, LCR_PRESET_FAST = 1 } lcr_preset;
