@@ -1127,6 +1127,57 @@ def test_newton_kernels_are_deterministic(hip_lib, kernel_family, task, mode):
         s_.close()
 
 
+@pytest.mark.parametrize("task,mode", [("push", "joint"), ("pick_place", "ee"), ("stack", "joint"), ("push_loop", "joint")])
+def test_cooperative_and_simt_solves_agree(hip_lib, kernel_family, monkeypatch, task, mode):
+    """The coupled envs of a wave are solved by three layouts of the same algorithm: the wave-uniform SIMT solve (LCR_COOP_MAX=0: every coupled substep in the SIMT copy),
+    the cooperative solves with the shipped hand-over threshold, and the cooperative solves only (64).  From the same state -- every cube next to its gripper, so that most
+    waves hold several coupled envs --, re-synchronised after every control step, they agree with each other the way each agrees with the oracle."""
+    from gym_lowcostrobot_amd import VecSim
+    from oracle import orc
+
+    if kernel_family != "faithful":
+        pytest.skip("the Newton kernels are the faithful preset's")
+    n = 1024
+    rng = np.random.default_rng(77)
+    sims = []
+    for cm in ("0", None, "64"):
+        if cm is None:
+            monkeypatch.delenv("LCR_COOP_MAX", raising=False)
+        else:
+            monkeypatch.setenv("LCR_COOP_MAX", cm)
+        sims.append(VecSim(task, n, observation_mode="state", action_mode=mode, auto_reset=False, max_episode_steps=0, base_seed=9))
+    monkeypatch.delenv("LCR_COOP_MAX", raising=False)
+    st = sims[0].get_state()
+    q, qd = util.random_arm_state(rng, n, scale_v=1.0)
+    st["qpos"][:6] = q.T; st["qvel"][:6] = qd.T
+    for e in range(n):
+        lp, _, _ = orc.fk(q[e])
+        st["qpos"][6:9, e] = lp[4] + rng.normal(0, 0.012, 3)
+    st["qpos"][8] = np.maximum(st["qpos"][8], 0.0149)
+    st["warm"][:] = 0
+    for s_ in sims:
+        s_.set_state(**st)
+    differ = 0
+    for t in range(5):
+        a = (0.5 * rng.uniform(-1, 1, (n, sims[0].action_dim))).astype(np.float32)
+        for s_ in sims:
+            s_.step(a)
+        sts = [s_.get_state() for s_ in sims]
+        assert np.isfinite(sts[1]["qpos"]).all()
+        for other in (sts[0], sts[2]):
+            dq = np.abs(other["qpos"][: sims[0].nq] - sts[1]["qpos"][: sims[0].nq]).max(0)
+            dv = np.abs(other["qvel"] - sts[1]["qvel"]).max(0)
+            # (the tolerance of the parity tests against the oracle; an env outside it met a contact decision -- a slot switching in another substep -- differently)
+            assert np.mean((dq <= 4e-5) & (dv <= 4e-3)) >= 0.98, (task, t, np.sort(dq)[-5:], np.sort(dv)[-5:])
+            assert dq.max() <= 3e-2, (task, t, np.sort(dq)[-5:])
+            differ += int((dq > 0).sum())
+        for s_ in (sims[0], sims[2]):
+            s_.set_state(**sts[1])
+    assert differ > 0   # the layouts were really different code paths (their roundings differ)
+    for s_ in sims:
+        s_.close()
+
+
 def test_zz_outlier_census(hip_lib):
     """(runs last in this file) every out-of-tolerance env seen by the parity loops above differed from the oracle in its
     active set; print the census"""
