@@ -404,7 +404,11 @@ def main():
                                 + ("; the two-waves-per-SIMD build of the two-wave kernels also spills ~30 registers of its cube wave at the 256-register cap "
                                    "(scratch: written once and read once per step, ~0.25 KB per env-step) and hands 42 floats per env from the cube wave to the arm wave "
                                    "through a global record in substeps with a finger on a cube" if "two waves per SIMD" in sim.step_kernel_family else ""),
-                "note": "state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick",
+                "note": ("state-only step is VALU/latency-bound by construction (SURVEY.md 8(d)); HBM is the mandated yard-stick" if args.obs == "state" else
+                         "the frames of step k are ray-cast on a second stream while the step kernel of step k + 1 runs (lcr.h: lcr_step; LCR_RENDER_OVERLAP=0 serialises them): "
+                         "kernel_ms is the period of a control step -- HIP events on the launch stream, which waits for the last frames before the closing event --, "
+                         "not the sum of the two kernels' durations"),
+                "frames_overlap_step_kernel": bool(args.obs != "state" and os.environ.get("LCR_RENDER_OVERLAP", "1") != "0"),
             },
             "state_finite": finite,
             "calibration_bytes_per_launch": calib_bytes or None,

@@ -89,7 +89,25 @@ struct lcr_sim {
     // lcr_fetch_host: pinned host mirror of the arena range [qpos .. did_reset] (+ terminal observations)
     size_t fetch_bytes, tobs_off, tobs_bytes;
     char *host_mirror;
+    // image observations: the frames of step k are ray-cast on a second stream from a snapshot of the poses while the step kernel of step k + 1 runs (lcr_step).  The
+    // step kernel is VALU-bound and ends with a tail of few slow waves, the frame kernel is HBM-write-bound: together they take little more than the longer one.
+    // Every other entry point first makes the caller's stream wait for the pending frames (join_render), so nothing but lcr_step sees the second stream.
+    hipStream_t rstream;         // null: frames on the caller's stream, after the step kernel (LCR_RENDER_OVERLAP=0)
+    hipEvent_t ev_snap[2], ev_rdone[2];
+    float *snap_qpos[2], *snap_target[2];
+    bool snap_used[2];
+    int rpar, rlast;
+    bool rpending;
 };
+
+static int join_render(lcr_sim *s) {
+    if (s->rpending) {
+        hipError_t e = hipStreamWaitEvent(s->stream, s->ev_rdone[s->rlast], 0);
+        if (e != hipSuccess) return (int)e;
+        s->rpending = false;
+    }
+    return 0;
+}
 
 extern "C" {
 
@@ -452,6 +470,18 @@ int lcr_create(const lcr_config *cfg, lcr_sim **out) {
     }
     e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) { (void)hipFree(s->arena); delete s; return fail(LCR_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e)); }
+    // the second stream of the frames (see lcr_sim); LCR_RENDER_OVERLAP=0: frames on the caller's stream, after the step kernel (A/B, profiling of one kernel at a time)
+    const char *ro = getenv("LCR_RENDER_OVERLAP");
+    if (s->has_images && !(ro && atoi(ro) == 0)) {
+        e = hipStreamCreateWithFlags(&s->rstream, hipStreamNonBlocking);
+        for (int p = 0; p < 2 && e == hipSuccess; p++) {
+            e = hipEventCreateWithFlags(&s->ev_snap[p], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_rdone[p], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->snap_qpos[p], sizeof(float) * (size_t)s->nq * N);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->snap_target[p], sizeof(float) * 3 * N);
+        }
+        if (e != hipSuccess) { lcr_destroy(s); return fail(LCR_ERR_HIP, "setting up the frame stream failed: %s", hipGetErrorString(e)); }
+    }
     *out = s;
     return LCR_OK;
 }
@@ -460,6 +490,14 @@ void lcr_destroy(lcr_sim *s) {
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipStreamSynchronize(s->stream);
+    if (s->rstream) {
+        (void)hipStreamSynchronize(s->rstream);
+        for (int p = 0; p < 2; p++) {
+            (void)hipEventDestroy(s->ev_snap[p]); (void)hipEventDestroy(s->ev_rdone[p]);
+            (void)hipFree(s->snap_qpos[p]); (void)hipFree(s->snap_target[p]);
+        }
+        (void)hipStreamDestroy(s->rstream);
+    }
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     if (s->render_dev) (void)hipFree(s->render_dev);
@@ -469,9 +507,12 @@ void lcr_destroy(lcr_sim *s) {
     delete s;
 }
 
-#define SIMCHK(s)                                             \
+#define SIMCHK_NOJOIN(s)                                      \
     if (!(s)) return fail(LCR_ERR_INVALID, "sim is NULL"); \
     HIPCHK(hipSetDevice((s)->cfg.device))
+#define SIMCHK(s)       \
+    SIMCHK_NOJOIN(s);   \
+    if (int jr_ = join_render(s)) return fail(LCR_ERR_HIP, "waiting for the frame kernel failed: %s", hipGetErrorString((hipError_t)jr_))
 
 int lcr_step_kernel_family(lcr_sim *s) {
     if (!s) return fail(LCR_ERR_INVALID, "sim is NULL");
@@ -480,6 +521,7 @@ int lcr_step_kernel_family(lcr_sim *s) {
 
 int lcr_set_stream(lcr_sim *s, void *hip_stream) {
     SIMCHK(s);
+    if (s->rstream) HIPCHK(hipStreamSynchronize(s->rstream));   // (nothing of the old stream's frames is in flight when the new stream takes over)
     s->stream = (hipStream_t)hip_stream;
     return LCR_OK;
 }
@@ -507,11 +549,27 @@ int lcr_reset(lcr_sim *s, const uint8_t *mask_host, const uint64_t *seeds_host) 
 }
 
 int lcr_step(lcr_sim *s, const float *action_dev) {
-    SIMCHK(s);
+    SIMCHK_NOJOIN(s);
     if (!action_dev) return fail(LCR_ERR_INVALID, "action is NULL");
     int rc = lcr_launch_step(s->dev, action_dev, s->ee_mode, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (s->has_images) {
+    if (s->has_images && s->rstream) {
+        // the frame kernel reads qpos and target only: snapshot them (2.7 MB for 32 768 StackTwoCubes envs against 15 GB of frames), then ray-cast on the second stream while
+        // this stream goes on with the next step.  Two snapshots in turn; the one about to be overwritten was read by the frames of two steps ago.
+        const int p = s->rpar;
+        const size_t N = (size_t)s->dev.n;
+        if (s->snap_used[p]) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_rdone[p], 0));
+        HIPCHK(hipMemcpyAsync(s->snap_qpos[p], s->dev.qpos, sizeof(float) * (size_t)s->nq * N, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->snap_target[p], s->dev.target, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipEventRecord(s->ev_snap[p], s->stream));
+        HIPCHK(hipStreamWaitEvent(s->rstream, s->ev_snap[p], 0));
+        LcrDev R = s->dev;
+        R.qpos = s->snap_qpos[p]; R.target = s->snap_target[p];
+        rc = lcr_launch_render_obs(R, s->cam_front, s->cam_top, s->rstream);
+        if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
+        HIPCHK(hipEventRecord(s->ev_rdone[p], s->rstream));
+        s->snap_used[p] = true; s->rpending = true; s->rlast = p; s->rpar = p ^ 1;
+    } else if (s->has_images) {
         rc = lcr_launch_render_obs(s->dev, s->cam_front, s->cam_top, s->stream);
         if (rc) return fail(LCR_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
@@ -691,7 +749,7 @@ int lcr_timer_end(lcr_sim *s, float *ms_out) {
 }
 
 int lcr_fill_random_actions(lcr_sim *s, float *action_dev, uint64_t seed, uint64_t step) {
-    SIMCHK(s);
+    SIMCHK_NOJOIN(s);   // (writes the caller's action buffer only)
     if (!action_dev) return fail(LCR_ERR_INVALID, "action is NULL");
     int rc = lcr_launch_fill_actions(action_dev, s->dev.n, s->k, s->dev.env_off, seed, step, s->stream);
     if (rc) return fail(LCR_ERR_HIP, "fill kernel launch failed: %s", hipGetErrorString((hipError_t)rc));

@@ -224,7 +224,7 @@ int lcr_step_kernel_family(lcr_sim *sim);
 
 /* HIP stream (hipStream_t passed as void*) all later work is enqueued on; NULL = default stream. */
 int lcr_set_stream(lcr_sim *sim, void *hip_stream);
-int lcr_sync(lcr_sim *sim); /* hipStreamSynchronize on the handle's stream */
+int lcr_sync(lcr_sim *sim); /* hipStreamSynchronize on the handle's stream (after making it wait for frames still being ray-cast, see lcr_step) */
 
 /* == reset(seed) (reach_cube_env.py:297-311, push:308-328, pick_place:316-336, stack:307-324).
  * mask_host: N bytes, nonzero = reset that env, NULL = all.  seeds_host: N uint64, env i is re-seeded
@@ -233,7 +233,11 @@ int lcr_sync(lcr_sim *sim); /* hipStreamSynchronize on the handle's stream */
 int lcr_reset(lcr_sim *sim, const uint8_t *mask_host, const uint64_t *seeds_host);
 
 /* == step(action) (reach_cube_env.py:313-333) for all envs: apply_action (joint or ee+IK) -> 20 physics
- * substeps -> reward / terminated / truncated -> fused auto-reset.  action_dev: [k][N] float32. */
+ * substeps -> reward / terminated / truncated -> fused auto-reset.  action_dev: [k][N] float32.
+ * Asynchronous.  With image observations the two frames of every env are ray-cast on a second, internal stream from a snapshot of the poses, so that the step kernel of
+ * the NEXT lcr_step overlaps them (BASELINE config 5: 9.7 -> see DESIGN.md section 3.4).  Every other entry point of this API first makes the handle's stream wait for
+ * those frames; a caller that reads lcr_obs_view.image_* with its own kernels on the handle's stream calls lcr_sync (or any other entry point) first.
+ * LCR_RENDER_OVERLAP=0 in the environment: frames on the handle's stream, after the step kernel. */
 int lcr_step(lcr_sim *sim, const float *action_dev);
 /* Convenience for host callers (single-env facade): copies [k][N] host floats then steps. */
 int lcr_step_host(lcr_sim *sim, const float *action_host);

@@ -1178,6 +1178,57 @@ def test_cooperative_and_simt_solves_agree(hip_lib, kernel_family, monkeypatch, 
         s_.close()
 
 
+@pytest.mark.parametrize("task,mode", [("stack", "joint"), ("pick_place", "ee")])
+def test_frames_on_the_second_stream_are_the_serial_frames(hip_lib, monkeypatch, task, mode):
+    """lcr_step ray-casts the frames on a second stream from a snapshot of the poses while the next step kernel runs (lcr.h).  Bit-identical to frames rendered on the
+    caller's stream after each step kernel (LCR_RENDER_OVERLAP=0): after back-to-back asynchronous steps -- the last frames --, after every single step, across auto-resets
+    and a masked reset in between, on the default stream and on a stream of the caller's."""
+    import torch
+    from gym_lowcostrobot_amd import VecSim
+
+    n = 192
+    monkeypatch.setenv("LCR_RENDER_OVERLAP", "0")
+    ref = VecSim(task, n, observation_mode="both", action_mode=mode, base_seed=3, max_episode_steps=7)
+    monkeypatch.delenv("LCR_RENDER_OVERLAP")
+    ovl = VecSim(task, n, observation_mode="both", action_mode=mode, base_seed=3, max_episode_steps=7)
+    acts = [(s_, s_.alloc_actions()) for s_ in (ref, ovl)]
+
+    def same():
+        for k in ("image_front", "image_top"):
+            np.testing.assert_array_equal(getattr(ref, k).numpy(), getattr(ovl, k).numpy(), err_msg=k)
+        a, b = ref.get_state(), ovl.get_state()
+        np.testing.assert_array_equal(a["qpos"], b["qpos"])
+
+    same()
+    t = 0
+    for burst in (1, 1, 9, 3, 12):          # episodes end every 7 steps: auto-resets fall inside the bursts
+        for _ in range(burst):
+            for s_, a in acts:
+                s_.fill_random_actions(a, 5, t); s_.step_device(a.ptr)
+            t += 1
+        same()
+    assert ref.image_front.numpy().std() > 1.0
+    m = (np.arange(n) % 3 == 0).astype(np.uint8)
+    for s_, a in acts:
+        s_.reset(mask=m, seeds=np.arange(n, dtype=np.uint64) + 100)
+    same()
+    stream = torch.cuda.Stream()
+    for s_, a in acts:
+        s_.set_stream(stream.cuda_stream)
+    for _ in range(6):
+        for s_, a in acts:
+            s_.fill_random_actions(a, 5, t); s_.step_device(a.ptr)
+        t += 1
+    same()
+    ids = np.nonzero(ovl.did_reset.numpy())[0]
+    if ids.size:   # terminal frames of the envs the last step reset
+        fa, fb = ref.render_terminal(ids), ovl.render_terminal(ids)
+        for x, y in zip(fa, fb):
+            np.testing.assert_array_equal(x, y)
+    for s_, a in acts:
+        s_.free(a); s_.close()
+
+
 def test_zz_outlier_census(hip_lib):
     """(runs last in this file) every out-of-tolerance env seen by the parity loops above differed from the oracle in its
     active set; print the census"""
