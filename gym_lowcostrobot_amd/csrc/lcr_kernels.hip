@@ -52,6 +52,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     static_assert(CPL == CPL_BOTH || NEWTON, "two copies of the substep: the Newton kernels");
     constexpr int NCC = NEWTON ? 8 : 4;   // cube<->cube manifold points (Stack): the Newton kernels carry eight slots, 4-7 in use with lcr_config.cc_points = 8
     constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();   // first LDS row of the cube<->cube records
+    constexpr int CCR = NEWTON ? CC_REC_NEWTON : CC_REC, CCRN = NEWTON ? CC_RN_NEWTON : 15;   // floats of a cube<->cube record, index of its Rn
     constexpr int NRW = ROLL ? 6 : 4;   // rows an arm slot may have
     Diag DG = {0u, 0u, 0u, 0u};   // this substep's share
     using namespace lcrm;
@@ -272,7 +273,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
     int cc_count = 0;       // (Stack) cube<->cube points of this lane
     bool coupled = false;   // (NEWTON) bodies of this lane's env touch -- its arm a cube, cube on cube --: they are ONE problem
     f3 ccn = mk(0.f, 0.f, 1.f), cct1 = mk(0.f, 1.f, 0.f), cct2 = mk(-1.f, 0.f, 0.f);
-    float *ccl = lds + CCB * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CC_REC + k)*64]
+    float *ccl = lds + CCB * LDS_ROW + lane;   // Stack: record field k of slot s at ccl[(s*CCR + k)*64]
     const size_t CS = 64;
     if constexpr (NC == 2) {
         const f3 dc = S.cp[1] - S.cp[0];
@@ -401,7 +402,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 float Rt = Rf * P.rt_cube;
                 f3 vrel = (S.cv[1] + cross(cww[1], r1)) - (S.cv[0] + cross(cww[0], r0));
                 f3 wrel = cww[1] - cww[0];
-                ccl[(size_t)(s * CC_REC + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CC_REC + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CC_REC + 2) * CS] = cpos[s].z;
+                ccl[(size_t)(s * CCR + 0) * CS] = cpos[s].x; ccl[(size_t)(s * CCR + 1) * CS] = cpos[s].y; ccl[(size_t)(s * CCR + 2) * CS] = cpos[s].z;
                 float ccLn = 1.f, ccLt = 0.f;   // metric of the block step (soc_step)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -413,25 +414,25 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     else diag = 2.f * iinv;
                     float Rr = r == 0 ? Rn : (r == 3 ? Rt : Rf);
                     {   // f: keep the previous substep's force if the slot was active then, and apply it
-                        float fw = (cc_act[s] && W.cc_prev[s]) ? ccl[(size_t)(s * CC_REC + 3 + r) * CS] : 0.f;
-                        ccl[(size_t)(s * CC_REC + 3 + r) * CS] = fw;
+                        float fw = (cc_act[s] && W.cc_prev[s]) ? ccl[(size_t)(s * CCR + 3 + r) * CS] : 0.f;
+                        ccl[(size_t)(s * CCR + 3 + r) * CS] = fw;
                         if (r < 3) {
                             f3 a0 = cross(r0, d), a1 = cross(r1, d);
                             ca[1] = axpy(minv * fw, d, ca[1]); ca[0] = axpy(-minv * fw, d, ca[0]);
                             cal[1] = axpy(iinv * fw, a1, cal[1]); cal[0] = axpy(-iinv * fw, a0, cal[0]);
                         } else { cal[1] = axpy(iinv * fw, d, cal[1]); cal[0] = axpy(-iinv * fw, d, cal[0]); }
                     }
-                    ccl[(size_t)(s * CC_REC + 7 + r) * CS] = aref;
+                    ccl[(size_t)(s * CCR + 7 + r) * CS] = aref;
                     if (r == 0) ccLn = 2.f * (diag + Rr); else ccLt = fmaf(2.f * (r == 3 ? P.mu_ct2 : P.mu_c2), diag + Rr, ccLt);
                 }
-                {   // k[] of soc_step in the record's four "inverse diagonal" fields
+                if constexpr (!NEWTON) {   // k[] of soc_step in the record's four "inverse diagonal" fields
                     const float iLt = cc_act[s] ? rcp(ccLt) : 0.f;
-                    ccl[(size_t)(s * CC_REC + 11) * CS] = cc_act[s] ? rcp(ccLn) : 0.f;
-                    ccl[(size_t)(s * CC_REC + 12) * CS] = P.mu_c2 * iLt;
-                    ccl[(size_t)(s * CC_REC + 13) * CS] = ccLn * rcp(ccLn + ccLt);
-                    ccl[(size_t)(s * CC_REC + 14) * CS] = P.mu_ct2 * iLt;
+                    ccl[(size_t)(s * CCR + 11) * CS] = cc_act[s] ? rcp(ccLn) : 0.f;
+                    ccl[(size_t)(s * CCR + 12) * CS] = P.mu_c2 * iLt;
+                    ccl[(size_t)(s * CCR + 13) * CS] = ccLn * rcp(ccLn + ccLt);
+                    ccl[(size_t)(s * CCR + 14) * CS] = P.mu_ct2 * iLt;
                 }
-                ccl[(size_t)(s * CC_REC + 15) * CS] = Rn;
+                ccl[(size_t)(s * CCR + CCRN) * CS] = Rn;
             }
         }
     }
@@ -821,7 +822,7 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                 C.enable = !coupled ? 7 : (pair0 ? 4 : (pair1 ? 2 : 0));
                 i1 = newton_solve<NC, NRW, false, NCC, 1>(C, y, ca, cal); i2 = newton_solve<NC, NRW, false, NCC, 2>(C, y, ca, cal);
                 i3 = newton_solve<NC, NRW, false, NCC, 4>(C, y, ca, cal);
-                float *stage = lds + NEWTON_G_ROWS * LDS_ROW + 8 * CC_REC * 64;
+                float *stage = lds + NEWTON_G_ROWS * LDS_ROW + 8 * CCR * 64;
                 const long long tc0 = P.diag == 2 ? clock64() : 0;
                 prof_patients = __popcll(cmask);
                 const unsigned long long m0 = __ballot(pair0), m1 = __ballot(pair1);
@@ -1071,17 +1072,17 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
             if (cc_any) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const f3 pos = mk(ccl[(size_t)(s * CC_REC + 0) * CS], ccl[(size_t)(s * CC_REC + 1) * CS], ccl[(size_t)(s * CC_REC + 2) * CS]);
+                    const f3 pos = mk(ccl[(size_t)(s * CCR + 0) * CS], ccl[(size_t)(s * CCR + 1) * CS], ccl[(size_t)(s * CCR + 2) * CS]);
                     const f3 r0 = pos - S.cp[0], r1 = pos - S.cp[1];
-                    const float Rn = ccl[(size_t)(s * CC_REC + 15) * CS];
+                    const float Rn = ccl[(size_t)(s * CCR + CCRN) * CS];
                     const float Rf = Rn * P.inv_impratio;
                     const float Rt = Rf * P.rt_cube;
                     float f[4], aref[4], inv[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        f[r] = ccl[(size_t)(s * CC_REC + 3 + r) * CS];
-                        aref[r] = ccl[(size_t)(s * CC_REC + 7 + r) * CS];
-                        inv[r] = ccl[(size_t)(s * CC_REC + 11 + r) * CS];
+                        f[r] = ccl[(size_t)(s * CCR + 3 + r) * CS];
+                        aref[r] = ccl[(size_t)(s * CCR + 7 + r) * CS];
+                        inv[r] = ccl[(size_t)(s * CCR + 11 + r) * CS];
                     }
                     // relative acceleration of the contact point (cube 1 minus cube 0) and relative angular acceleration
                     const f3 A = (ca[1] + cross(cal[1], r1)) - (ca[0] + cross(cal[0], r0));
@@ -1095,8 +1096,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
                     soc_step<4>(f, uu, inv, P.inv_mu_c2, P.inv_mu_ct2, 0.f, 4, nf);   // one projected-gradient step of the block (lcr_step_common.h)
                     const float d0 = nf[0] - f[0], e1 = nf[1] - f[1], e2 = nf[2] - f[2], e3 = nf[3] - f[3];
                     track(d0, e1, e2, e3, nf[0], nf[1], nf[2], nf[3]);
-                    ccl[(size_t)(s * CC_REC + 3) * CS] = nf[0]; ccl[(size_t)(s * CC_REC + 4) * CS] = nf[1];
-                    ccl[(size_t)(s * CC_REC + 5) * CS] = nf[2]; ccl[(size_t)(s * CC_REC + 6) * CS] = nf[3];
+                    ccl[(size_t)(s * CCR + 3) * CS] = nf[0]; ccl[(size_t)(s * CCR + 4) * CS] = nf[1];
+                    ccl[(size_t)(s * CCR + 5) * CS] = nf[2]; ccl[(size_t)(s * CCR + 6) * CS] = nf[3];
                     // a += M^-1 J^T delta: the force change F acts at the contact point on cube 1 and, negated, on cube 0
                     const f3 Fd = axpy(d0, ccn, axpy(e1, cct1, e2 * cct2));
                     const f3 T1 = axpy(e3, ccn, cross(r1, Fd)), T0 = axpy(e3, ccn, cross(r0, Fd));
@@ -1203,7 +1204,8 @@ DEV bool substep(const LcrDev &P, EnvState<NC> &S, const float (&ctrl)[6], float
 // ------------------------------------------------------------------------------------------------
 template <int NC, bool EE, bool ADAPT, bool ROLL, bool BIG, bool NEWTON = false>
 __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__restrict__ action) {
-    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CC_REC * 64 : 0) + coop_floats<NC>() : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records = 74 KiB)
+    constexpr int CCR = NEWTON ? CC_REC_NEWTON : CC_REC;
+    __shared__ float lds[NEWTON ? NEWTON_G_ROWS * LDS_ROW + (NC == 2 ? 8 * CCR * 64 : 0) + coop_floats<NC>() : LdsSize<NC, false, ROLL, BIG>::value];   // (NEWTON: 4 x 6 + 4 g rows = 42 KiB per wave, + eight cube<->cube records of 12 floats = 66 KiB)
     constexpr int NCC = NEWTON ? 8 : 4;
     constexpr int CCB = NEWTON ? NEWTON_G_ROWS : cc_base_rows<NC, BIG, ROLL>();
     const int lane = threadIdx.x;
@@ -1319,7 +1321,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
         for (int s = 0; s < NCC; s++) {
             W.cc_prev[s] = wld(s < 4 ? WARM_CCPREV + s : WARM_CCPREV2 + (s - 4)) != 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CC_REC + 3 + r) * 64] = wld(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r);
+            for (int r = 0; r < 4; r++) ccl[(size_t)(s * CCR + 3 + r) * 64] = wld(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r);
         }
     }
     Diag DG = {0u, 0u, 0u, 0u};
@@ -1435,7 +1437,7 @@ __global__ __launch_bounds__(64) void lcr_step_kernel(LcrDev P, const float *__r
             for (int s = 0; s < NCC; s++) {
                 wst(s < 4 ? WARM_CCPREV + s : WARM_CCPREV2 + (s - 4), W.cc_prev[s] ? 1.f : 0.f);
 #pragma unroll
-                for (int r = 0; r < 4; r++) wst(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r, W.cc_prev[s] ? ccl[(size_t)(s * CC_REC + 3 + r) * 64] : 0.f);
+                for (int r = 0; r < 4; r++) wst(s < 4 ? WARM_CC + 4 * s + r : WARM_CC2 + 4 * (s - 4) + r, W.cc_prev[s] ? ccl[(size_t)(s * CCR + 3 + r) * 64] : 0.f);
             }
         }
     }

@@ -164,7 +164,7 @@ struct NewtonCtx {
     FloorSlot (&WS)[4];          // PushCubeLoop rails (lcr_kernels_loop.hip), pair coordinates
     const float (&wsg)[2];
     bool wall_any;
-    float *ccl;                  // StackTwoCubes: cube<->cube records in LDS, field k of slot s at ccl[(s * CC_REC + k) * 64]
+    float *ccl;                  // StackTwoCubes: cube<->cube records in LDS, field k of slot s at ccl[(s * CC_REC_NEWTON + k) * 64]
     const bool (&cc_act)[NCC];
     bool cc_any;
     f3 ccn, cct1, cct2;
@@ -331,7 +331,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
             row[q][o + 0] = lin.x; row[q][o + 1] = lin.y; row[q][o + 2] = lin.z; row[q][o + 3] = ang.x; row[q][o + 4] = ang.y; row[q][o + 5] = ang.z;
         }
     };
-    auto cc_pos = [&](int s) -> f3 { return mk(C.ccl[(size_t)(s * CC_REC + 0) * 64], C.ccl[(size_t)(s * CC_REC + 1) * 64], C.ccl[(size_t)(s * CC_REC + 2) * 64]); };
+    auto cc_pos = [&](int s) -> f3 { return mk(C.ccl[(size_t)(s * CC_REC_NEWTON + 0) * 64], C.ccl[(size_t)(s * CC_REC_NEWTON + 1) * 64], C.ccl[(size_t)(s * CC_REC_NEWTON + 2) * 64]); };
     auto cc_rows = [&](int s, float (&row)[4][NX]) {
         const f3 pos = cc_pos(s);
         cube_rows(CubeFrame{C.ccn, C.cct1, C.cct2, pos - C.cp[NC - 1]}, NC - 1, 1.f, row, true);
@@ -405,7 +405,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
                     cc_rows(s, row);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        float a = SUB ? -C.ccl[(size_t)(s * CC_REC + 7 + q) * 64] : 0.f;
+                        float a = SUB ? -C.ccl[(size_t)(s * CC_REC_NEWTON + 7 + q) * 64] : 0.f;
 #pragma unroll
                         for (int i = 0; i < NX; i++) { if (i >= OC[0]) a = fmaf(row[q][i], v[i], a); }
                         out[Z_CC + 4 * s + q] = a;
@@ -479,7 +479,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         if constexpr (HAS_CC) {
             if (C.cc_any) {
 #pragma unroll
-                for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC + 15) * 64], C.cc_act[s], Z_CC + 4 * s);
+                for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC_NEWTON + CC_RN_NEWTON) * 64], C.cc_act[s], Z_CC + 4 * s);
             }
         }
         return LsVal{acc, hac};
@@ -534,7 +534,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
         if constexpr (HAS_CC) {
             if (C.cc_any) {
 #pragma unroll
-                for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC + 15) * 64], C.cc_act[s], Z_CC + 4 * s);
+                for (int s = 0; s < NCC; s++) cube_con(C.ccl[(size_t)(s * CC_REC_NEWTON + CC_RN_NEWTON) * 64], C.cc_act[s], Z_CC + 4 * s);
             }
         }
         return best;
@@ -663,7 +663,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
 #pragma unroll
                 for (int s = 0; s < NCC; s++) {
                     const float m2[4] = {1.f, P.mu_c2, P.mu_c2, P.mu_ct2};
-                    const float Rn = C.ccl[(size_t)(s * CC_REC + 15) * 64];
+                    const float Rn = C.ccl[(size_t)(s * CC_REC_NEWTON + CC_RN_NEWTON) * 64];
                     float z[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) z[q] = zs[Z_CC + 4 * s + q];
@@ -671,7 +671,7 @@ DEV int newton_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float (&y)[6], f3 (&ca)[
                     blk_eval<4>(z, Rn, Rn * P.inv_impratio * P.mu_c2, m2, C.cc_act[s], B);
                     if (OUT) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC + 3 + q) * 64] = B.f[q];
+                        for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC_NEWTON + 3 + q) * 64] = B.f[q];
                         continue;
                     }
                     float row[4][NX];

@@ -115,11 +115,11 @@ DEV void coop_stage(const NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, const
 #pragma unroll
         for (int s = 0; s < NCC; s++) {
             const bool act = C.cc_any && C.cc_act[s];
-            const f3 pos = act ? mk(C.ccl[(size_t)(s * CC_REC + 0) * 64], C.ccl[(size_t)(s * CC_REC + 1) * 64], C.ccl[(size_t)(s * CC_REC + 2) * 64]) : zero3;
+            const f3 pos = act ? mk(C.ccl[(size_t)(s * CC_REC_NEWTON + 0) * 64], C.ccl[(size_t)(s * CC_REC_NEWTON + 1) * 64], C.ccl[(size_t)(s * CC_REC_NEWTON + 2) * 64]) : zero3;
             float aref[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) aref[q] = act ? C.ccl[(size_t)(s * CC_REC + 7 + q) * 64] : 0.f;
-            const float Rn = act ? C.ccl[(size_t)(s * CC_REC + 15) * 64] : 1.f;
+            for (int q = 0; q < 4; q++) aref[q] = act ? C.ccl[(size_t)(s * CC_REC_NEWTON + 7 + q) * 64] : 0.f;
+            const float Rn = act ? C.ccl[(size_t)(s * CC_REC_NEWTON + CC_RN_NEWTON) * 64] : 1.f;
             rec(13 + s, C.ccn, C.cct1, C.cct2, pos - C.cp[0], pos - C.cp[NC - 1], aref, 4, Rn, Rn * P.inv_impratio * P.mu_c2, P.mu_c2, P.mu_ct2, 0.f, -1.f, 1.f, act, 0.f);
         }
     }
@@ -491,7 +491,7 @@ DEV int coop_solve(NewtonCtx<NC, NRW, WALLS, NCC> &C, float *stage, int lane, in
 #pragma unroll
                     for (int s = 0; s < NCC; s++)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC + 3 + q) * 64] = stage[(13 + s) * 8 + q];
+                        for (int q = 0; q < 4; q++) C.ccl[(size_t)(s * CC_REC_NEWTON + 3 + q) * 64] = stage[(13 + s) * 8 + q];
                 }
             }
             if constexpr (WALLS) {

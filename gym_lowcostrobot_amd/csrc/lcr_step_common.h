@@ -340,6 +340,7 @@ constexpr int LDS_ROW = 6 * 64;            // one g row for 64 lanes
 constexpr int LDS_G_FLOATS = AS_TOTAL_ROWS * LDS_ROW;  // 20 rows -> 30 KiB per wave (4 waves per CU: 120 of 160 KiB)
 // Stack only: cube<->cube contact records, 4 slots x 16 floats per lane: pos3 f4 aref4 inv4 Rn (LDS, see LdsSize)
 constexpr int CC_REC = 16;
+constexpr int CC_REC_NEWTON = 12, CC_RN_NEWTON = 11;   // the Newton kernels keep no inverse-diagonal fields (11-14 of the sweep kernels' record): pos 0-2, force 3-6, aref 7-10, Rn 11 -- 8 KiB less LDS per StackTwoCubes wave
 // The per-substep constants of the floor<->cube slots of cube 0 (aref[4], inv[4]: written once per substep, read once per PGS
 // sweep) are parked in LDS as 16-B vectors instead of occupying 32 registers across the whole solver loop:
 // [slot 0..3][aref|inv][lane][4] = 8 KiB per wave (30 + 8 = 38 of the 40 KiB a wave may use at four waves per CU).
