@@ -201,6 +201,12 @@ typedef struct lcr_host_view {
     const float *terminal_obs;  /* [18][N], copied only when any_reset */
 } lcr_host_view;
 
+/* Environment variables the library reads (measurement / A-B overrides, none needed in production; all read at lcr_create unless stated):
+ *   LCR_COOP_MAX=n        Newton kernels: coupled envs per wave solved cooperatively before the wave falls back to the coupled SIMT solves (default 8; 16 for
+ *                         StackTwoCubes and PushCubeLoop; 0 = never cooperatively)
+ *   LCR_RENDER_OVERLAP=0  image observations: frames on the handle's stream after the step kernel instead of on the second stream (see lcr_step)
+ *   LCR_STEP_KERNEL=single|coop1|coop2, LCR_STACK_LDS=small|big   sweep kernels (LCR_PRESET_FAST): pin a kernel family / LDS variant
+ *   LCR_RENDER_COUNT=1    frame kernel: count ray-cast passes into the diagnostics arrays (tools/render_work.py; read at the first frame launch) */
 int lcr_abi_version(void);
 const char *lcr_last_error(void);
 
